@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py - MB/s of input for the suffix-array build on uniform-random bytes (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W [--size BYTES] [--workload random|text|dna]
+
+A "step" is one complete suffix-array build (16-bit radix histogram, two 8-bit scatter levels, LDS bucket
+sorts, refinement rounds) of one synthetic input that is already resident in HBM.  N = 1: the whole
+array on one MI355X.  N > 1 (launched by torch.distributed.run, one rank per GPU): the 16-bit key space
+is split into N count-balanced ranges, every rank sorts its range into its slice of the full array and
+the slices are exchanged with one all-gatherv (grouped per-root broadcasts over RCCL/xGMI); total work
+is fixed, so "scaling" is "strong".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(sample_bytes, seed):
+    """The unmodified reference (oracle/_ref, "reference") or our C restatement ("port") timed on the
+    host cores on a bounded sample of the same stream.  Checker/baseline only - never the product."""
+    import numpy as np  # noqa: F401
+
+    import oracle
+    from msufsort_amd import gen
+    t = gen.random_bytes(sample_bytes, seed)
+    ncpu = os.cpu_count() or 1
+    if oracle.have_reference():
+        cores = max(1, min(32, ncpu))
+        kind = "reference"
+        best = None
+        for _ in range(3):                      # spin-wait pool: take the best of 3
+            t0 = time.perf_counter()
+            oracle.ref_make_suffix_array(t, cores)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    else:
+        cores, kind = 1, "port"
+        t0 = time.perf_counter()
+        oracle.make_suffix_array(t)
+        best = time.perf_counter() - t0
+    return {"value": round(sample_bytes / best / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": kind,
+            "sample": f"first {sample_bytes} bytes of the same splitmix64 stream, make_suffix_array wall time incl. SA allocation, best of 3"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=(1 << 30) - 1)   # 2^30-1: the oracle's ceiling
+    ap.add_argument("--workload", default="random")
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 27)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import msufsort_amd as M
+    from msufsort_amd import gen
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    n = args.size
+    t = gen.GENERATORS[args.workload](n, args.seed)
+    d_text = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    d_text[:n] = torch.from_numpy(t).to(dev)
+    d_sa = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    ctx = M.DeviceContext(local, n)
+
+    if world > 1:
+        bounds = ctx.shard_bounds(d_text, n, world)
+        views = [d_sa[bounds[g]:bounds[g + 1]] for g in range(world)]
+
+    def step():
+        if world == 1:
+            ctx.make_sa(d_text, n, d_sa)
+        else:
+            lo, hi = bounds[rank], bounds[rank + 1]
+            sl = views[rank] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
+            ctx.make_sa_shard(d_text, n, sl, max(hi - lo, 1), rank, world, text_rounds=64)
+            # all-gatherv of the slices: one broadcast per root, grouped (RCCL has no v-variant)
+            works = [dist.broadcast(views[g], src=g, async_op=True) for g in range(world) if bounds[g + 1] > bounds[g]]
+            for w in works:
+                w.wait()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    phases = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        phases.append(ctx.timings())
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        x = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        dt = float(x.item())
+
+    ok = True
+    if rank == 0:
+        ok = ctx.validate_sa(d_text, n, d_sa) == 0     # on-device checker on the assembled array
+
+    if rank == 0:
+        K = args.steps
+        ms_per_step = dt / K * 1e3
+        m = phases[-1].m
+        avg = lambda f: sum(getattr(p, f) for p in phases) / K   # noqa: E731
+        # per-launch device time (HIP events on the engine's stream) and ALGORITHMIC bytes
+        kern = {
+            "k_hist16": (avg("hist16_ms"), n),
+            "k_scatter0": (avg("scatter0_ms"), n + 8 * m),
+            "k_partition(level 1)": (avg("scatter1_ms"), 16 * m),
+            "k_sort_mid(bucket sort)": (avg("bucket_sort_ms"), 12 * m),
+        }
+        dom = max(kern, key=lambda k: kern[k][0])
+        dms, dbytes = kern[dom]
+        ach = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+        radix_ms = kern["k_hist16"][0] + kern["k_scatter0"][0]
+        out = {
+            "metric": "MB/s input for SA build on 1 GiB random bytes",
+            "value": round(n / (dt / K) / 1e6, 2),
+            "unit": "MB/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "valid": bool(ok),
+            "config": {"workload": f"{args.workload} bytes (splitmix64 seed {args.seed}), n={n}, int32 SA, 16-bit-key range sharding x{world}",
+                       "n": n, "index": "int32"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launch_ms": round(dms, 4), "algorithmic_bytes": int(dbytes)},
+            "radix_pass": {"read_bytes": 2 * n, "ms": round(radix_ms, 4),
+                           "read_frac_of_hbm_peak": round((2 * n / (radix_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4) if radix_ms > 0 else None},
+            "end_to_end": {"compulsory_bytes": 5 * n + 4, "frac_of_hbm_peak": round(((5 * n + 4) / (dt / K) / 1e9) / HBM_PEAK_GBS, 5)},
+            "phases_ms": {k: round(v[0], 4) for k, v in kern.items()} | {"refine": round(avg("refine_ms"), 4), "device_total": round(avg("total_ms"), 4)},
+        }
+        if not args.no_cpu and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.seed)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

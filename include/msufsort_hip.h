@@ -1,0 +1,138 @@
+/*
+ * msufsort_hip.h - C-ABI of the MI355X (gfx950) suffix-array / BWT engine.
+ *
+ * This is the drop-in boundary for the hot path of michaelmaniscalco/msufsort.  The
+ * reference has no FFI layer; its public surface is the C++ class maniscalco::msufsort
+ * (reference src/library/msufsort/msufsort.h:42-75) and three free templates
+ * (msufsort.h:403-476).  include/library/msufsort.h in this repository keeps that C++
+ * surface verbatim and forwards to the entry points below; any other host language binds
+ * the same symbols (see INTEGRATION.md for the stubs).
+ *
+ * Conventions (identical to the reference):
+ *   - SA has n+1 int32 entries, SA[0] = n (the empty suffix), SA[1..n] = suffixes in
+ *     lexicographic order of unsigned bytes, a proper prefix sorting first.
+ *   - BWT is n bytes with the sentinel row removed; the sentinel row index (the row r
+ *     with SA[r] == 0, always in [1, n]) is returned separately.
+ *   - LCP[i] = lcp(suffix SA[i+1], suffix SA[i+2]) for i in [0, n-2]; LCP[n-1] = 0.
+ *
+ * All functions return 0 on success or a negative msufsort_hip_status; nothing throws
+ * across this boundary.  `_dev` variants take device pointers (HBM-resident data);
+ * the others take host pointers (pageable is fine) and stage through HBM.
+ * A context owns one HIP stream and a workspace; calls on one context are serialised,
+ * distinct contexts are independent.
+ */
+#ifndef MSUFSORT_HIP_H
+#define MSUFSORT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum msufsort_hip_status {
+    MSUFSORT_HIP_OK = 0,
+    MSUFSORT_HIP_ERR_NO_DEVICE = -1,     /* no gfx950 device visible: the product path has no CPU fallback */
+    MSUFSORT_HIP_ERR_BAD_ARG = -2,
+    MSUFSORT_HIP_ERR_TOO_LARGE = -3,     /* n > 2^31 - 2 for the int32 entry points */
+    MSUFSORT_HIP_ERR_HIP = -4,           /* a HIP runtime call failed; see msufsort_hip_last_error */
+    MSUFSORT_HIP_ERR_NOMEM = -5,
+    MSUFSORT_HIP_ERR_INTERNAL = -6,      /* internal capacity/consistency check tripped */
+    MSUFSORT_HIP_ERR_UNSUPPORTED = -7    /* e.g. deep ties in a sharded (n_shards > 1) build */
+} msufsort_hip_status;
+
+typedef struct msufsort_hip_ctx msufsort_hip_ctx;
+
+/* Tunables; zero-initialise and override what you need. */
+typedef struct msufsort_hip_opts {
+    int32_t device;            /* HIP device ordinal (default 0) */
+    int32_t shard;             /* this call builds shard `shard` of `n_shards` (16-bit-key range split); */
+    int32_t n_shards;          /*   0 or 1 = whole array */
+    int32_t text_rounds;       /* key-gather rounds before switching to prefix doubling (0 = default) */
+    int32_t verbose;           /* 1: per-round statistics on stderr */
+    int32_t reserved[11];
+} msufsort_hip_opts;
+
+/* Per-phase device time of the last build on this context (hipEvent, milliseconds), plus
+ * the algorithmic byte counts bench.py uses for the roofline. */
+typedef struct msufsort_hip_timings {
+    double total_ms;
+    double hist16_ms;          /* 16-bit radix histogram: reads n bytes */
+    double scatter0_ms;        /* first-byte scatter: reads n, writes 8*m */
+    double scatter1_ms;        /* second-byte scatter: reads 8*m, writes 8*m */
+    double bucket_sort_ms;     /* round-0 LDS sorts of the 16-bit buckets */
+    double refine_ms;          /* all later rounds (key gathers / prefix doubling) */
+    double other_ms;
+    int64_t n;
+    int64_t m;                 /* suffixes sorted by the radix path (n minus trailing 0x00 run) */
+    int32_t rounds;            /* rounds after round 0 */
+    int32_t doubling_rounds;
+    int64_t unresolved_after_round0;
+    int64_t reserved[8];
+} msufsort_hip_timings;
+
+int msufsort_hip_device_count(void);
+const char* msufsort_hip_strerror(int status);
+const char* msufsort_hip_last_error(void);             /* thread-local detail of the last failure */
+
+/* Context: stream + workspace for inputs up to max_n bytes (grown on demand if exceeded). */
+int msufsort_hip_ctx_create(msufsort_hip_ctx** out, int32_t device, int64_t max_n);
+void msufsort_hip_ctx_destroy(msufsort_hip_ctx* ctx);
+void* msufsort_hip_ctx_stream(msufsort_hip_ctx* ctx);  /* hipStream_t, for hipEvent timing */
+int msufsort_hip_ctx_sync(msufsort_hip_ctx* ctx);
+int msufsort_hip_last_timings(msufsort_hip_ctx* ctx, msufsort_hip_timings* out);
+
+/* ---- suffix array: replaces msufsort::make_suffix_array (reference msufsort.cpp:1730-1767,
+ *      first_stage_its cpp:1559-1726 + second_stage_its cpp:1021-1057) ---- */
+int msufsort_hip_make_sa_i32(const uint8_t* text, int64_t n, int32_t* sa_out /* n+1 */,
+                             const msufsort_hip_opts* opts);
+/* d_text must have at least n + MSUFSORT_HIP_TEXT_PAD readable bytes; the pad is zeroed by the call. */
+#define MSUFSORT_HIP_TEXT_PAD 64
+int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
+                                 int32_t* d_sa_out /* n+1 */, const msufsort_hip_opts* opts);
+/* Sharded build (multi-GPU): writes only SA[1 + lo, 1 + hi) of the full array into
+ * d_slice_out (hi - lo entries) and reports the slice bounds.  Shard 0 also owns SA[0] and the
+ * trailing-zero-run rows, which lie inside its slice. */
+int msufsort_hip_make_sa_shard_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
+                                   int32_t* d_slice_out, int64_t slice_capacity,
+                                   int64_t* slice_lo, int64_t* slice_hi,
+                                   const msufsort_hip_opts* opts);
+/* Slice bounds only (all shards), without sorting: bounds[n_shards + 1], in SA rows. */
+int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
+                                  int32_t n_shards, int64_t* bounds);
+
+/* ---- forward BWT: replaces msufsort::forward_burrows_wheeler_transform (cpp:1771-1817) ---- */
+int msufsort_hip_forward_bwt(uint8_t* inout, int64_t n, int64_t* sentinel_row,
+                             const msufsort_hip_opts* opts);
+int msufsort_hip_forward_bwt_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
+                                 uint8_t* d_bwt_out /* n */, int64_t* sentinel_row,
+                                 const msufsort_hip_opts* opts);
+/* BWT from an SA that is already in HBM (gather T[SA[r]-1]). */
+int msufsort_hip_bwt_from_sa_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int64_t n,
+                                 const int32_t* d_sa, uint8_t* d_bwt_out, int64_t* sentinel_row);
+
+/* ---- inverse BWT: replaces msufsort::reverse_burrows_wheeler_transform (cpp:1821-2096) ---- */
+int msufsort_hip_inverse_bwt(uint8_t* inout, int64_t n, int64_t sentinel_row,
+                             const msufsort_hip_opts* opts);
+int msufsort_hip_inverse_bwt_dev(msufsort_hip_ctx* ctx, const uint8_t* d_bwt, int64_t n,
+                                 int64_t sentinel_row, uint8_t* d_text_out,
+                                 const msufsort_hip_opts* opts);
+
+/* ---- LCP in the demo's convention (reference src/executable/msufsort/main.cpp:16-159) ---- */
+int msufsort_hip_lcp_i32(const uint8_t* text, int64_t n, const int32_t* sa /* n+1 */,
+                         int32_t* lcp_out /* n */, const msufsort_hip_opts* opts);
+int msufsort_hip_lcp_i32_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int64_t n,
+                             const int32_t* d_sa, int32_t* d_lcp_out);
+
+/* ---- validation on device: checker of reference main.cpp:236-270 (+ permutation check) ---- */
+int msufsort_hip_validate_sa_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int64_t n,
+                                 const int32_t* d_sa, int64_t* error_count);
+
+/* ---- stage probes used by the parity tests (not part of the reference surface) ---- */
+int msufsort_hip_debug_hist16_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
+                                  uint32_t* d_hist /* 65536 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSUFSORT_HIP_H */

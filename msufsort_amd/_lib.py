@@ -1,0 +1,99 @@
+"""ctypes binding of the C-ABI in include/msufsort_hip.h (the drop-in boundary).
+
+The HIP library is the product: if it is missing or cannot be loaded this module raises -
+there is no CPU or pure-Python fallback here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmsufsort_hip.so")
+
+TEXT_PAD = 64
+
+
+class Opts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("shard", C.c_int32), ("n_shards", C.c_int32),
+                ("text_rounds", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32 * 11)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("hist16_ms", C.c_double), ("scatter0_ms", C.c_double),
+                ("scatter1_ms", C.c_double), ("bucket_sort_ms", C.c_double), ("refine_ms", C.c_double),
+                ("other_ms", C.c_double), ("n", C.c_int64), ("m", C.c_int64), ("rounds", C.c_int32),
+                ("doubling_rounds", C.c_int32), ("unresolved_after_round0", C.c_int64),
+                ("reserved", C.c_int64 * 8)]
+
+
+# every symbol include/msufsort_hip.h declares (checked by tests/test_cabi.py)
+SYMBOLS = [
+    "msufsort_hip_device_count", "msufsort_hip_strerror", "msufsort_hip_last_error",
+    "msufsort_hip_ctx_create", "msufsort_hip_ctx_destroy", "msufsort_hip_ctx_stream", "msufsort_hip_ctx_sync",
+    "msufsort_hip_last_timings", "msufsort_hip_make_sa_i32", "msufsort_hip_make_sa_i32_dev",
+    "msufsort_hip_make_sa_shard_dev", "msufsort_hip_shard_bounds_dev", "msufsort_hip_forward_bwt",
+    "msufsort_hip_forward_bwt_dev", "msufsort_hip_bwt_from_sa_dev", "msufsort_hip_inverse_bwt",
+    "msufsort_hip_inverse_bwt_dev", "msufsort_hip_lcp_i32", "msufsort_hip_lcp_i32_dev",
+    "msufsort_hip_validate_sa_dev", "msufsort_hip_debug_hist16_dev",
+]
+
+_lib = None
+
+
+class MsufsortHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libmsufsort_hip.so (built by msufsort_amd/csrc/Makefile); raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MsufsortHipError(
+            f"{LIB_PATH} is missing: build it with `make -C msufsort_amd/csrc` "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes in one process leave the
+    # second one without devices.  Load torch's first (when torch is installed) so that this library
+    # binds to the same runtime.  torch is plumbing here (device memory, streams, torch.distributed).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+    L.msufsort_hip_device_count.restype = C.c_int
+    L.msufsort_hip_strerror.restype = C.c_char_p
+    L.msufsort_hip_strerror.argtypes = [C.c_int]
+    L.msufsort_hip_last_error.restype = C.c_char_p
+    L.msufsort_hip_ctx_create.argtypes = [C.POINTER(vp), i32, i64]
+    L.msufsort_hip_ctx_destroy.argtypes = [vp]
+    L.msufsort_hip_ctx_destroy.restype = None
+    L.msufsort_hip_ctx_stream.argtypes = [vp]
+    L.msufsort_hip_ctx_stream.restype = vp
+    L.msufsort_hip_ctx_sync.argtypes = [vp]
+    L.msufsort_hip_last_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.msufsort_hip_make_sa_i32.argtypes = [vp, i64, vp, C.POINTER(Opts)]
+    L.msufsort_hip_make_sa_i32_dev.argtypes = [vp, vp, i64, vp, C.POINTER(Opts)]
+    L.msufsort_hip_make_sa_shard_dev.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(Opts)]
+    L.msufsort_hip_shard_bounds_dev.argtypes = [vp, vp, i64, i32, C.POINTER(i64)]
+    L.msufsort_hip_forward_bwt.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(Opts)]
+    L.msufsort_hip_forward_bwt_dev.argtypes = [vp, vp, i64, vp, C.POINTER(i64), C.POINTER(Opts)]
+    L.msufsort_hip_bwt_from_sa_dev.argtypes = [vp, vp, i64, vp, vp, C.POINTER(i64)]
+    L.msufsort_hip_inverse_bwt.argtypes = [vp, i64, i64, C.POINTER(Opts)]
+    L.msufsort_hip_inverse_bwt_dev.argtypes = [vp, vp, i64, i64, vp, C.POINTER(Opts)]
+    L.msufsort_hip_lcp_i32.argtypes = [vp, i64, vp, vp, C.POINTER(Opts)]
+    L.msufsort_hip_lcp_i32_dev.argtypes = [vp, vp, i64, vp, vp]
+    L.msufsort_hip_validate_sa_dev.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
+    L.msufsort_hip_debug_hist16_dev.argtypes = [vp, vp, i64, vp]
+    _lib = L
+    return L
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        L = lib()
+        msg = L.msufsort_hip_strerror(status).decode()
+        detail = L.msufsort_hip_last_error().decode()
+        raise MsufsortHipError(f"{what}: {msg} ({status}) {detail}")

@@ -1,0 +1,260 @@
+// BWT / LCP / validation kernels (forward BWT: reference msufsort.cpp:1771-1817 semantics via
+// BWT[r] = T[SA[r]-1]; LCP: reference src/executable/msufsort/main.cpp:16-159; checker: main.cpp:210-270).
+#pragma once
+#include "sa_kernels.hip.h"
+
+// row r with SA[r] == 0 (the sentinel row, cpp:1283-1286)
+__global__ __launch_bounds__(256) void k_find_sentinel(const u32* __restrict__ sa, u64 rows, u32* __restrict__ counters)
+{
+    for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r < rows; r += (u64)gridDim.x * 256u)
+        if (sa[r] == 0) counters[C_SENT] = (u32)r;
+}
+
+// BWT bytes with the sentinel row removed (cpp:1811-1815)
+__global__ __launch_bounds__(256) void k_bwt_gather(const u8* __restrict__ text, const u32* __restrict__ sa, u64 rows,
+                                                    const u32* __restrict__ counters, u8* __restrict__ out)
+{
+    const u32 sent = counters[C_SENT];
+    for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r < rows; r += (u64)gridDim.x * 256u) {
+        const u32 v = sa[r];
+        if (v != 0) out[r - (r > sent)] = text[v - 1];
+    }
+}
+
+__device__ __forceinline__ u32 dev_match_length(const u8* __restrict__ text, u64 n, u64 a, u64 b)
+{
+    if (a > b) { const u64 x = a; a = b; b = x; }
+    u64 m = 0;
+    while (b + m + 8 <= n) {
+        u64 x, y;
+        __builtin_memcpy(&x, text + a + m, 8);
+        __builtin_memcpy(&y, text + b + m, 8);
+        if (x != y) { m += (u64)(__ffsll((long long)(x ^ y)) - 1) >> 3; return (u32)m; }
+        m += 8;
+    }
+    while (b + m < n && text[a + m] == text[b + m]) ++m;
+    return (u32)m;
+}
+
+// demo convention (main.cpp:66-101): out[i] = lcp(SA[i+1], SA[i+2]), i in [0, n-2]; out[n-1] = 0
+__global__ __launch_bounds__(256) void k_lcp(const u8* __restrict__ text, u64 n, const u32* __restrict__ sa, u32* __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u)
+        out[i] = (i + 1 < n) ? dev_match_length(text, n, sa[i + 1], sa[i + 2]) : 0u;
+}
+
+// validate_suffix_array (main.cpp:236-270): SA[0] == n, adjacent suffixes strictly increasing
+// ("shorter is smaller", main.cpp:210-232) plus range and permutation checks (bitmap of seen indices).
+__global__ __launch_bounds__(256) void k_validate(const u8* __restrict__ text, u64 n, const u32* __restrict__ sa,
+                                                  u32* __restrict__ seen /* ceil(n/32) zeroed */, unsigned long long* __restrict__ errors)
+{
+    for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r <= n; r += (u64)gridDim.x * 256u) {
+        const u32 v = sa[r];
+        if (r == 0) { if (v != (u32)n) atomicAdd(errors, 1ull); continue; }
+        if (v >= n) { atomicAdd(errors, 1ull); continue; }
+        const u32 old = atomicOr(&seen[v >> 5], 1u << (v & 31));
+        if (old & (1u << (v & 31))) atomicAdd(errors, 1ull);
+        if (r >= 2) {
+            const u32 a = sa[r - 1];
+            if (a >= n) continue;
+            const u32 l = dev_match_length(text, n, a, v);
+            const u64 pa = (u64)a + l, pb = (u64)v + l;
+            bool ok;
+            if (pa >= n) ok = true;                 // a ran out first: a is the shorter -> a < v
+            else if (pb >= n) ok = false;
+            else ok = text[pa] < text[pb];
+            if (a == v) ok = false;
+            if (!ok) atomicAdd(errors, 1ull);
+        }
+    }
+}
+
+// ================================================================================================
+// Inverse BWT (reverse_burrows_wheeler_transform, reference msufsort.cpp:1821-2096).
+//   rows 0..n of the BWT matrix; byte i of the stored BWT is row i + (i >= sentinel) (cpp:1907-1913).
+//   (i)   per-tile symbol histogram                      (cpp:1842-1879)
+//   (ii)  device-wide exclusive scan, symbol-major / tile-minor, base 1   (cpp:1880-1889)
+//   (iii) stable ranked scatter -> forward links link[k] = row            (cpp:1891-1919)
+//   (iv)  marker-terminated chain walks, one chain per lane               (cpp:1922-2063)
+//   (v)   fragment order by list ranking (pointer jumping) instead of the serial stitch (cpp:2065-2095)
+// ================================================================================================
+#define IBWT_WT 8192u          // rows per wave-tile
+#define IBWT_S 256u            // splitter stride (rows that are multiples of S start a chain)
+
+__device__ __forceinline__ u32 ibwt_sym(const u8* __restrict__ bwt, u32 row, u32 sent)
+{
+    return bwt[row - (row > sent)];
+}
+
+__global__ __launch_bounds__(256) void k_ibwt_count(const u8* __restrict__ bwt, u32 rows, u32 sent, u32 ntiles, u32* __restrict__ counts)
+{
+    __shared__ u32 h[4][256];
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32 tile = blockIdx.x * 4 + w;
+    for (u32 i = lane; i < 256; i += 64) h[w][i] = 0;
+    __syncthreads();
+    if (tile < ntiles) {
+        const u32 beg = tile * IBWT_WT;
+        const u32 end = (rows - beg < IBWT_WT) ? rows : beg + IBWT_WT;
+        for (u32 r = beg + lane; r < end; r += 64)
+            if (r != sent) atomicAdd(&h[w][ibwt_sym(bwt, r, sent)], 1u);
+    }
+    __syncthreads();
+    if (tile < ntiles)
+        for (u32 i = lane; i < 256; i += 64) counts[(u64)i * ntiles + tile] = h[w][i];
+}
+
+// generic device-wide exclusive scan of u32[N]: partial -> top -> final
+#define SCAN_ITEMS 8
+#define SCAN_BLOCK (1024 * SCAN_ITEMS)
+__device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* wsum /*16*/, u32& block_total)
+{
+    u32 wt;
+    const u32 e = wave_excl_scan(v, wt);
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = wt;
+    __syncthreads();
+    u32 wbase = 0, tot = 0;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) { const u32 s = wsum[k]; if (k < (threadIdx.x >> 6)) wbase += s; tot += s; }
+    __syncthreads();
+    block_total = tot;
+    return wbase + e;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_partial(const u32* __restrict__ in, u64 N, u32* __restrict__ block_sums)
+{
+    __shared__ u32 wsum[16];
+    const u64 base = (u64)blockIdx.x * SCAN_BLOCK + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < N) s += in[base + k];
+    u32 tot;
+    (void)block_excl_scan_1024(s, wsum, tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_top(u32* __restrict__ sums, u32 nb, u32 init)
+{
+    __shared__ u32 wsum[16];
+    __shared__ u32 s_carry;
+    if (threadIdx.x == 0) s_carry = init;
+    __syncthreads();
+    for (u32 b = 0; b < nb; b += 1024u) {
+        const u32 i = b + threadIdx.x;
+        const u32 v = i < nb ? sums[i] : 0u;
+        u32 tot;
+        const u32 e = block_excl_scan_1024(v, wsum, tot);
+        const u32 carry = s_carry;
+        if (i < nb) sums[i] = carry + e;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_final(u32* __restrict__ data, u64 N, const u32* __restrict__ block_sums)
+{
+    __shared__ u32 wsum[16];
+    const u64 base = (u64)blockIdx.x * SCAN_BLOCK + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 v[SCAN_ITEMS];
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < N) ? data[base + k] : 0u; s += v[k]; }
+    u32 tot;
+    u32 e = block_excl_scan_1024(s, wsum, tot) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < N) data[base + k] = e; e += v[k]; }
+}
+
+// stable ranked scatter: link[C[c] + rank] = row  (one wave per tile, 64 rows per step)
+__global__ __launch_bounds__(256) void k_ibwt_scatter(const u8* __restrict__ bwt, u32 rows, u32 sent, u32 ntiles,
+                                                      const u32* __restrict__ offs, u32* __restrict__ link)
+{
+    __shared__ u32 cur[4][256];
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32 tile = blockIdx.x * 4 + w;
+    if (blockIdx.x == 0 && threadIdx.x == 0) link[0] = sent;      // cpp:1891
+    if (tile < ntiles) for (u32 i = lane; i < 256; i += 64) cur[w][i] = offs[(u64)i * ntiles + tile];
+    __syncthreads();
+    if (tile >= ntiles) return;
+    const u32 beg = tile * IBWT_WT;
+    const u32 end = (rows - beg < IBWT_WT) ? rows : beg + IBWT_WT;
+    const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (u32 r0 = beg; r0 < end; r0 += 64) {
+        const u32 r = r0 + lane;
+        const bool valid = r < end && r != sent;
+        const u32 c = valid ? ibwt_sym(bwt, r, sent) : 0u;
+        u64 mask = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (c >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            mask &= bit ? bal : ~bal;
+        }
+        if (valid) {
+            const int leader = __ffsll((long long)mask) - 1;
+            u32 old = 0;
+            if ((int)lane == leader) old = atomicAdd(&cur[w][c], (u32)__popcll(mask));
+            old = __shfl(old, leader, 64);
+            link[old + (u32)__popcll(mask & lt_mask)] = r;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ibwt_pack(const u8* __restrict__ bwt, u32 rows, u32 sent, const u32* __restrict__ link, u64* __restrict__ packed)
+{
+    for (u64 k = (u64)blockIdx.x * 256u + threadIdx.x; k < rows; k += (u64)gridDim.x * 256u) {
+        const u32 sym = (k == sent) ? 0u : ibwt_sym(bwt, (u32)k, sent);
+        packed[k] = (u64)link[k] | ((u64)sym << 32);
+    }
+}
+
+__device__ __forceinline__ bool ibwt_marked(u32 row, u32 sent) { return (row & (IBWT_S - 1)) == 0 || row == sent; }
+__device__ __forceinline__ u32 ibwt_id(u32 row, u32 sent, u32 kreg) { return (row == sent && (sent & (IBWT_S - 1))) ? kreg : row / IBWT_S; }
+__device__ __forceinline__ u32 ibwt_start(u32 id, u32 sent, u32 kreg) { return id == kreg ? sent : id * IBWT_S; }
+
+// pass A: length and successor of every chain (chain 0 = row 0 is the terminal)
+__global__ __launch_bounds__(256) void k_ibwt_walk_a(const u64* __restrict__ packed, u32 sent, u32 kreg, u32 K,
+                                                     u32* __restrict__ queue, u32* __restrict__ nxt, u32* __restrict__ dist)
+{
+    u32 id = atomicAdd(queue, 1u) + 1u;
+    u32 cur = 0, len = 0;
+    if (id < K) cur = ibwt_start(id, sent, kreg);
+    while (id < K) {
+        cur = (u32)packed[cur];
+        ++len;
+        if (ibwt_marked(cur, sent)) {
+            nxt[id] = ibwt_id(cur, sent, kreg);
+            dist[id] = len;
+            id = atomicAdd(queue, 1u) + 1u;
+            if (id < K) { cur = ibwt_start(id, sent, kreg); len = 0; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ibwt_jump(const u32* __restrict__ nxt, const u32* __restrict__ dist, u32 K,
+                                                   u32* __restrict__ nxt2, u32* __restrict__ dist2)
+{
+    const u32 j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= K) return;
+    const u32 x = nxt[j];
+    dist2[j] = dist[j] + dist[x];
+    nxt2[j] = nxt[x];
+}
+
+// pass B: walk again, now writing text bytes at their final positions
+__global__ __launch_bounds__(256) void k_ibwt_walk_b(const u64* __restrict__ packed, u32 sent, u32 kreg, u32 K, u32 n,
+                                                     u32* __restrict__ queue, const u32* __restrict__ dist, u8* __restrict__ out)
+{
+    u32 id = atomicAdd(queue, 1u) + 1u;
+    u32 cur = 0, p = 0;
+    if (id < K) { cur = (u32)packed[ibwt_start(id, sent, kreg)]; p = n - dist[id]; }
+    while (id < K) {
+        const u64 e = packed[cur];
+        out[p++] = (u8)(e >> 32);
+        if (ibwt_marked(cur, sent)) {
+            id = atomicAdd(queue, 1u) + 1u;
+            if (id < K) { cur = (u32)packed[ibwt_start(id, sent, kreg)]; p = n - dist[id]; }
+        } else cur = (u32)e;
+    }
+}

@@ -1,0 +1,612 @@
+// Host driver + C-ABI of the MI355X suffix-array / BWT engine (see include/msufsort_hip.h).
+// Replaces, behind the reference's own API, msufsort::make_suffix_array (reference
+// src/library/msufsort/msufsort.cpp:1730-1767), forward_burrows_wheeler_transform (cpp:1771-1817),
+// reverse_burrows_wheeler_transform (cpp:1821-2096) and the demo's LCP (main.cpp:16-159).
+// There is NO CPU fallback in this library: without a HIP device every entry point fails.
+#include "sa_kernels.hip.h"
+#include "bwt_kernels.hip.h"
+#include "../../include/msufsort_hip.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_));    \
+            return MSUFSORT_HIP_ERR_HIP;                                                       \
+        }                                                                                      \
+    } while (0)
+
+#define TRY(expr)                         \
+    do {                                  \
+        int r_ = (expr);                  \
+        if (r_ != MSUFSORT_HIP_OK) return r_; \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return MSUFSORT_HIP_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        need = (need + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); p = nullptr; return MSUFSORT_HIP_ERR_NOMEM; }
+        bytes = need;
+        return MSUFSORT_HIP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct msufsort_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool attrs_set = false;
+    // workspace
+    DevBuf rec[3], pool_rec[2], pool_hdr[2];
+    DevBuf lists[2][3], large_round[2], lvl[2], seg0;
+    DevBuf hist_partial, hist, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
+    DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2;
+    u32* h_counters = nullptr;   // pinned
+    u32* h_bstart = nullptr;     // pinned, 65537
+    u32 list_cap[3] = {0, 0, 0};
+    u32 large_cap = 0;
+    u64 cap_m = 0;               // records capacity
+    msufsort_hip_timings tm{};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+    int set_attrs()
+    {
+        if (attrs_set) return MSUFSORT_HIP_OK;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>()));
+        attrs_set = true;
+        return MSUFSORT_HIP_OK;
+    }
+
+    int ensure_workspace(u64 m)
+    {
+        if (m <= cap_m) return MSUFSORT_HIP_OK;
+        u64 cap = m + 1024;
+        for (auto& b : rec) TRY(b.ensure(cap * 8));
+        for (auto& b : pool_rec) TRY(b.ensure(cap * 8));
+        for (auto& b : pool_hdr) TRY(b.ensure(cap * 8));
+        list_cap[0] = (u32)(cap / (TINY_MAX + 1) + 16);
+        list_cap[1] = (u32)(cap / (CAP_A + 1) + 16);
+        list_cap[2] = (u32)(cap / (CAP_B + 1) + 16);
+        large_cap = (u32)(cap / (CAP_C + 1) + 16);
+        for (int s = 0; s < 2; ++s) {
+            for (int c = 0; c < 3; ++c) TRY(lists[s][c].ensure((size_t)list_cap[c] * sizeof(Desc)));
+            TRY(large_round[s].ensure((size_t)large_cap * sizeof(Desc)));
+            TRY(lvl[s].ensure((size_t)large_cap * sizeof(Desc)));
+        }
+        TRY(seg0.ensure(256 * sizeof(Desc)));
+        size_t nchild = std::max<size_t>(65536, (size_t)large_cap * 256);
+        TRY(child_start.ensure(nchild * 4));
+        TRY(child_cnt.ensure(65536 * 4));
+        TRY(cursor.ensure(nchild * 4));
+        TRY(seg_hist.ensure(nchild * 4));
+        TRY(cursor0.ensure(256 * 4));
+        TRY(tile_start.ensure(((size_t)std::max<u32>(large_cap, 256) + 1) * 4));
+        TRY(trivial.ensure((size_t)std::max<u32>(large_cap, 256) * 4));
+        TRY(hist_partial.ensure((size_t)128 * 65536 * 4));
+        TRY(hist.ensure(65536 * 4));
+        TRY(bstart.ensure(65537 * 4));
+        TRY(counters.ensure(C_NCOUNTERS * 4));
+        cap_m = cap;
+        return MSUFSORT_HIP_OK;
+    }
+
+    void release_all()
+    {
+        for (auto& b : rec) b.release();
+        for (auto& b : pool_rec) b.release();
+        for (auto& b : pool_hdr) b.release();
+        for (int s = 0; s < 2; ++s) { for (int c = 0; c < 3; ++c) lists[s][c].release(); large_round[s].release(); lvl[s].release(); }
+        seg0.release(); hist_partial.release(); hist.release(); bstart.release(); child_start.release(); child_cnt.release();
+        cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
+        isa.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release();
+        cap_m = 0;
+    }
+
+    int read_counters()
+    {
+        HIP_TRY(hipMemcpyAsync(h_counters, counters.p, C_NCOUNTERS * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (h_counters[C_ERR]) { set_error("device capacity check tripped (flags 0x%x)", h_counters[C_ERR]); return MSUFSORT_HIP_ERR_INTERNAL; }
+        return MSUFSORT_HIP_OK;
+    }
+};
+
+namespace {
+
+__global__ void k_zero_idx(u32* counters, u32 mask)
+{
+    const u32 t = threadIdx.x;
+    if (t < C_NCOUNTERS && ((mask >> t) & 1u)) counters[t] = 0;
+}
+
+__global__ void k_last_nonzero(const u8* __restrict__ text, u64 n, unsigned long long* out)
+{
+    unsigned long long best = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (text[i]) best = i + 1;
+    for (int s = 32; s >= 1; s >>= 1) { unsigned long long o = __shfl_xor(best, s, 64); if (o > best) best = o; }
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
+}
+
+inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+struct Bench {   // event timing of phases
+    hipStream_t s;
+    hipEvent_t a, b;
+};
+
+// number of trailing 0x00 bytes of the device text
+int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out)
+{
+    u8 tail[4096];
+    u64 k = std::min<u64>(n, sizeof tail);
+    HIP_TRY(hipMemcpyAsync(tail, d_text + (n - k), k, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    u64 z = 0;
+    while (z < k && tail[k - 1 - z] == 0) ++z;
+    if (z < k || k == n) { *z_out = z; return MSUFSORT_HIP_OK; }
+    // the whole tail is zero: scan on the device
+    TRY(c->aux0.ensure(8));
+    HIP_TRY(hipMemsetAsync(c->aux0.p, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_last_nonzero, dim3(2048), dim3(256), 0, c->stream, d_text, n, c->aux0.as<unsigned long long>());
+    unsigned long long last = 0;
+    HIP_TRY(hipMemcpyAsync(&last, c->aux0.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *z_out = n - last;
+    return MSUFSORT_HIP_OK;
+}
+
+struct ShardPlan {
+    u32 klo = 0, khi = 65536;
+    u64 row_lo = 0, row_hi = 0;     // rows of the full SA (n+1 rows) owned by this shard
+};
+
+// hist16 + reduce (+ scan for the given key range).  Leaves hist/bstart and the level-0/1 set-up on the device.
+int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
+{
+    u32 nchunks = (u32)std::min<u64>(128, std::max<u64>(1, (m + 65535) / 65536));
+    u64 chunk_len = (m + nchunks - 1) / nchunks;
+    chunk_len = (chunk_len + 16383) / 16384 * 16384;
+    hipLaunchKernelGGL(k_hist16, dim3(2 * nchunks), dim3(1024), 131072, c->stream, d_text, (u32)m, (u32)chunk_len, c->hist_partial.as<u32>());
+    hipLaunchKernelGGL(k_reduce16, dim3(64), dim3(1024), 0, c->stream, c->hist_partial.as<u32>(), nchunks, c->hist.as<u32>());
+    HIP_TRY(hipGetLastError());
+    return MSUFSORT_HIP_OK;
+}
+
+void run_scan(msufsort_hip_ctx* c, u32 klo, u32 khi, u64 z)
+{
+    hipLaunchKernelGGL(k_scan16, dim3(1), dim3(1024), 0, c->stream, c->hist.as<u32>(), c->bstart.as<u32>(), klo, khi,
+                       c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->cursor0.as<u32>(),
+                       c->seg0.as<Desc>(), c->tile_start.as<u32>(), c->counters.as<u32>(), (u32)z);
+}
+
+int plan_shards(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64 z, u64 m, int n_shards, std::vector<u32>& cuts, std::vector<u64>& rows)
+{
+    cuts.assign(n_shards + 1, 0);
+    rows.assign(n_shards + 1, 0);
+    cuts[n_shards] = 65536;
+    rows[n_shards] = n + 1;
+    if (m == 0 || n_shards == 1) { if (n_shards > 1) for (int g = 1; g < n_shards; ++g) { cuts[g] = 65536; rows[g] = n + 1; } return MSUFSORT_HIP_OK; }
+    TRY(run_hist(c, d_text, m));
+    run_scan(c, 0, 65536, z);
+    HIP_TRY(hipMemcpyAsync(c->h_bstart, c->bstart.p, 65537 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int g = 1; g < n_shards; ++g) {
+        u64 target = m * (u64)g / (u64)n_shards;
+        u32 k = (u32)(std::lower_bound(c->h_bstart, c->h_bstart + 65536, (u32)target) - c->h_bstart);
+        if (k < cuts[g - 1]) k = cuts[g - 1];
+        cuts[g] = k;
+        rows[g] = 1 + z + c->h_bstart[k];
+    }
+    return MSUFSORT_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The suffix-array build for one shard.  d_sa_local points at the row of the shard's first radix-sorted
+// suffix (global row 1 + z + bstart[klo]); `with_head` also writes SA[0] and the trailing-zero rows.
+// ------------------------------------------------------------------------------------------------
+int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of this shard's slice */, u64 slice_row_lo,
+             u64 z, u32 klo, u32 khi, bool with_head, const msufsort_hip_opts* opts, bool hist_done)
+{
+    const int verbose = opts ? opts->verbose : 0;
+    const bool sharded = opts && opts->n_shards > 1;
+    int text_rounds = (opts && opts->text_rounds > 0) ? opts->text_rounds : 4;
+    if (const char* e = getenv("MSUFSORT_HIP_TEXT_ROUNDS")) text_rounds = std::max(1, atoi(e));
+    const u64 m = n - z;
+    hipStream_t st = c->stream;
+    auto& tm = c->tm;
+    memset(&tm, 0, sizeof tm);
+    tm.n = (int64_t)n; tm.m = (int64_t)m;
+    TRY(c->set_attrs());
+    HIP_TRY(hipEventRecord(c->ev[0], st));
+    if (with_head) hipLaunchKernelGGL(k_sa_head, dim3(cdiv(std::max<u64>(z, 1), 256)), dim3(256), 0, st, d_sa_rows, (u32)n, (u32)z);
+    if (m == 0) { HIP_TRY(hipEventRecord(c->ev[5], st)); HIP_TRY(hipStreamSynchronize(st)); return MSUFSORT_HIP_OK; }
+    TRY(c->ensure_workspace(m));
+    u32* counters = c->counters.as<u32>();
+    HIP_TRY(hipMemsetAsync(counters, 0, C_NCOUNTERS * 4, st));
+    RecBufs bufs{{c->rec[0].as<u64>(), c->rec[1].as<u64>(), c->rec[2].as<u64>()}};
+
+    // ---- round 0: 16-bit histogram, offsets, two 8-bit scatter levels ----
+    if (!hist_done) TRY(run_hist(c, d_text, m));
+    HIP_TRY(hipEventRecord(c->ev[1], st));
+    run_scan(c, klo, khi, z);
+    // rows of this shard's radix-sorted suffixes start at global row 1 + z + bstart[klo]
+    u64 rank0;
+    if (klo == 0) rank0 = z;
+    else { HIP_TRY(hipMemcpyAsync(c->h_bstart, c->bstart.p, 65537 * 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); rank0 = z + c->h_bstart[klo]; }
+    u32* sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
+    hipLaunchKernelGGL(k_scatter0, dim3(cdiv(m, P1_TILE)), dim3(P1_THREADS), 0, st, d_text, (u32)m, klo, khi, c->cursor0.as<u32>(), bufs.p[0]);
+    HIP_TRY(hipEventRecord(c->ev[2], st));
+    hipLaunchKernelGGL(k_partition, dim3(cdiv(m, P1_TILE) + 256), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
+                       c->tile_start.as<u32>(), 24u, c->cursor.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u);
+    HIP_TRY(hipEventRecord(c->ev[3], st));
+
+    int cur = 0;                 // slot of the current round's lists / pool
+    u32 sb = 1, nb = 2;          // record buffer holding the current segments / receiving next round's
+    u32 mode = MODE_TEXT;
+    u64 depth = 5;               // text bytes consumed after round 0: bucket bytes 0,1 + key bytes 2,3,4
+    auto make_lists = [&](int slot) {
+        Lists L;
+        for (int k = 0; k < 3; ++k) { L.cls[k] = c->lists[slot][k].as<Desc>(); L.cap[k] = c->list_cap[k]; }
+        L.cnt_idx = slot ? C_LIST1 : C_LIST0;
+        return L;
+    };
+    auto alts = [&](u32 s, u32 nx, u32 a[3]) { u32 third = 3 - s - nx; a[s] = third; a[third] = s; a[nx] = nx; };
+
+    // children of the 65,536 two-byte buckets
+    {
+        u32 a[3]; a[0] = 1; a[1] = 0; a[2] = 2;
+        hipLaunchKernelGGL(k_children, dim3(256), dim3(256), 0, st, bufs, c->seg0.as<Desc>(), 256u, c->child_start.as<u32>(), c->child_cnt.as<u32>(),
+                           (const u32*)nullptr, a[0], a[1], a[2], sa_local, (u32*)nullptr, (u32)MODE_TEXT,
+                           c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), (u32)std::min<u64>(c->cap_m, 0xffffffffu),
+                           make_lists(cur), c->lvl[0].as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters);
+    }
+    TRY(c->read_counters());
+
+    int round = 0;
+    for (;; ++round) {
+        const int nxt = cur ^ 1;
+        u32 a[3];
+        alts(sb, nb, a);
+        if (round == 0) { a[0] = 1; a[1] = 0; a[2] = 2; }   // round 0 ping-pongs between buffers 0 and 1
+        const u32 cap32 = (u32)std::min<u64>(c->cap_m, 0xffffffffu);
+        // ---- partition levels for large segments ----
+        {
+            Desc* src_list; u32 nl, ntiles; int lp;       // lp = index of the lvl list used as destination
+            u32 shift;
+            if (round == 0) { src_list = c->lvl[0].as<Desc>(); nl = c->h_counters[C_LVL0]; ntiles = c->h_counters[C_LVLT0]; lp = 1; shift = 16; }
+            else { src_list = c->large_round[cur].as<Desc>(); nl = c->h_counters[(cur ? C_LIST1 : C_LIST0) + 3]; ntiles = c->h_counters[cur ? C_LTILES1 : C_LTILES0]; lp = 0; shift = 24; }
+            while (nl > 0) {
+                const bool last = (shift == 0);
+                const u32 cnt_idx = lp ? C_LVL1 : C_LVL0, til_idx = lp ? C_LVLT1 : C_LVLT0;
+                hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << cnt_idx) | (1u << til_idx));
+                hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, src_list, nl, c->tile_start.as<u32>());
+                HIP_TRY(hipMemsetAsync(c->seg_hist.p, 0, (size_t)nl * 256 * 4, st));
+                HIP_TRY(hipMemsetAsync(c->trivial.p, 0, (size_t)nl * 4, st));
+                hipLaunchKernelGGL(k_count, dim3(ntiles), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.as<u32>(), shift, c->seg_hist.as<u32>());
+                hipLaunchKernelGGL(k_segscan, dim3(nl), dim3(256), 0, st, src_list, nl, c->seg_hist.as<u32>(), c->child_start.as<u32>(), c->cursor.as<u32>(), c->trivial.as<u32>());
+                hipLaunchKernelGGL(k_partition, dim3(ntiles), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.as<u32>(), shift,
+                                   c->cursor.as<u32>(), c->trivial.as<u32>(), a[0], a[1], a[2]);
+                hipLaunchKernelGGL(k_children, dim3(nl), dim3(256), 0, st, bufs, src_list, nl, c->child_start.as<u32>(), c->seg_hist.as<u32>(),
+                                   c->trivial.as<u32>(), a[0], a[1], a[2], sa_local, c->isa.as<u32>(), mode,
+                                   c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), cap32,
+                                   make_lists(cur), c->lvl[lp].as<Desc>(), c->large_cap, cnt_idx, til_idx, counters);
+                TRY(c->read_counters());
+                src_list = c->lvl[lp].as<Desc>();
+                nl = c->h_counters[cnt_idx];
+                ntiles = c->h_counters[til_idx];
+                lp ^= 1;
+                if (last) {
+                    if (nl > 0) {
+                        hipLaunchKernelGGL(k_carry, dim3(nl), dim3(256), 0, st, bufs, src_list, nl, sa_local, c->isa.as<u32>(), mode,
+                                           bufs.p[nb], nb, (u32)(nxt ? C_SEG1 : C_SEG0), cap32,
+                                           c->large_round[nxt].as<Desc>(), c->large_cap, (u32)((nxt ? C_LIST1 : C_LIST0) + 3), (u32)(nxt ? C_LTILES1 : C_LTILES0), counters);
+                    }
+                    break;
+                }
+                shift -= 8;
+            }
+        }
+        // ---- LDS sorts of everything that fits ----
+        Emit em;
+        em.pool_rec = c->pool_rec[nxt].as<u64>(); em.pool_hdr = c->pool_hdr[nxt].as<u64>();
+        em.seg_rec = bufs.p[nb]; em.seg_buf = nb;
+        em.pool_cnt_idx = nxt ? C_POOL1 : C_POOL0; em.seg_cnt_idx = nxt ? C_SEG1 : C_SEG0;
+        em.pool_cap = cap32; em.seg_cap = cap32;
+        em.lists = make_lists(nxt);
+        const u32 base = cur ? C_LIST1 : C_LIST0;
+        const u32 nA = c->h_counters[base + 0], nB = c->h_counters[base + 1], nC = c->h_counters[base + 2];
+        const u32 nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
+        if (nC) k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(nC), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
+                    bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters);
+        if (nB) k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(nB), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
+                    bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters);
+        if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS><<<dim3(nA), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
+                    bufs, c->lists[cur][0].as<Desc>(), nA, sa_local, c->isa.as<u32>(), mode, em, counters);
+        if (nP) hipLaunchKernelGGL(k_sort_tiny, dim3(cdiv(nP, 256)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(),
+                                   (u32)(cur ? C_POOL1 : C_POOL0), sa_local, c->isa.as<u32>(), mode,
+                                   em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32, counters);
+        if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
+        TRY(c->read_counters());
+        const u32 nb_base = nxt ? C_LIST1 : C_LIST0;
+        const u64 actP = c->h_counters[nxt ? C_POOL1 : C_POOL0], actS = c->h_counters[nxt ? C_SEG1 : C_SEG0];
+        if (verbose)
+            fprintf(stderr, "[msufsort_hip] round %d mode %s depth %llu: sorted A=%u B=%u C=%u tiny=%u -> next tiny=%llu seg=%llu (A=%u B=%u C=%u L=%u)\n",
+                    round, mode == MODE_TEXT ? "text" : "isa", (unsigned long long)depth, nA, nB, nC, nP, (unsigned long long)actP, (unsigned long long)actS,
+                    c->h_counters[nb_base], c->h_counters[nb_base + 1], c->h_counters[nb_base + 2], c->h_counters[nb_base + 3]);
+        if (round == 0) tm.unresolved_after_round0 = (int64_t)(actP + actS);
+        if (actP + actS == 0) break;
+        if (round > 200) { set_error("no convergence after %d rounds", round); return MSUFSORT_HIP_ERR_INTERNAL; }
+
+        // ---- prepare next round ----
+        cur = nxt;
+        { u32 third = 3 - sb - nb; sb = nb; nb = (round == 0) ? 0u : third; if (nb == sb) nb = (sb + 1) % 3; }
+        const u32 curP = cur ? C_POOL1 : C_POOL0, curS = cur ? C_SEG1 : C_SEG0, curL = cur ? C_LIST1 : C_LIST0;
+        const u32 oP = cur ? C_POOL0 : C_POOL1, oS = cur ? C_SEG0 : C_SEG1, oL = cur ? C_LIST0 : C_LIST1, oT = cur ? C_LTILES0 : C_LTILES1;
+        hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters,
+                           (1u << oP) | (1u << oS) | (0xfu << oL) | (1u << oT));
+        if (mode == MODE_TEXT && round + 1 > text_rounds) {
+            if (sharded) { set_error("ties deeper than %llu bytes in a sharded build (prefix doubling needs the full rank array)", (unsigned long long)depth); return MSUFSORT_HIP_ERR_UNSUPPORTED; }
+            // switch to prefix doubling: build the inverse suffix array
+            TRY(c->isa.ensure((size_t)(n + 1) * 4));
+            hipLaunchKernelGGL(k_isa_init, dim3(std::min<u32>(cdiv(m + z, 256), 65536u)), dim3(256), 0, st, sa_local, counters, c->isa.as<u32>(), (u32)n, (u32)z);
+            if (actP) hipLaunchKernelGGL(k_isa_pool, dim3(std::min<u32>(cdiv(actP, 256), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), counters, curP, c->isa.as<u32>());
+            for (int k = 0; k < 3; ++k) {
+                const u32 cnt = c->h_counters[curL + k];
+                if (cnt) hipLaunchKernelGGL(k_isa_segs, dim3(cnt), dim3(256), 0, st, bufs, c->lists[cur][k].as<Desc>(), cnt, counters, c->isa.as<u32>());
+            }
+            if (u32 cnt = c->h_counters[curL + 3]) hipLaunchKernelGGL(k_isa_segs, dim3(cnt), dim3(256), 0, st, bufs, c->large_round[cur].as<Desc>(), cnt, counters, c->isa.as<u32>());
+            mode = MODE_ISA;
+        }
+        // refill keys of all still-tied suffixes
+        if (actP) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actP, 256), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
+                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode);
+        if (actS) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actS, 256), 65536u)), dim3(256), 0, st, bufs.p[sb], counters, curS,
+                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode);
+        if (mode == MODE_TEXT) depth += 4; else { depth *= 2; tm.doubling_rounds++; }
+        tm.rounds++;
+    }
+    HIP_TRY(hipEventRecord(c->ev[5], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); tm.total_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); tm.hist16_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); tm.scatter0_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); tm.scatter1_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); tm.bucket_sort_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); tm.refine_ms = ms;
+    return MSUFSORT_HIP_OK;
+}
+
+int zero_pad(msufsort_hip_ctx* c, u8* d_text, u64 n)
+{
+    HIP_TRY(hipMemsetAsync(d_text + n, 0, MSUFSORT_HIP_TEXT_PAD, c->stream));
+    return MSUFSORT_HIP_OK;
+}
+
+int check_n(int64_t n)
+{
+    if (n < 0) { set_error("negative length"); return MSUFSORT_HIP_ERR_BAD_ARG; }
+    if (n > 0x7ffffffeLL) { set_error("n = %lld exceeds the int32 limit 2^31-2", (long long)n); return MSUFSORT_HIP_ERR_TOO_LARGE; }
+    return MSUFSORT_HIP_OK;
+}
+
+// temporary context for the host-pointer entry points
+struct TmpCtx {
+    msufsort_hip_ctx* c = nullptr;
+    ~TmpCtx() { if (c) msufsort_hip_ctx_destroy(c); }
+};
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int msufsort_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* msufsort_hip_strerror(int status)
+{
+    switch (status) {
+        case MSUFSORT_HIP_OK: return "ok";
+        case MSUFSORT_HIP_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+        case MSUFSORT_HIP_ERR_BAD_ARG: return "bad argument";
+        case MSUFSORT_HIP_ERR_TOO_LARGE: return "input too large for the int32 interface";
+        case MSUFSORT_HIP_ERR_HIP: return "HIP runtime error";
+        case MSUFSORT_HIP_ERR_NOMEM: return "out of device memory";
+        case MSUFSORT_HIP_ERR_INTERNAL: return "internal error";
+        case MSUFSORT_HIP_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}
+
+const char* msufsort_hip_last_error(void) { return g_last_error.c_str(); }
+
+int msufsort_hip_ctx_create(msufsort_hip_ctx** out, int32_t device, int64_t max_n)
+{
+    if (!out) return MSUFSORT_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    if (msufsort_hip_device_count() <= 0) { set_error("no HIP device visible"); return MSUFSORT_HIP_ERR_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(device));
+    auto* c = new msufsort_hip_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return MSUFSORT_HIP_ERR_HIP; }
+    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    (void)hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), C_NCOUNTERS * 4, hipHostMallocDefault);
+    (void)hipHostMalloc(reinterpret_cast<void**>(&c->h_bstart), 65537 * 4, hipHostMallocDefault);
+    if (!c->h_counters || !c->h_bstart) { msufsort_hip_ctx_destroy(c); set_error("hipHostMalloc failed"); return MSUFSORT_HIP_ERR_NOMEM; }
+    if (max_n > 0) {
+        int r = c->ensure_workspace((u64)max_n);
+        if (r) { msufsort_hip_ctx_destroy(c); return r; }
+    }
+    *out = c;
+    return MSUFSORT_HIP_OK;
+}
+
+void msufsort_hip_ctx_destroy(msufsort_hip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->release_all();
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->h_bstart) (void)hipHostFree(c->h_bstart);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void* msufsort_hip_ctx_stream(msufsort_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int msufsort_hip_ctx_sync(msufsort_hip_ctx* c)
+{
+    if (!c) return MSUFSORT_HIP_ERR_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_last_timings(msufsort_hip_ctx* c, msufsort_hip_timings* out)
+{
+    if (!c || !out) return MSUFSORT_HIP_ERR_BAD_ARG;
+    *out = c->tm;
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_sa_out, const msufsort_hip_opts* opts)
+{
+    if (!c || !d_sa_out || (n > 0 && !d_text)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n(n));
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) { HIP_TRY(hipMemsetAsync(d_sa_out, 0, 4, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); return MSUFSORT_HIP_OK; }
+    TRY(zero_pad(c, d_text, (u64)n));
+    u64 z = 0;
+    TRY(trailing_zeros(c, d_text, (u64)n, &z));
+    msufsort_hip_opts o{};
+    if (opts) o = *opts;
+    o.n_shards = 1; o.shard = 0;
+    return build_sa(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 65536, true, &o, false);
+}
+
+int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t n_shards, int64_t* bounds)
+{
+    if (!c || !bounds || n_shards < 1 || (n > 0 && !d_text)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n(n));
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) { for (int g = 0; g <= n_shards; ++g) bounds[g] = g ? 1 : 0; return MSUFSORT_HIP_OK; }
+    TRY(zero_pad(c, d_text, (u64)n));
+    u64 z = 0;
+    TRY(trailing_zeros(c, d_text, (u64)n, &z));
+    TRY(c->ensure_workspace((u64)n - z));
+    std::vector<u32> cuts; std::vector<u64> rows;
+    TRY(plan_shards(c, d_text, (u64)n, z, (u64)n - z, n_shards, cuts, rows));
+    for (int g = 0; g <= n_shards; ++g) bounds[g] = (int64_t)rows[g];
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_make_sa_shard_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_slice_out, int64_t slice_capacity,
+                                   int64_t* slice_lo, int64_t* slice_hi, const msufsort_hip_opts* opts)
+{
+    if (!c || !d_slice_out || !opts || opts->n_shards < 1 || opts->shard < 0 || opts->shard >= opts->n_shards || (n > 0 && !d_text)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n(n));
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) {
+        if (slice_lo) *slice_lo = 0;
+        if (slice_hi) *slice_hi = opts->shard == 0 ? 1 : 0;
+        if (opts->shard == 0) { HIP_TRY(hipMemsetAsync(d_slice_out, 0, 4, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+        return MSUFSORT_HIP_OK;
+    }
+    TRY(zero_pad(c, d_text, (u64)n));
+    u64 z = 0;
+    TRY(trailing_zeros(c, d_text, (u64)n, &z));
+    const u64 m = (u64)n - z;
+    TRY(c->ensure_workspace(m));
+    std::vector<u32> cuts; std::vector<u64> rows;
+    TRY(plan_shards(c, d_text, (u64)n, z, m, opts->n_shards, cuts, rows));
+    const int g = opts->shard;
+    const u64 lo = rows[g], hi = rows[g + 1];
+    if (slice_lo) *slice_lo = (int64_t)lo;
+    if (slice_hi) *slice_hi = (int64_t)hi;
+    if ((int64_t)(hi - lo) > slice_capacity) { set_error("slice needs %llu rows, capacity %lld", (unsigned long long)(hi - lo), (long long)slice_capacity); return MSUFSORT_HIP_ERR_BAD_ARG; }
+    if (hi == lo) return MSUFSORT_HIP_OK;
+    const bool hist_done = (m > 0 && opts->n_shards > 1);
+    return build_sa(c, d_text, (u64)n, reinterpret_cast<u32*>(d_slice_out), lo, z, cuts[g], cuts[g + 1], g == 0, opts, hist_done);
+}
+
+int msufsort_hip_make_sa_i32(const uint8_t* text, int64_t n, int32_t* sa_out, const msufsort_hip_opts* opts)
+{
+    if (!sa_out || (n > 0 && !text)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n(n));
+    if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
+    TmpCtx t;
+    TRY(msufsort_hip_ctx_create(&t.c, opts ? opts->device : 0, 0));
+    msufsort_hip_ctx* c = t.c;
+    TRY(c->text_own.ensure((size_t)n + MSUFSORT_HIP_TEXT_PAD));
+    TRY(c->sa_own.ensure(((size_t)n + 1) * 4));
+    HIP_TRY(hipMemcpyAsync(c->text_own.p, text, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    TRY(msufsort_hip_make_sa_i32_dev(c, c->text_own.as<u8>(), n, c->sa_own.as<int32_t>(), opts));
+    HIP_TRY(hipMemcpyAsync(sa_out, c->sa_own.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_debug_hist16_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, uint32_t* d_hist)
+{
+    if (!c || !d_text || !d_hist || n <= 0) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n(n));
+    HIP_TRY(hipSetDevice(c->device));
+    TRY(c->set_attrs());
+    TRY(zero_pad(c, d_text, (u64)n));
+    TRY(c->ensure_workspace((u64)n));
+    TRY(run_hist(c, d_text, (u64)n));
+    HIP_TRY(hipMemcpyAsync(d_hist, c->hist.p, 65536 * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MSUFSORT_HIP_OK;
+}
+
+#include "bwt_host.inc"
+
+}  // extern "C"

@@ -1,0 +1,962 @@
+// Device kernels of the MI355X (gfx950) suffix-array builder.  Included once by engine.hip.
+//
+// What is being replaced: the stage-1 hot path of the reference ITS sort -
+//   count_suffixes              reference msufsort.cpp:1496-1521  -> k_hist16 (+ k_reduce16/k_scan16)
+//   bucket offsets              reference msufsort.cpp:1603-1630  -> k_scan16
+//   initial_two_byte_radix_sort reference msufsort.cpp:1525-1555  -> k_scatter0 + k_partition (2 x 8 bit)
+//   multikey_quicksort          reference msufsort.cpp:488-642    -> k_sort_mid / k_sort_tiny (LDS radix on
+//                                                                    big-endian key words) + k_partition levels
+//   tandem-repeat shortcut      reference msufsort.cpp:316-484    -> prefix doubling on ranks (k_refill isa mode)
+// and, because every suffix is sorted here (no A/B/B* reduction), the stage-2 induction sweeps
+// (cpp:646-1057) have no counterpart: the output of the sorts is already the final suffix array.
+//
+// Order semantics.  The reference orders unsigned bytes with "a proper prefix sorts first"
+// (compare_suffixes cpp:147-180).  Here the text is treated as padded with infinitely many 0x00 bytes;
+// two suffixes then compare equal forever only if both lie inside the trailing 0x00 run of the text
+// (see DESIGN.md), so the host places those z suffixes first (ranks 0..z-1, descending index) and the
+// kernels sort the remaining m = n - z suffixes with plain unsigned key comparisons and no tie rule.
+//
+// Records are 64-bit: (key32 << 32) | suffix_index.  key32 is a big-endian window of the text
+// (get_value, cpp:129-143) or, in prefix-doubling rounds, the rank of suffix index+h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct Desc {            // one segment = run of records that are equal on everything consumed so far
+    u32 rec_off;         // first record (in record buffer `buf`)
+    u32 len;
+    u32 sa_off;          // first (shard-local) suffix-array row of the segment
+    u32 buf;             // record buffer index 0..2
+};
+
+struct RecBufs { u64* p[3]; };
+
+// counters block (device resident, read back by the host once per phase)
+enum {
+    C_POOL0 = 0, C_POOL1 = 1,         // tiny-pool element counts (slot 0/1)
+    C_SEG0 = 2, C_SEG1 = 3,           // segment-array element counts
+    C_LIST0 = 4,                      // [4..7]  slot 0: class A, B, C, large
+    C_LIST1 = 8,                      // [8..11] slot 1
+    C_LTILES0 = 12, C_LTILES1 = 13,   // tiles of the large list of slot 0/1
+    C_LVL0 = 14, C_LVL1 = 15,         // level ping-pong large lists
+    C_LVLT0 = 16, C_LVLT1 = 17,       // their tile counts
+    C_ERR = 18,
+    C_SENT = 19,                      // BWT sentinel row
+    C_MS = 20,                        // suffixes in this shard
+    C_RANK0 = 21,                     // global rank of the shard's first row
+    C_NCOUNTERS = 32
+};
+
+// size classes of the LDS sorts
+#define TINY_MAX 32
+#define CLS_A_THREADS 64
+#define CLS_A_ITEMS 8        // <= 512
+#define CLS_B_THREADS 256
+#define CLS_B_ITEMS 18       // <= 4608
+#define CLS_C_THREADS 1024
+#define CLS_C_ITEMS 18       // <= 18432
+#define CAP_A (CLS_A_THREADS * CLS_A_ITEMS)
+#define CAP_B (CLS_B_THREADS * CLS_B_ITEMS)
+#define CAP_C (CLS_C_THREADS * CLS_C_ITEMS)
+
+#define P1_THREADS 512
+#define P1_ITEMS 16
+#define P1_TILE (P1_THREADS * P1_ITEMS)      // 8192 records per tile
+
+#define MODE_TEXT 0
+#define MODE_ISA 1
+
+struct Lists {            // destination lists for segments discovered by a kernel
+    Desc* cls[3];         // A, B, C
+    u32 cap[3];
+    u32 cnt_idx;          // index of class-A counter in the counters block (B, C follow)
+};
+
+struct Emit {             // where still-tied runs go (next round)
+    u64* pool_rec;        // tiny pool: low 32 bits = suffix index
+    u64* pool_hdr;        // sa_start | len << 32 | off << 40
+    u64* seg_rec;         // segment array (record buffer `seg_buf`)
+    u32 seg_buf;
+    u32 pool_cnt_idx;     // counter indices
+    u32 seg_cnt_idx;
+    u32 pool_cap, seg_cap;
+    Lists lists;
+};
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ u32 wave_excl_scan(u32 v, u32& total)
+{
+    u32 x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 y = __shfl_up(x, d, 64);
+        if ((int)lane_id() >= d) x += y;
+    }
+    total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+// exclusive scan of 256 LDS values by the FIRST wave of the block (4 per lane); other waves skip.
+// caller: __syncthreads() before (inputs ready) and after (outputs ready).
+__device__ __forceinline__ u32 scan256_first_wave(const u32* in, u32* out)
+{
+    u32 total = 0;
+    if (threadIdx.x < 64) {
+        u32 l = threadIdx.x;
+        u32 t0 = in[4 * l], t1 = in[4 * l + 1], t2 = in[4 * l + 2], t3 = in[4 * l + 3];
+        u32 e = wave_excl_scan(t0 + t1 + t2 + t3, total);
+        out[4 * l] = e; out[4 * l + 1] = e + t0; out[4 * l + 2] = e + t0 + t1; out[4 * l + 3] = e + t0 + t1 + t2;
+    }
+    return total;   // valid in wave 0 only
+}
+
+__device__ __forceinline__ u32 class_of(u32 len)   // 0:A 1:B 2:C 3:large   (len > TINY_MAX)
+{
+    return len <= CAP_A ? 0u : (len <= CAP_B ? 1u : (len <= CAP_C ? 2u : 3u));
+}
+
+__device__ __forceinline__ u64 pack_hdr(u32 sa_start, u32 len, u32 off)
+{
+    return (u64)sa_start | ((u64)len << 32) | ((u64)off << 40);
+}
+
+__device__ __forceinline__ void push_desc(const Lists& L, u32* counters, u32 cls, Desc d)
+{
+    u32 i = atomicAdd(&counters[L.cnt_idx + cls], 1u);
+    if (i < L.cap[cls]) L.cls[cls][i] = d; else atomicOr(&counters[C_ERR], 1u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16-bit radix histogram (count_suffixes, cpp:1496-1521).  A 65,536-bin u32 histogram is 256 KiB and
+// does not fit the 160 KiB LDS, so each workgroup counts one HALF of the key space (32,768 bins =
+// 128 KiB) over its chunk of the text; two workgroups share a chunk.  16 B per lane coalesced loads.
+// partial[chunk][65536] is reduced by k_reduce16.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u32 m, u32 chunk_len,
+                                                 u32* __restrict__ partial)
+{
+    extern __shared__ u32 h_lds[];
+    const u32 chunk = blockIdx.x >> 1, half = blockIdx.x & 1u;
+    for (u32 i = threadIdx.x; i < 32768u; i += 1024u) h_lds[i] = 0;
+    __syncthreads();
+    const u64 cbeg = (u64)chunk * chunk_len;
+    u64 cend = cbeg + chunk_len;
+    if (cend > m) cend = m;
+    for (u64 base = cbeg + (u64)threadIdx.x * 16u; base < cend; base += 1024u * 16u) {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + base);
+        const u32 nxt = text[base + 16];
+        const u32 w[5] = {v.x, v.y, v.z, v.w, nxt};
+        const u32 lim = (u32)((cend - base) < 16 ? (cend - base) : 16);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+            const u32 b1 = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u;
+            const u32 key = (b0 << 8) | b1;
+            if ((u32)j < lim && (key >> 15) == half) atomicAdd(&h_lds[key & 0x7fffu], 1u);
+        }
+    }
+    __syncthreads();
+    u32* out = partial + (u64)chunk * 65536u + half * 32768u;
+    for (u32 i = threadIdx.x; i < 32768u; i += 1024u) out[i] = h_lds[i];
+}
+
+__global__ __launch_bounds__(1024) void k_reduce16(const u32* __restrict__ partial, u32 nchunks, u32* __restrict__ hist)
+{
+    const u32 key = blockIdx.x * 1024u + threadIdx.x;
+    u32 s = 0;
+    for (u32 c = 0; c < nchunks; ++c) s += partial[(u64)c * 65536u + key];
+    hist[key] = s;
+}
+
+// Exclusive scan of the 65,536 counts (bucket offsets, cpp:1603-1630) + set-up of the two scatter
+// levels for the key range [klo, khi) of this shard.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_scan16(const u32* __restrict__ hist, u32* __restrict__ bstart /*65537*/,
+                                                 u32 klo, u32 khi,
+                                                 u32* __restrict__ child_start, u32* __restrict__ child_cnt,
+                                                 u32* __restrict__ cursor1, u32* __restrict__ cursor0,
+                                                 Desc* __restrict__ seg0, u32* __restrict__ tile_start0 /*257*/,
+                                                 u32* __restrict__ counters, u32 z)
+{
+    __shared__ u32 wsum[16];
+    __shared__ u32 s_in[256], s_out[256];
+    const u32 t = threadIdx.x;
+    u32 loc = 0;
+    for (u32 k = 0; k < 64; ++k) loc += hist[t * 64 + k];
+    u32 wtot;
+    u32 ex = wave_excl_scan(loc, wtot);
+    if (lane_id() == 63) wsum[t >> 6] = wtot;
+    __syncthreads();
+    if (t < 64) {
+        u32 v = (t < 16) ? wsum[t] : 0, tot;
+        u32 e = wave_excl_scan(v, tot);
+        if (t < 16) wsum[t] = e;
+        if (t == 0) bstart[65536] = tot;
+    }
+    __syncthreads();
+    u32 run = wsum[t >> 6] + ex;
+    for (u32 k = 0; k < 64; ++k) { bstart[t * 64 + k] = run; run += hist[t * 64 + k]; }
+    __syncthreads();
+    const u32 base = bstart[klo];
+    for (u32 key = t; key < 65536u; key += 1024u) {
+        const bool in = key >= klo && key < khi;
+        const u32 s = in ? bstart[key] - base : 0u;
+        child_start[key] = s;
+        cursor1[key] = s;
+        child_cnt[key] = in ? hist[key] : 0u;
+    }
+    if (t < 256) {
+        u32 lo = t << 8, hi = (t + 1) << 8;
+        if (lo < klo) lo = klo;
+        if (hi > khi) hi = khi;
+        Desc d = {0, 0, 0, 0};
+        if (lo < hi) { d.rec_off = bstart[lo] - base; d.len = bstart[hi] - bstart[lo]; d.sa_off = d.rec_off; }
+        seg0[t] = d;
+        cursor0[t] = d.rec_off;
+        s_in[t] = (d.len + P1_TILE - 1) / P1_TILE;
+    }
+    __syncthreads();
+    u32 tt = scan256_first_wave(s_in, s_out);
+    if (t == 0) {
+        tile_start0[256] = tt;
+        counters[C_MS] = bstart[khi] - base;
+        counters[C_RANK0] = z + base;
+    }
+    __syncthreads();
+    if (t < 256) tile_start0[t] = s_out[t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level-0 scatter: text -> records bucketed by FIRST byte (initial_two_byte_radix_sort, cpp:1525-1555,
+// first half).  Record key = the 4 bytes that follow the first byte, so the next level needs no gather.
+// Per tile: LDS histogram with returning LDS atomics gives the rank inside the tile, one global atomic
+// per (tile, bin) claims the output range, records are staged bin-sorted in LDS and written as runs.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(P1_THREADS) void k_scatter0(const u8* __restrict__ text, u32 m, u32 klo, u32 khi,
+                                                         u32* __restrict__ cursor0, u64* __restrict__ out)
+{
+    __shared__ u64 stage[P1_TILE];
+    __shared__ u8 sbin[P1_TILE];
+    __shared__ u32 hist[256], lstart[256], gbase[256];
+    const u32 t = threadIdx.x;
+    const u64 base = (u64)blockIdx.x * P1_TILE + (u64)t * 16u;
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    u32 w[6] = {0, 0, 0, 0, 0, 0};
+    if (base < m) {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + base);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        w[4] = *reinterpret_cast<const u32*>(text + base + 16);
+        w[5] = 0;
+    }
+    u32 rank[16];
+    u32 validmask = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+        const u32 b1 = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u;
+        const u32 k16 = (b0 << 8) | b1;
+        const bool valid = (base + j < m) && k16 >= klo && k16 < khi;
+        rank[j] = 0;
+        if (valid) { rank[j] = atomicAdd(&hist[b0], 1u); validmask |= 1u << j; }
+    }
+    __syncthreads();
+    if (t < 256) {
+        const u32 c = hist[t];
+        gbase[t] = c ? atomicAdd(&cursor0[t], c) : 0u;
+    }
+    __syncthreads();
+    const u32 total = scan256_first_wave(hist, lstart);
+    __shared__ u32 s_total;
+    if (t == 0) s_total = total;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (validmask & (1u << j)) {
+            const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+            u32 key = 0;
+#pragma unroll
+            for (int q = 1; q <= 4; ++q)
+                key = (key << 8) | ((w[(j + q) >> 2] >> (8 * ((j + q) & 3))) & 255u);
+            const u32 slot = lstart[b0] + rank[j];
+            stage[slot] = ((u64)key << 32) | (u64)(u32)(base + j);
+            sbin[slot] = (u8)b0;
+        }
+    }
+    __syncthreads();
+    const u32 tot = s_total;
+    for (u32 s = t; s < tot; s += P1_THREADS) {
+        const u32 b = sbin[s];
+        out[gbase[b] + (s - lstart[b])] = stage[s];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic multi-tile partition level for LARGE segments (the role multikey_quicksort's partition
+// loop cpp:591-625 plays for big partitions): split every listed segment by one key byte.
+// k_count: per-segment 256-bin histogram; k_segscan: child offsets + cursors; k_partition: scatter.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 find_seg(const u32* __restrict__ tile_start, u32 nseg, u32 tile)
+{
+    u32 lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (tile_start[mid] <= tile) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(P1_THREADS) void k_count(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+                                                      const u32* __restrict__ tile_start, u32 shift,
+                                                      u32* __restrict__ seg_hist)
+{
+    __shared__ u32 hist[256];
+    __shared__ u32 s_seg;
+    const u32 t = threadIdx.x;
+    if (blockIdx.x >= tile_start[nseg]) return;
+    if (t == 0) s_seg = find_seg(tile_start, nseg, blockIdx.x);
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    const u32 s = s_seg;
+    const Desc d = list[s];
+    const u32 off = (blockIdx.x - tile_start[s]) * P1_TILE;
+    const u64* src = bufs.p[d.buf] + d.rec_off;
+#pragma unroll 4
+    for (int j = 0; j < P1_ITEMS; ++j) {
+        const u32 p = off + j * P1_THREADS + t;
+        if (p < d.len) atomicAdd(&hist[(u32)(src[p] >> (32 + shift)) & 255u], 1u);
+    }
+    __syncthreads();
+    if (t < 256 && hist[t]) atomicAdd(&seg_hist[(u64)s * 256u + t], hist[t]);
+}
+
+__global__ __launch_bounds__(256) void k_segscan(const Desc* __restrict__ list, u32 nseg,
+                                                 const u32* __restrict__ seg_hist,
+                                                 u32* __restrict__ child_start, u32* __restrict__ cursor,
+                                                 u32* __restrict__ trivial)
+{
+    __shared__ u32 s_in[256], s_out[256];
+    const u32 s = blockIdx.x, t = threadIdx.x;
+    if (s >= nseg) return;
+    const Desc d = list[s];
+    const u32 c = seg_hist[(u64)s * 256u + t];
+    s_in[t] = c;
+    __syncthreads();
+    scan256_first_wave(s_in, s_out);
+    __syncthreads();
+    const u32 st = d.rec_off + s_out[t];
+    child_start[(u64)s * 256u + t] = st;
+    cursor[(u64)s * 256u + t] = st;
+    if (c == d.len) trivial[s] = 1u;        // everything in one bin: the scatter is skipped
+    if (t == 0 && d.len == 0) trivial[s] = 1u;
+}
+
+__global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+                                                          const u32* __restrict__ tile_start, u32 shift,
+                                                          u32* __restrict__ cursor, const u32* __restrict__ trivial,
+                                                          u32 alt0, u32 alt1, u32 alt2)
+{
+    __shared__ u64 stage[P1_TILE];
+    __shared__ u8 sbin[P1_TILE];
+    __shared__ u32 hist[256], lstart[256], gbase[256];
+    __shared__ u32 s_seg, s_total;
+    const u32 t = threadIdx.x;
+    if (blockIdx.x >= tile_start[nseg]) return;
+    if (t == 0) s_seg = find_seg(tile_start, nseg, blockIdx.x);
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    const u32 s = s_seg;
+    if (trivial && trivial[s]) return;
+    const Desc d = list[s];
+    const u32 off = (blockIdx.x - tile_start[s]) * P1_TILE;
+    const u64* src = bufs.p[d.buf] + d.rec_off;
+    const u32 alt = d.buf == 0 ? alt0 : (d.buf == 1 ? alt1 : alt2);
+    u64* dst = bufs.p[alt];
+    u64 rec[P1_ITEMS];
+    u32 rank[P1_ITEMS];
+#pragma unroll
+    for (int j = 0; j < P1_ITEMS; ++j) {
+        const u32 p = off + j * P1_THREADS + t;
+        rec[j] = 0; rank[j] = 0xffffffffu;
+        if (p < d.len) {
+            rec[j] = src[p];
+            rank[j] = atomicAdd(&hist[(u32)(rec[j] >> (32 + shift)) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    if (t < 256) {
+        const u32 c = hist[t];
+        gbase[t] = c ? atomicAdd(&cursor[(u64)s * 256u + t], c) : 0u;
+    }
+    __syncthreads();
+    const u32 total = scan256_first_wave(hist, lstart);
+    if (t == 0) s_total = total;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < P1_ITEMS; ++j) {
+        if (rank[j] != 0xffffffffu) {
+            const u32 b = (u32)(rec[j] >> (32 + shift)) & 255u;
+            const u32 slot = lstart[b] + rank[j];
+            stage[slot] = rec[j];
+            sbin[slot] = (u8)b;
+        }
+    }
+    __syncthreads();
+    const u32 tot = s_total;
+    for (u32 q = t; q < tot; q += P1_THREADS) {
+        const u32 b = sbin[q];
+        dst[gbase[b] + (q - lstart[b])] = stage[q];
+    }
+}
+
+// Route the 256 children of every partitioned segment by size (partition scheduling, cpp:1652-1683,
+// becomes a size-class dispatch): 1 -> final, 2..32 -> tiny pool, 33..CAP_C -> LDS-sort lists,
+// larger -> next partition level.
+__global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __restrict__ parents, u32 nseg,
+                                                  const u32* __restrict__ child_start, const u32* __restrict__ child_cnt,
+                                                  const u32* __restrict__ trivial, u32 alt0, u32 alt1, u32 alt2,
+                                                  u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                  u64* __restrict__ pool_rec, u64* __restrict__ pool_hdr, u32 pool_cnt_idx, u32 pool_cap,
+                                                  Lists lists, Desc* __restrict__ lvl_dst, u32 lvl_cap, u32 lvl_cnt_idx, u32 lvl_tiles_idx,
+                                                  u32* __restrict__ counters)
+{
+    const u64 c = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (c >= (u64)nseg * 256u) return;
+    const u32 s = (u32)(c >> 8);
+    const u32 cnt = child_cnt[c];
+    if (cnt == 0) return;
+    const Desc par = parents[s];
+    const u32 start = child_start[c];
+    const bool triv = trivial && trivial[s];
+    const u32 buf = triv ? par.buf : (par.buf == 0 ? alt0 : (par.buf == 1 ? alt1 : alt2));
+    const u32 sa = par.sa_off + (start - par.rec_off);
+    const u64* src = bufs.p[buf] + start;
+    const u32 rank0 = counters[C_RANK0];
+    if (cnt == 1) {
+        const u32 idx = (u32)src[0];
+        sa_out[sa] = idx;
+        if (mode == MODE_ISA) isa[idx] = rank0 + sa + 1u;
+    } else if (cnt <= TINY_MAX) {
+        const u32 b = atomicAdd(&counters[pool_cnt_idx], cnt);
+        if (b + cnt > pool_cap) { atomicOr(&counters[C_ERR], 2u); return; }
+        for (u32 k = 0; k < cnt; ++k) { pool_rec[b + k] = src[k]; pool_hdr[b + k] = pack_hdr(sa, cnt, k); }
+    } else {
+        const Desc d = {start, cnt, sa, buf};
+        const u32 cls = class_of(cnt);
+        if (cls < 3) push_desc(lists, counters, cls, d);
+        else {
+            const u32 i = atomicAdd(&counters[lvl_cnt_idx], 1u);
+            if (i < lvl_cap) lvl_dst[i] = d; else atomicOr(&counters[C_ERR], 4u);
+            atomicAdd(&counters[lvl_tiles_idx], (cnt + P1_TILE - 1) / P1_TILE);
+        }
+    }
+}
+
+// exclusive scan of the tile counts of a large-segment list (single workgroup)
+__global__ __launch_bounds__(1024) void k_tiles(const Desc* __restrict__ list, u32 nseg, u32* __restrict__ tile_start)
+{
+    __shared__ u32 wsum[16];
+    __shared__ u32 s_carry;
+    const u32 t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 b = 0; b < nseg; b += 1024u) {
+        const u32 i = b + t;
+        const u32 v = i < nseg ? (list[i].len + P1_TILE - 1) / P1_TILE : 0u;
+        u32 wt;
+        const u32 e = wave_excl_scan(v, wt);
+        if (lane_id() == 63) wsum[t >> 6] = wt;
+        __syncthreads();
+        u32 wbase = 0, tot = 0;
+        for (u32 k = 0; k < 16; ++k) { if (k < (t >> 6)) wbase += wsum[k]; tot += wsum[k]; }
+        const u32 carry = s_carry;
+        if (i < nseg) tile_start[i] = carry + wbase + e;
+        __syncthreads();
+        if (t == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (t == 0) tile_start[nseg] = s_carry;
+}
+
+// Segments that stayed larger than CAP_C after all four key bytes: all keys equal, carry them to the
+// next round unchanged (one workgroup per segment).
+__global__ __launch_bounds__(256) void k_carry(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+                                               u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                               u64* __restrict__ seg_rec, u32 seg_buf, u32 seg_cnt_idx, u32 seg_cap,
+                                               Desc* __restrict__ large_next, u32 large_cap, u32 large_cnt_idx, u32 large_tiles_idx,
+                                               u32* __restrict__ counters)
+{
+    __shared__ u32 s_base, s_ok;
+    const u32 s = blockIdx.x;
+    if (s >= nseg) return;
+    const Desc d = list[s];
+    if (threadIdx.x == 0) {
+        const u32 b = atomicAdd(&counters[seg_cnt_idx], d.len);
+        s_base = b;
+        s_ok = 1;
+        if ((u64)b + d.len > seg_cap) { atomicOr(&counters[C_ERR], 8u); s_ok = 0; }
+        else {
+            const u32 i = atomicAdd(&counters[large_cnt_idx], 1u);
+            if (i < large_cap) { const Desc nd = {b, d.len, d.sa_off, seg_buf}; large_next[i] = nd; }
+            else { atomicOr(&counters[C_ERR], 16u); s_ok = 0; }
+            atomicAdd(&counters[large_tiles_idx], (d.len + P1_TILE - 1) / P1_TILE);
+        }
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const u64* src = bufs.p[d.buf] + d.rec_off;
+    const u32 rank0 = counters[C_RANK0];
+    for (u32 p = threadIdx.x; p < d.len; p += 256u) {
+        const u64 r = src[p];
+        seg_rec[s_base + p] = r;
+        sa_out[d.sa_off + p] = (u32)r;
+        if (mode == MODE_ISA) isa[(u32)r] = rank0 + d.sa_off + 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Key refill for the next round (get_value, cpp:129-143): key = big-endian 4-byte window of the text at
+// depth `d`, zero beyond the end; in prefix-doubling rounds key = rank of suffix index + h (0 past n).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32* __restrict__ counters, u32 cnt_idx,
+                                                const u8* __restrict__ text, const u32* __restrict__ isa,
+                                                u32 n, u64 depth, u32 mode)
+{
+    const u32 count = counters[cnt_idx];
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < count; i += (u64)gridDim.x * 256u) {
+        const u32 idx = (u32)rec[i];
+        const u64 pos = (u64)idx + depth;
+        u32 key = 0;
+        if (pos < n) {
+            if (mode == MODE_TEXT) {
+                u32 v;
+                __builtin_memcpy(&v, text + pos, 4);      // text is padded with >= 64 zero bytes
+                key = __builtin_bswap32(v);
+            } else key = isa[pos];
+        }
+        rec[i] = ((u64)key << 32) | idx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS sort of one mid-size segment (33 .. THREADS*ITEMS records) - the GPU counterpart of
+// multikey_quicksort + multikey_insertion_sort (cpp:488-642, 223-312) for one partition.
+// LSD radix on the key bytes that actually differ inside the segment, 8 bits per pass, stable ranks
+// from wave-wide digit matching (ballots) + per-wave digit counters in LDS.  After sorting: rows are
+// written to the suffix array, equal-key runs are detected with ballot bitmaps and the still-tied
+// runs are compacted into next round's tiny pool / segment array.
+// ------------------------------------------------------------------------------------------------
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+                                                      u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                      Emit em, u32* __restrict__ counters)
+{
+    constexpr int CAP = THREADS * ITEMS;
+    constexpr int W = THREADS / 64;
+    constexpr int NW = CAP / 64;                    // bitmap words
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int MSD_BITS = CAP >= 16384 ? 12 : (CAP >= 4096 ? 10 : 7);
+    constexpr int NBIN = 1 << MSD_BITS;                         // sub-buckets of the MSD fast path
+    constexpr int WCNT = (W * 256 > NBIN ? W * 256 : NBIN) + 8; // LSD per-wave digit counters / MSD histogram
+    constexpr u32 MSD_LIMIT = 48;                               // largest sub-bucket the counting rank accepts
+    u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP
+    u32* wcnt = ex + CAP;                                       // WCNT
+    u32* tot = wcnt + WCNT;                                     // 256
+    u32* dbase = tot + 256;                                     // 256
+    u64* bm_eq = reinterpret_cast<u64*>(dbase + 256);           // NW
+    u64* bm_tiny = bm_eq + NW;                                  // NW
+    u64* bm_seg = bm_tiny + NW;                                 // NW
+    u32* pre_tiny = reinterpret_cast<u32*>(bm_seg + NW);        // NW
+    u32* pre_seg = pre_tiny + NW;                               // NW
+    u32* misc = pre_seg + NW;                                   // 8
+
+    if (blockIdx.x >= nseg) return;
+    const Desc d = list[blockIdx.x];
+    const u32 len = d.len;
+    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const u32 wbase = wv * 64u * ITEMS;
+    const u64* src = bufs.p[d.buf] + d.rec_off;
+    const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+
+    u32 key[ITEMS], idx[ITEMS], pos[ITEMS];
+    u32 diff = 0;
+    const u32 key0 = (u32)(src[0] >> 32);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = wbase + j * 64 + lane;
+        key[j] = 0xffffffffu; idx[j] = 0xffffffffu;
+        if (p < len) { const u64 r = src[p]; key[j] = (u32)(r >> 32); idx[j] = (u32)r; diff |= key[j] ^ key0; }
+    }
+    // block-wide OR of diff
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) diff |= __shfl_xor(diff, s, 64);
+    if (t < 8) misc[t] = 0;
+    __syncthreads();
+    if (lane == 0 && diff) atomicOr(&misc[0], diff);
+    __syncthreads();
+    diff = misc[0];
+    // number of item rows this wave takes part in (rows with at least one valid element)
+    int rows = 0;
+    if (wbase < len) { const u32 rem = len - wbase; rows = (int)((rem + 63u) / 64u); if (rows > ITEMS) rows = ITEMS; }
+
+    // ---- fast path: one MSD split on the top varying bits into NBIN sub-buckets (unstable ranks from
+    // returning LDS atomics), then every record finds its final place by counting inside its sub-bucket.
+    // Uniformly distributed keys (round 0 of random input) give sub-buckets of ~4; skewed keys trip
+    // MSD_LIMIT and take the distribution-independent LSD passes below instead.
+    bool sorted_done = (diff == 0);
+    if (diff != 0) {
+        const int hb = 31 - __clz((int)diff);
+        const u32 sh = hb + 1 > MSD_BITS ? (u32)(hb + 1 - MSD_BITS) : 0u;
+        u32* hist = wcnt;
+        for (u32 i = t; i < (u32)NBIN + 1u; i += THREADS) hist[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (j < rows) {
+                const u32 p = wbase + j * 64 + lane;
+                if (p < len) pos[j] = atomicAdd(&hist[(key[j] >> sh) & (NBIN - 1)], 1u);
+            }
+        __syncthreads();
+        {   // exclusive scan of hist[NBIN] in place, E consecutive bins per thread; block max of the counts
+            constexpr int E = NBIN / THREADS;
+            u32 c[E], sum = 0, mx = 0;
+#pragma unroll
+            for (int k = 0; k < E; ++k) { c[k] = hist[t * E + k]; sum += c[k]; mx = c[k] > mx ? c[k] : mx; }
+            u32 wt;
+            u32 e = wave_excl_scan(sum, wt);
+#pragma unroll
+            for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(mx, s2, 64); mx = o > mx ? o : mx; }
+            if (lane == 63) tot[wv] = wt;
+            if (lane == 0) atomicMax(&misc[4], mx);
+            __syncthreads();
+            u32 wb = 0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) if (k < (int)wv) wb += tot[k];
+            e += wb;
+#pragma unroll
+            for (int k = 0; k < E; ++k) { hist[t * E + k] = e; e += c[k]; }
+            if (t == THREADS - 1) hist[NBIN] = e;
+        }
+        __syncthreads();
+        if (misc[4] <= MSD_LIMIT) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = wbase + j * 64 + lane;
+                    if (p < len) { pos[j] += hist[(key[j] >> sh) & (NBIN - 1)]; ex[pos[j]] = key[j]; }
+                }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = wbase + j * 64 + lane;
+                    if (p < len) {
+                        const u32 dg = (key[j] >> sh) & (NBIN - 1);
+                        const u32 b0 = hist[dg], b1 = hist[dg + 1], my = key[j], me = pos[j];
+                        u32 f = b0;
+                        for (u32 q = b0; q < b1; ++q) { const u32 kk = ex[q]; f += (kk < my) || (kk == my && q < me); }
+                        pos[j] = f;
+                    }
+                }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) if (j < rows) { const u32 p = wbase + j * 64 + lane; if (p < len) ex[pos[j]] = key[j]; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) if (j < rows) { const u32 p = wbase + j * 64 + lane; key[j] = p < len ? ex[p] : 0xffffffffu; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) if (j < rows) { const u32 p = wbase + j * 64 + lane; if (p < len) ex[pos[j]] = idx[j]; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) if (j < rows) { const u32 p = wbase + j * 64 + lane; idx[j] = p < len ? ex[p] : 0xffffffffu; }
+            __syncthreads();
+            sorted_done = true;
+        }
+    }
+
+    for (u32 shift = 0; shift < 32 && !sorted_done; shift += 8) {
+        if (((diff >> shift) & 255u) == 0) continue;            // byte equal everywhere: pass not needed
+        for (u32 i = t; i < (u32)W * 256u; i += THREADS) wcnt[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (j < rows) {
+                const u32 dg = (key[j] >> shift) & 255u;
+                u64 mask = ~0ull;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const bool bit = (dg >> b) & 1u;
+                    const u64 bal = __ballot(bit);
+                    mask &= bit ? bal : ~bal;
+                }
+                const int leader = __ffsll((long long)mask) - 1;
+                u32 old = 0;
+                if ((int)lane == leader) old = atomicAdd(&wcnt[wv * 256u + dg], (u32)__popcll(mask));
+                old = __shfl(old, leader, 64);
+                pos[j] = old + (u32)__popcll(mask & lt_mask);
+            }
+        }
+        __syncthreads();
+        for (u32 dg = t; dg < 256u; dg += THREADS) {
+            u32 run = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) { const u32 c = wcnt[w * 256 + dg]; wcnt[w * 256 + dg] = run; run += c; }
+            tot[dg] = run;
+        }
+        __syncthreads();
+        scan256_first_wave(tot, dbase);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (j < rows) {
+                const u32 dg = (key[j] >> shift) & 255u;
+                pos[j] += dbase[dg] + wcnt[wv * 256u + dg];
+                ex[pos[j]] = key[j];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) if (j < rows) key[j] = ex[wbase + j * 64 + lane];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[pos[j]] = idx[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) if (j < rows) idx[j] = ex[wbase + j * 64 + lane];
+        __syncthreads();
+    }
+
+    // ---- equal-key runs ----
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[wbase + j * 64 + lane] = key[j];
+    for (u32 i = t; i < (u32)NW; i += THREADS) { bm_eq[i] = 0; bm_tiny[i] = 0; bm_seg[i] = 0; }
+    __syncthreads();
+    bool any_eq = false;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if (j < rows) {
+            const u32 p = wbase + j * 64 + lane;
+            const bool eqn = (p + 1 < len) && (key[j] == ex[p + 1]);
+            const u64 bal = __ballot(eqn);
+            if (lane == 0) bm_eq[p >> 6] = bal;
+            any_eq |= (bal != 0);
+        }
+    __syncthreads();
+    // ex <- idx is not needed: idx stays in registers.  Write rows + ranks.
+    const u32 rank0 = counters[C_RANK0];
+    u32 rs[ITEMS], rl[ITEMS];        // run start / run length of each of my elements
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if (j < rows) {
+            const u32 p = wbase + j * 64 + lane;
+            rs[j] = p; rl[j] = 1;
+            if (p < len) {
+                const bool eqn = (bm_eq[p >> 6] >> (p & 63)) & 1ull;
+                const bool eqp = p > 0 && ((bm_eq[(p - 1) >> 6] >> ((p - 1) & 63)) & 1ull);
+                u32 s = p, e = p;
+                if (eqp) {
+                    const u32 q = p - 1;
+                    int w = (int)(q >> 6);
+                    u64 inv = ~bm_eq[w] & (~0ull >> (63 - (q & 63)));
+                    while (inv == 0 && w > 0) { --w; inv = ~bm_eq[w]; }
+                    s = inv ? (u32)((w << 6) + 63 - __clzll((long long)inv)) + 1u : 0u;
+                }
+                if (eqn) {
+                    int w = (int)(p >> 6);
+                    u64 inv = ~bm_eq[w] & (~0ull << (p & 63));
+                    while (inv == 0) { ++w; inv = ~bm_eq[w]; }
+                    e = (u32)((w << 6) + __ffsll((long long)inv) - 1);
+                }
+                rs[j] = s; rl[j] = e - s + 1;
+                sa_out[d.sa_off + p] = idx[j];
+                if (mode == MODE_ISA) isa[idx[j]] = rank0 + d.sa_off + s + 1u;
+            }
+        }
+    if (!__syncthreads_or(any_eq)) return;
+
+    // ---- compact still-tied runs into next round's structures ----
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if (j < rows) {
+            const u32 p = wbase + j * 64 + lane;
+            const bool tied = (p < len) && rl[j] > 1;
+            const u64 bt = __ballot(tied && rl[j] <= TINY_MAX);
+            const u64 bs = __ballot(tied && rl[j] > TINY_MAX);
+            if (lane == 0) { bm_tiny[p >> 6] = bt; bm_seg[p >> 6] = bs; }
+        }
+    __syncthreads();
+    if (t < 64) {
+        u32 ct = 0, cs = 0;
+        constexpr int PER = (NW + 63) / 64;
+        u32 lt_[PER], ls_[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int w = (int)t * PER + k;
+            lt_[k] = w < NW ? (u32)__popcll(bm_tiny[w]) : 0u;
+            ls_[k] = w < NW ? (u32)__popcll(bm_seg[w]) : 0u;
+            ct += lt_[k]; cs += ls_[k];
+        }
+        u32 tt, ts;
+        u32 et = wave_excl_scan(ct, tt);
+        u32 es = wave_excl_scan(cs, ts);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int w = (int)t * PER + k;
+            if (w < NW) { pre_tiny[w] = et; pre_seg[w] = es; }
+            et += lt_[k]; es += ls_[k];
+        }
+        if (t == 0) {
+            u32 bt = 0, bs = 0;
+            if (tt) { bt = atomicAdd(&counters[em.pool_cnt_idx], tt); if ((u64)bt + tt > em.pool_cap) { atomicOr(&counters[C_ERR], 32u); tt = 0xffffffffu; } }
+            if (ts) { bs = atomicAdd(&counters[em.seg_cnt_idx], ts); if ((u64)bs + ts > em.seg_cap) { atomicOr(&counters[C_ERR], 64u); ts = 0xffffffffu; } }
+            misc[1] = bt; misc[2] = bs; misc[3] = (tt == 0xffffffffu || ts == 0xffffffffu) ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (misc[3]) return;
+    const u32 base_t = misc[1], base_s = misc[2];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if (j < rows) {
+            const u32 p = wbase + j * 64 + lane;
+            if (p < len && rl[j] > 1) {
+                const u32 w = p >> 6;
+                if (rl[j] <= TINY_MAX) {
+                    const u32 o = base_t + pre_tiny[w] + (u32)__popcll(bm_tiny[w] & lt_mask);
+                    em.pool_rec[o] = (u64)idx[j];
+                    em.pool_hdr[o] = pack_hdr(d.sa_off + rs[j], rl[j], p - rs[j]);
+                } else {
+                    const u32 o = base_s + pre_seg[w] + (u32)__popcll(bm_seg[w] & lt_mask);
+                    em.seg_rec[o] = (u64)idx[j];
+                    if (p == rs[j]) {
+                        const Desc nd = {o, rl[j], d.sa_off + rs[j], em.seg_buf};
+                        push_desc(em.lists, counters, class_of(rl[j]), nd);
+                    }
+                }
+            }
+        }
+}
+
+template <int THREADS, int ITEMS>
+constexpr size_t sort_mid_lds_bytes()
+{
+    constexpr int CAP = THREADS * ITEMS;
+    constexpr int NBIN = 1 << (CAP >= 16384 ? 12 : (CAP >= 4096 ? 10 : 7));
+    constexpr int WC = ((THREADS / 64) * 256 > NBIN ? (THREADS / 64) * 256 : NBIN) + 8;
+    return (size_t)(THREADS * ITEMS) * 4 + (size_t)WC * 4 + 256 * 4 * 2 +
+           (size_t)(THREADS * ITEMS / 64) * (8 * 3 + 4 * 2) + 8 * 4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tiny runs (2..32 records), millions of them on text/DNA inputs: flat pool, one lane per record,
+// rank by counting inside the run (the insertion-sort regime of cpp:223-312).  A workgroup owns the
+// runs that START in its 256-slot window and loads a 31-slot halo.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_rec, const u64* __restrict__ pool_hdr,
+                                                   u32 cnt_idx, u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                   u64* __restrict__ next_rec, u64* __restrict__ next_hdr, u32 next_cnt_idx, u32 next_cap,
+                                                   u32* __restrict__ counters)
+{
+    constexpr int WIN = 256, HALO = 32, TOT = WIN + HALO;
+    __shared__ u32 lkey[TOT], lrun[TOT];
+    __shared__ u32 s_total, s_base;
+    const u32 count = counters[cnt_idx];
+    const u64 b0 = (u64)blockIdx.x * WIN;
+    if (b0 >= count) return;
+    const u32 t = threadIdx.x;
+    if (t == 0) s_total = 0;
+    u64 rec[2] = {0, 0}, hdr[2] = {0, 0};
+    bool have[2] = {false, false};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const u32 e = t + k * WIN;
+        if (e < TOT && b0 + e < count) { rec[k] = pool_rec[b0 + e]; hdr[k] = pool_hdr[b0 + e]; have[k] = true; lkey[e] = (u32)(rec[k] >> 32); }
+    }
+    __syncthreads();
+    const u32 rank0 = counters[C_RANK0];
+    u32 n_lt[2], n_eq[2], n_eqb[2], lead[2];
+    bool owned[2] = {false, false};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const u32 e = t + k * WIN;
+        n_lt[k] = n_eq[k] = n_eqb[k] = 0; lead[k] = 0;
+        if (have[k]) {
+            const u32 sa_start = (u32)hdr[k], len = (u32)(hdr[k] >> 32) & 255u, off = (u32)(hdr[k] >> 40) & 255u;
+            if (e >= off && e - off < WIN) {
+                owned[k] = true;
+                const u32 ls = e - off, my = lkey[e];
+                bool found = false;
+                for (u32 q = 0; q < len; ++q) {
+                    const u32 kk = lkey[ls + q];
+                    n_lt[k] += kk < my;
+                    if (kk == my) { if (!found) { found = true; lead[k] = ls + q; } n_eq[k]++; n_eqb[k] += q < off; }
+                }
+                const u32 row = sa_start + n_lt[k] + n_eqb[k];
+                sa_out[row] = (u32)rec[k];
+                if (mode == MODE_ISA) isa[(u32)rec[k]] = rank0 + sa_start + n_lt[k] + 1u;
+                if (n_eq[k] > 1 && n_eqb[k] == 0) lrun[e] = atomicAdd(&s_total, n_eq[k]);
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0 && s_total) {
+        const u32 b = atomicAdd(&counters[next_cnt_idx], s_total);
+        s_base = b;
+        if ((u64)b + s_total > next_cap) { atomicOr(&counters[C_ERR], 128u); s_base = 0xffffffffu; }
+    }
+    __syncthreads();
+    if (s_total == 0 || s_base == 0xffffffffu) return;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (owned[k] && n_eq[k] > 1) {
+            const u32 sa_start = (u32)hdr[k];
+            const u32 o = s_base + lrun[lead[k]] + n_eqb[k];
+            next_rec[o] = (u64)(u32)rec[k];
+            next_hdr[o] = pack_hdr(sa_start + n_lt[k], n_eq[k], n_eqb[k]);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inverse suffix array for the prefix-doubling rounds (replaces the tandem-repeat machinery,
+// cpp:316-484).  isa[i] = 1 + rank of suffix i; still-tied suffixes get the rank of their group head.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_isa_init(const u32* __restrict__ sa_local, const u32* __restrict__ counters,
+                                                  u32* __restrict__ isa, u32 n, u32 z)
+{
+    const u32 ms = counters[C_MS], rank0 = counters[C_RANK0];
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < (u64)ms + z; i += (u64)gridDim.x * 256u) {
+        if (i < ms) isa[sa_local[i]] = rank0 + (u32)i + 1u;
+        else { const u32 j = (u32)(i - ms); isa[n - 1 - j] = j + 1u; }     // trailing 0x00 run
+    }
+}
+
+__global__ __launch_bounds__(256) void k_isa_pool(const u64* __restrict__ pool_rec, const u64* __restrict__ pool_hdr,
+                                                  const u32* __restrict__ counters, u32 cnt_idx, u32* __restrict__ isa)
+{
+    const u32 count = counters[cnt_idx], rank0 = counters[C_RANK0];
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < count; i += (u64)gridDim.x * 256u)
+        isa[(u32)pool_rec[i]] = rank0 + (u32)pool_hdr[i] + 1u;
+}
+
+__global__ __launch_bounds__(256) void k_isa_segs(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+                                                  const u32* __restrict__ counters, u32* __restrict__ isa)
+{
+    if (blockIdx.x >= nseg) return;
+    const Desc d = list[blockIdx.x];
+    const u32 rank0 = counters[C_RANK0];
+    const u64* src = bufs.p[d.buf] + d.rec_off;
+    for (u32 p = threadIdx.x; p < d.len; p += 256u) isa[(u32)src[p]] = rank0 + d.sa_off + 1u;
+}
+
+// SA[0] = n and the trailing-zero-run rows (descending index)
+__global__ __launch_bounds__(256) void k_sa_head(u32* __restrict__ sa, u32 n, u32 z)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) sa[0] = n;
+    if (i < z) sa[1 + i] = n - 1 - (u32)i;
+}

@@ -1,0 +1,176 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, reached through the C-ABI, against the oracle,
+the committed golden vectors of the unmodified reference, and size-independent properties."""
+import numpy as np
+import pytest
+
+from msufsort_amd import gen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    import msufsort_amd as m
+    assert m.device_count() > 0, "no GPU visible: the product path has no CPU fallback"
+    return m
+
+
+def _input(d):
+    if "text" in d:
+        return np.array(d["text"], dtype=np.uint8)
+    if "alphabet" in d:
+        return gen.sweep_bytes(d["alphabet"], d["n"])
+    if d["generator"] == "tile37":
+        return np.tile(gen.dna_bytes(37, d["seed"]), 5000)
+    return gen.GENERATORS[d["generator"]](d["n"], d["seed"])
+
+
+def _check_golden(M, oracle, d, literal=False):
+    t = _input(d)
+    assert "%016x" % oracle.fnv1a64(t) == d["input_fnv"]
+    sa = M.make_suffix_array(t)
+    assert sa[0] == d["n"] and sa[1] == d["sa_first"] and sa[-1] == d["sa_last"]
+    assert "%016x" % oracle.fnv1a64(sa) == d["sa_fnv"]
+    bwt, sent = M.forward_burrows_wheeler_transform(t)
+    assert sent == d["sentinel"]
+    assert "%016x" % oracle.fnv1a64(bwt) == d["bwt_fnv"]
+    assert (M.reverse_burrows_wheeler_transform(bwt, sent) == t).all()
+    lcp = M.make_lcp_array(t, sa)
+    assert "%016x" % oracle.fnv1a64(lcp) == d["lcp_fnv"]
+    if literal:
+        assert sa.tolist() == d["sa"] and bwt.tolist() == d["bwt"] and lcp.tolist() == d["lcp"]
+
+
+def test_literal_golden(M, oracle_mod, golden):
+    for d in golden["literal"]:
+        _check_golden(M, oracle_mod, d, literal=True)
+
+
+def test_empty_input(M):
+    assert M.make_suffix_array(b"").tolist() == [0]
+    b, s = M.forward_burrows_wheeler_transform(b"")
+    assert b.size == 0 and s == 0
+
+
+def test_sweep_golden(M, oracle_mod, golden):
+    # thinned version of the demo's self test, reference main.cpp:389-435
+    for d in golden["sweep"]:
+        _check_golden(M, oracle_mod, d)
+
+
+@pytest.mark.parametrize("i", range(10))
+def test_generated_golden(M, oracle_mod, golden, i):
+    _check_golden(M, oracle_mod, golden["generated"][i])
+
+
+def test_class_api(M, oracle_mod):
+    s = M.msufsort(4)
+    t = gen.text_bytes(30000, 8)
+    sa = s.make_suffix_array(t)
+    assert (sa == oracle_mod.make_suffix_array(t)).all()
+    b, r = s.forward_burrows_wheeler_transform(t)
+    assert (M.msufsort.reverse_burrows_wheeler_transform(b, r, 4) == t).all()
+    # int8 input is reinterpreted as uint8 like the reference templates (h:444)
+    t8 = gen.random_bytes(5000, 2).view(np.int8)
+    assert (M.make_suffix_array(t8) == oracle_mod.make_suffix_array(t8.view(np.uint8))).all()
+
+
+@pytest.mark.parametrize("alphabet,n", [(1, 70000), (2, 200000), (4, 1 << 20), (256, 1 << 22)])
+def test_vs_oracle_sizes(M, oracle_mod, alphabet, n):
+    t = gen.sweep_bytes(alphabet, n) if alphabet < 256 else gen.random_bytes(n, 99)
+    sa = M.make_suffix_array(t)
+    want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+    assert (sa == want).all()
+
+
+def test_edge_cases(M, oracle_mod):
+    cases = [b"\x00" * 70000, b"\xff" * 40000, b"ab" * 30000 + b"\x00" * 100, b"\x00\x01" * 25000,
+             bytes(gen.random_bytes(100000, 6) % 3) + b"\x00" * 5000,
+             b"a" * 20000 + b"b" + b"a" * 20000, bytes(range(256)) * 300]
+    for c in cases:
+        t = np.frombuffer(c, dtype=np.uint8)
+        sa = M.make_suffix_array(t)
+        want = oracle_mod.ref_make_suffix_array(t, 4) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+        assert (sa == want).all()
+        b, s = M.forward_burrows_wheeler_transform(t)
+        assert (M.reverse_burrows_wheeler_transform(b, s) == t).all()
+
+
+def test_prefix_doubling_path(M, oracle_mod):
+    # force the switch to rank doubling after one key round
+    t = gen.dna_tandem_bytes(400000, 5)
+    sa = M.make_suffix_array(t, text_rounds=1)
+    want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else None
+    if want is not None:
+        assert (sa == want).all()
+    assert oracle_mod.validate_sa(t, sa) == 0
+
+
+def _dev(M, t):
+    import torch
+    n = t.size
+    d = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+    d[:n] = torch.from_numpy(t).cuda()
+    return d
+
+
+def test_device_api_and_checker(M, oracle_mod):
+    import torch
+    t = gen.text_bytes(1 << 21, 4)
+    n = t.size
+    ctx = M.DeviceContext(0)
+    d = _dev(M, t)
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, n, sa)
+    assert ctx.validate_sa(d, n, sa) == 0
+    want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+    assert (sa.cpu().numpy() == want).all()
+    # the on-device checker must see a broken array
+    bad = sa.clone()
+    bad[1000], bad[1001] = sa[1001].item(), sa[1000].item()
+    assert ctx.validate_sa(d, n, bad) > 0
+    # hist16 probe against numpy
+    h = torch.zeros(65536, dtype=torch.int32, device="cuda")
+    ctx.debug_hist16(d, n, h)
+    tt = np.concatenate([t, np.zeros(1, np.uint8)]).astype(np.uint32)
+    assert (h.cpu().numpy() == np.bincount((tt[:-1] << 8) | tt[1:], minlength=65536)).all()
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_logical_shards_concatenate(M, oracle_mod, shards):
+    """G logical shards on one device must reassemble to the full array."""
+    import torch
+    for t in (gen.random_bytes(3 << 20, 31), gen.text_bytes(1 << 20, 6)):
+        n = t.size
+        ctx = M.DeviceContext(0)
+        d = _dev(M, t)
+        full = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        bounds = ctx.shard_bounds(d, n, shards)
+        assert bounds[0] == 0 and bounds[-1] == n + 1 and all(a <= b for a, b in zip(bounds, bounds[1:]))
+        for g in range(shards):
+            lo, hi = bounds[g], bounds[g + 1]
+            sl = full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device="cuda")
+            l2, h2 = ctx.make_sa_shard(d, n, sl, max(hi - lo, 1), g, shards, text_rounds=16)
+            assert (l2, h2) == (lo, hi)
+        want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+        assert (full.cpu().numpy() == want).all()
+
+
+def test_large_random_properties(M):
+    """256 MiB uniform random (BASELINE config 2): on-device checker (order + permutation),
+    BWT -> inverse BWT round trip, all in HBM."""
+    import torch
+    n = 1 << 28
+    t = gen.random_bytes(n, 12345)
+    ctx = M.DeviceContext(0)
+    d = _dev(M, t)
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, n, sa)
+    assert ctx.validate_sa(d, n, sa) == 0
+    assert int(sa[0]) == n
+    bwt = torch.empty(n, dtype=torch.uint8, device="cuda")
+    sent = ctx.bwt_from_sa(d, n, sa, bwt)
+    assert 1 <= sent <= n and int(sa[sent]) == 0
+    inv = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ctx.inverse_bwt(bwt, n, sent, inv)
+    assert torch.equal(inv, d[:n])
