@@ -72,7 +72,7 @@ struct msufsort_hip_ctx {
     DevBuf rec[3], pool_rec[2], pool_hdr[2];
     DevBuf lists[2][3], large_round[2], lvl[2], seg0;
     DevBuf hist_partial, hist, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
-    DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2;
+    DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, doneB, doneC;
     u32* h_counters = nullptr;   // pinned
     u32* h_bstart = nullptr;     // pinned, 65537
     u32 list_cap[3] = {0, 0, 0};
@@ -91,6 +91,10 @@ struct msufsort_hip_ctx {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast<CLS_C_THREADS, CLS_C_ITEMS, 14, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS, 14>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast<CLS_B_THREADS, CLS_B_ITEMS, 12, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12>()));
         attrs_set = true;
         return MSUFSORT_HIP_OK;
     }
@@ -124,6 +128,8 @@ struct msufsort_hip_ctx {
         TRY(hist.ensure(65536 * 4));
         TRY(bstart.ensure(65537 * 4));
         TRY(counters.ensure(C_NCOUNTERS * 4));
+        TRY(doneB.ensure((size_t)list_cap[1] * 4));
+        TRY(doneC.ensure((size_t)list_cap[2] * 4));
         cap_m = cap;
         return MSUFSORT_HIP_OK;
     }
@@ -136,7 +142,7 @@ struct msufsort_hip_ctx {
         for (int s = 0; s < 2; ++s) { for (int c = 0; c < 3; ++c) lists[s][c].release(); large_round[s].release(); lvl[s].release(); }
         seg0.release(); hist_partial.release(); hist.release(); bstart.release(); child_start.release(); child_cnt.release();
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
-        isa.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release();
+        isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release();
         cap_m = 0;
     }
 
@@ -355,12 +361,31 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         const u32 base = cur ? C_LIST1 : C_LIST0;
         const u32 nA = c->h_counters[base + 0], nB = c->h_counters[base + 1], nC = c->h_counters[base + 2];
         const u32 nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
-        if (nC) k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(nC), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
-                    bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters);
-        if (nB) k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(nB), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
-                    bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters);
+        const bool use_fast = getenv("MSUFSORT_HIP_NO_FAST") == nullptr;
+        if (nC) {
+            const u32* skip = nullptr;
+            if (use_fast) {
+                HIP_TRY(hipMemsetAsync(c->doneC.p, 0, (size_t)nC * 4, st));
+                k_sort_fast<CLS_C_THREADS, CLS_C_ITEMS, 14, false><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_fast_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS, 14>(), st>>>(
+                    bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneC.as<u32>());
+                skip = c->doneC.as<u32>();
+            }
+            k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(nC), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
+                bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, skip);
+        }
+        if (nB) {
+            const u32* skip = nullptr;
+            if (use_fast) {
+                HIP_TRY(hipMemsetAsync(c->doneB.p, 0, (size_t)nB * 4, st));
+                k_sort_fast<CLS_B_THREADS, CLS_B_ITEMS, 12, true><<<dim3(std::min<u32>(nB, 256u * 4u)), dim3(CLS_B_THREADS), sort_fast_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12>(), st>>>(
+                    bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneB.as<u32>());
+                skip = c->doneB.as<u32>();
+            }
+            k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(nB), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
+                bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, skip);
+        }
         if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS><<<dim3(nA), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
-                    bufs, c->lists[cur][0].as<Desc>(), nA, sa_local, c->isa.as<u32>(), mode, em, counters);
+                    bufs, c->lists[cur][0].as<Desc>(), nA, sa_local, c->isa.as<u32>(), mode, em, counters, (const u32*)nullptr);
         if (nP) hipLaunchKernelGGL(k_sort_tiny, dim3(cdiv(nP, 256)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(),
                                    (u32)(cur ? C_POOL1 : C_POOL0), sa_local, c->isa.as<u32>(), mode,
                                    em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32, counters);

@@ -266,11 +266,9 @@ __global__ __launch_bounds__(P1_THREADS) void k_scatter0(const u8* __restrict__ 
         if (valid) { rank[j] = atomicAdd(&hist[b0], 1u); validmask |= 1u << j; }
     }
     __syncthreads();
-    if (t < 256) {
-        const u32 c = hist[t];
-        gbase[t] = c ? atomicAdd(&cursor0[t], c) : 0u;
-    }
-    __syncthreads();
+    // claim the output ranges now, consume the answer after staging (hides the atomic's latency)
+    u32 claim = 0;
+    if (t < 256) { const u32 c = hist[t]; if (c) claim = atomicAdd(&cursor0[t], c); }
     const u32 total = scan256_first_wave(hist, lstart);
     __shared__ u32 s_total;
     if (t == 0) s_total = total;
@@ -288,6 +286,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_scatter0(const u8* __restrict__ 
             sbin[slot] = (u8)b0;
         }
     }
+    if (t < 256) gbase[t] = claim;
     __syncthreads();
     const u32 tot = s_total;
     for (u32 s = t; s < tot; s += P1_THREADS) {
@@ -389,11 +388,8 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
         }
     }
     __syncthreads();
-    if (t < 256) {
-        const u32 c = hist[t];
-        gbase[t] = c ? atomicAdd(&cursor[(u64)s * 256u + t], c) : 0u;
-    }
-    __syncthreads();
+    u32 claim = 0;
+    if (t < 256) { const u32 c = hist[t]; if (c) claim = atomicAdd(&cursor[(u64)s * 256u + t], c); }
     const u32 total = scan256_first_wave(hist, lstart);
     if (t == 0) s_total = total;
     __syncthreads();
@@ -406,6 +402,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
             sbin[slot] = (u8)b;
         }
     }
+    if (t < 256) gbase[t] = claim;
     __syncthreads();
     const u32 tot = s_total;
     for (u32 q = t; q < tot; q += P1_THREADS) {
@@ -426,35 +423,48 @@ __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __re
                                                   u32* __restrict__ counters)
 {
     const u64 c = (u64)blockIdx.x * 256u + threadIdx.x;
-    if (c >= (u64)nseg * 256u) return;
-    const u32 s = (u32)(c >> 8);
-    const u32 cnt = child_cnt[c];
-    if (cnt == 0) return;
-    const Desc par = parents[s];
-    const u32 start = child_start[c];
-    const bool triv = trivial && trivial[s];
-    const u32 buf = triv ? par.buf : (par.buf == 0 ? alt0 : (par.buf == 1 ? alt1 : alt2));
-    const u32 sa = par.sa_off + (start - par.rec_off);
+    const bool live = c < (u64)nseg * 256u;
+    const u32 s = live ? (u32)(c >> 8) : 0u;
+    const u32 cnt = live ? child_cnt[c] : 0u;
+    Desc par = {0, 0, 0, 0};
+    u32 start = 0, buf = 0, sa = 0;
+    if (cnt) {
+        par = parents[s];
+        start = child_start[c];
+        const bool triv = trivial && trivial[s];
+        buf = triv ? par.buf : (par.buf == 0 ? alt0 : (par.buf == 1 ? alt1 : alt2));
+        sa = par.sa_off + (start - par.rec_off);
+    }
     const u64* src = bufs.p[buf] + start;
     const u32 rank0 = counters[C_RANK0];
     if (cnt == 1) {
         const u32 idx = (u32)src[0];
         sa_out[sa] = idx;
         if (mode == MODE_ISA) isa[idx] = rank0 + sa + 1u;
-    } else if (cnt <= TINY_MAX) {
+    } else if (cnt > 1 && cnt <= TINY_MAX) {
         const u32 b = atomicAdd(&counters[pool_cnt_idx], cnt);
-        if (b + cnt > pool_cap) { atomicOr(&counters[C_ERR], 2u); return; }
-        for (u32 k = 0; k < cnt; ++k) { pool_rec[b + k] = src[k]; pool_hdr[b + k] = pack_hdr(sa, cnt, k); }
-    } else {
-        const Desc d = {start, cnt, sa, buf};
-        const u32 cls = class_of(cnt);
-        if (cls < 3) push_desc(lists, counters, cls, d);
-        else {
-            const u32 i = atomicAdd(&counters[lvl_cnt_idx], 1u);
-            if (i < lvl_cap) lvl_dst[i] = d; else atomicOr(&counters[C_ERR], 4u);
-            atomicAdd(&counters[lvl_tiles_idx], (cnt + P1_TILE - 1) / P1_TILE);
+        if (b + cnt > pool_cap) atomicOr(&counters[C_ERR], 2u);
+        else for (u32 k = 0; k < cnt; ++k) { pool_rec[b + k] = src[k]; pool_hdr[b + k] = pack_hdr(sa, cnt, k); }
+    }
+    // descriptors: one counter atomic per wave and class instead of one per child
+    const u32 cls = cnt > TINY_MAX ? class_of(cnt) : 4u;
+    const u64 lt_mask = lane_id() ? (~0ull >> (64 - lane_id())) : 0ull;
+    const Desc d = {start, cnt, sa, buf};
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+        const u64 m = __ballot(cls == k);
+        if (m == 0) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        u32 base = 0;
+        if ((int)lane_id() == leader) base = atomicAdd(&counters[k < 3 ? lists.cnt_idx + k : lvl_cnt_idx], (u32)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (cls == k) {
+            const u32 i = base + (u32)__popcll(m & lt_mask);
+            if (k < 3) { if (i < lists.cap[k]) lists.cls[k][i] = d; else atomicOr(&counters[C_ERR], 1u); }
+            else { if (i < lvl_cap) lvl_dst[i] = d; else atomicOr(&counters[C_ERR], 4u); }
         }
     }
+    if (cls == 3) atomicAdd(&counters[lvl_tiles_idx], (cnt + P1_TILE - 1) / P1_TILE);
 }
 
 // exclusive scan of the tile counts of a large-segment list (single workgroup)
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32
 template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                       u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
-                                                      Emit em, u32* __restrict__ counters)
+                                                      Emit em, u32* __restrict__ counters, const u32* __restrict__ skip)
 {
     constexpr int CAP = THREADS * ITEMS;
     constexpr int W = THREADS / 64;
@@ -576,6 +586,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_mid(RecBufs bufs, const Desc* 
     u32* misc = pre_seg + NW;                                   // 8
 
     if (blockIdx.x >= nseg) return;
+    if (skip && skip[blockIdx.x]) return;           // already sorted by k_sort_fast
     const Desc d = list[blockIdx.x];
     const u32 len = d.len;
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
@@ -840,6 +851,207 @@ __global__ __launch_bounds__(THREADS) void k_sort_mid(RecBufs bufs, const Desc* 
                 }
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast LDS sort for segments whose keys are spread out (the 16-bit buckets of round 0 on random-like
+// input).  Persistent workgroups (static stride over the list), the next segment's records are
+// prefetched into registers while the current one is sorted:
+//   1. one MSD split on the top varying BITS of the key into 2^BITS sub-buckets; the rank inside the
+//      sub-bucket comes from a returning LDS atomic (order inside a sub-bucket is arbitrary);
+//   2. block-wide exclusive scan of the sub-bucket counts;
+//   3. every record counts, inside its own (tiny) sub-bucket, the keys below it and the equal keys before
+//      it: that IS its final row, and the number of equal keys IS its tie-run length - no second pass,
+//      no neighbour compares;
+//   4. suffix indices are exchanged through LDS and written to the suffix array coalesced.
+// A segment with a sub-bucket above FAST_LIMIT (skewed keys) is left to k_sort_mid (done[seg] stays 0).
+// ------------------------------------------------------------------------------------------------
+#define FAST_LIMIT 40u
+template <int THREADS, int ITEMS, int BITS, bool PREFETCH>
+__global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+                                                       u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                       Emit em, u32* __restrict__ counters, u32* __restrict__ done)
+{
+    constexpr int CAP = THREADS * ITEMS;
+    constexpr int W = THREADS / 64;
+    constexpr int NBIN = 1 << BITS;
+    constexpr int E = NBIN / THREADS;
+    constexpr u32 TRASH_POS = CAP;            // ex slot that absorbs the lanes past the end of the segment
+    constexpr u32 TRASH_BIN = NBIN + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP + 64
+    u32* hist = ex + CAP + 64;                                  // NBIN + 16
+    u32* tot = hist + NBIN + 16;                                // 16
+    u32* misc = tot + 16;                                       // 16
+
+    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const u32 wbase = wv * 64u * ITEMS;
+    u32 seg = blockIdx.x;
+    if (seg >= nseg) return;
+    Desc d = list[seg];
+    u64 nrec[ITEMS];
+    {
+        const u64* src = bufs.p[d.buf] + d.rec_off;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; nrec[j] = p < d.len ? src[p] : ~0ull; }
+    }
+    const u32 rank0 = counters[C_RANK0];
+    for (;;) {
+        const u32 len = d.len, sa_off = d.sa_off, cur = seg;
+        u32 key[ITEMS], idx[ITEMS], pos[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { key[j] = (u32)(nrec[j] >> 32); idx[j] = (u32)nrec[j]; }
+        seg += gridDim.x;
+        const bool more = seg < nseg;
+        bool fetched = false;
+        int rows = 0;
+        if (wbase < len) { const u32 rem = len - wbase; rows = (int)((rem + 63u) / 64u); if (rows > ITEMS) rows = ITEMS; }
+
+        if (t < 16) misc[t] = 0;
+        for (u32 i = t; i < (u32)NBIN + 16u; i += THREADS) hist[i] = 0;
+        if (t == 0) misc[5] = key[0];
+        __syncthreads();                                                            // (1)
+        u32 diff = 0;
+        { const u32 k0 = misc[5];
+#pragma unroll
+          for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; diff |= (p < len) ? (key[j] ^ k0) : 0u; } }
+#pragma unroll
+        for (int s2 = 32; s2 >= 1; s2 >>= 1) diff |= __shfl_xor(diff, s2, 64);
+        if (lane == 0 && diff) atomicOr(&misc[0], diff);
+        __syncthreads();                                                            // (2)
+        diff = misc[0];
+        const int hb = diff ? 31 - __clz((int)diff) : 0;
+        const u32 sh = hb + 1 > BITS ? (u32)(hb + 1 - BITS) : 0u;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (j < rows) {
+                const u32 p = wbase + j * 64 + lane;
+                const u32 dg = p < len ? ((key[j] >> sh) & (NBIN - 1)) : TRASH_BIN;
+                pos[j] = atomicAdd(&hist[dg], 1u);
+            }
+        __syncthreads();                                                            // (3)
+        {   // exclusive scan of hist[0..NBIN) in place, E consecutive bins per thread; block max of the counts
+            u32 sum = 0, mx = 0;
+#pragma unroll
+            for (int k = 0; k < E; ++k) { const u32 c = hist[t * E + k]; sum += c; mx = c > mx ? c : mx; }
+            u32 wt;
+            u32 e = wave_excl_scan(sum, wt);
+#pragma unroll
+            for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(mx, s2, 64); mx = o > mx ? o : mx; }
+            if (lane == 63) tot[wv] = wt;
+            if (lane == 0) atomicMax(&misc[1], mx);
+            __syncthreads();                                                        // (4)
+            u32 wb = 0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) if (k < (int)wv) wb += tot[k];
+            e += wb;
+#pragma unroll
+            for (int k = 0; k < E; ++k) { const u32 c = hist[t * E + k]; hist[t * E + k] = e; e += c; }
+            if (t == THREADS - 1) hist[NBIN] = e;
+        }
+        __syncthreads();                                                            // (5)
+        const bool ok = diff != 0 && misc[1] <= FAST_LIMIT;
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = wbase + j * 64 + lane;
+                    const bool v = p < len;
+                    const u32 dg = (key[j] >> sh) & (NBIN - 1);
+                    pos[j] = v ? hist[dg] + pos[j] : TRASH_POS;
+                    ex[pos[j]] = key[j];
+                }
+            __syncthreads();                                                        // (6)
+            // pos[] becomes the final row; info[] = run start (16 bits) | run length << 16 | my offset << 24
+            u32 info[ITEMS];
+            bool tie = false;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                info[j] = 1u << 16;
+                if (j < rows) {
+                    const u32 p = wbase + j * 64 + lane;
+                    const bool v = p < len;
+                    const u32 dg = (key[j] >> sh) & (NBIN - 1);
+                    const u32 b0 = v ? hist[dg] : 0u, b1 = v ? hist[dg + 1] : 0u, my = key[j], me = pos[j];
+                    u32 lt = 0, eq = 0, eqb = 0;
+                    for (u32 q = b0; q < b1; ++q) { const u32 kk = ex[q]; lt += kk < my; eq += kk == my; eqb += (kk == my) & (q < me); }
+                    if (v) { pos[j] = b0 + lt + eqb; info[j] = (b0 + lt) | (eq << 16) | (eqb << 24); tie |= eq > 1; }
+                }
+            }
+            // keys are dead from here on: prefetch the next segment of this workgroup into their registers
+            if (PREFETCH && more) {
+                d = list[seg];
+                const u64* src = bufs.p[d.buf] + d.rec_off;
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; nrec[j] = p < d.len ? src[p] : ~0ull; }
+                fetched = true;
+            }
+            __syncthreads();                                                        // (7)
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[pos[j]] = idx[j];
+            __syncthreads();                                                        // (8)
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = wbase + j * 64 + lane;
+                    if (p < len) {
+                        sa_out[sa_off + p] = ex[p];
+                        if (mode == MODE_ISA) isa[idx[j]] = rank0 + sa_off + (info[j] & 0xffffu) + 1u;
+                    }
+                }
+            if (t == 0) done[cur] = 1u;
+            if (__syncthreads_or(tie)) {                                            // (9)
+                // compact still-tied runs: run leader (offset 0) reserves room, members follow
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    const u32 rl = (info[j] >> 16) & 255u;
+                    if (j < rows && rl > 1 && (info[j] >> 24) == 0)
+                        ex[info[j] & 0xffffu] = atomicAdd(&misc[rl <= TINY_MAX ? 2 : 3], rl);
+                }
+                __syncthreads();
+                if (t == 0) {
+                    u32 bt = 0, bs = 0, bad = 0;
+                    const u32 tt = misc[2], ts = misc[3];
+                    if (tt) { bt = atomicAdd(&counters[em.pool_cnt_idx], tt); if ((u64)bt + tt > em.pool_cap) { atomicOr(&counters[C_ERR], 32u); bad = 1; } }
+                    if (ts) { bs = atomicAdd(&counters[em.seg_cnt_idx], ts); if ((u64)bs + ts > em.seg_cap) { atomicOr(&counters[C_ERR], 64u); bad = 1; } }
+                    misc[6] = bt; misc[7] = bs; misc[8] = bad;
+                }
+                __syncthreads();
+                if (!misc[8]) {
+                    const u32 base_t = misc[6], base_s = misc[7];
+#pragma unroll
+                    for (int j = 0; j < ITEMS; ++j) {
+                        const u32 rs = info[j] & 0xffffu, rl = (info[j] >> 16) & 255u, ro = info[j] >> 24;
+                        if (j < rows && rl > 1) {
+                            if (rl <= TINY_MAX) {
+                                const u32 o = base_t + ex[rs] + ro;
+                                em.pool_rec[o] = (u64)idx[j];
+                                em.pool_hdr[o] = pack_hdr(sa_off + rs, rl, ro);
+                            } else {
+                                const u32 o = base_s + ex[rs] + ro;
+                                em.seg_rec[o] = (u64)idx[j];
+                                if (ro == 0) { const Desc nd = {o, rl, sa_off + rs, em.seg_buf}; push_desc(em.lists, counters, class_of(rl), nd); }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (!more) break;
+        if (!fetched) {
+            d = list[seg];
+            const u64* src = bufs.p[d.buf] + d.rec_off;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; nrec[j] = p < d.len ? src[p] : ~0ull; }
+        }
+    }
+}
+
+template <int THREADS, int ITEMS, int BITS>
+constexpr size_t sort_fast_lds_bytes()
+{
+    return ((size_t)THREADS * ITEMS + 64 + ((size_t)1 << BITS) + 16 + 16 + 16) * 4;
 }
 
 template <int THREADS, int ITEMS>
