@@ -65,6 +65,7 @@ def main():
     import torch
 
     import msufsort_amd as M
+    from msufsort_amd import dist as mdist
     from msufsort_amd import gen
 
     rank = int(os.environ.get("RANK", "0"))
@@ -74,8 +75,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("MSUFSORT_BENCH_BACKEND", "nccl")     # "nccl" IS RCCL on ROCm
+        if os.environ.get("MSUFSORT_BENCH_ONE_DEVICE"):                # test hook: all ranks share GPU 0
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
     n = args.size
     t = gen.GENERATORS[args.workload](n, args.seed)
@@ -84,21 +91,13 @@ def main():
     d_sa = torch.empty(n + 1, dtype=torch.int32, device=dev)
     ctx = M.DeviceContext(local, n)
 
-    if world > 1:
-        bounds = ctx.shard_bounds(d_text, n, world)
-        views = [d_sa[bounds[g]:bounds[g + 1]] for g in range(world)]
+    bounds = ctx.shard_bounds(d_text, n, world) if world > 1 else None
 
     def step():
         if world == 1:
             ctx.make_sa(d_text, n, d_sa)
         else:
-            lo, hi = bounds[rank], bounds[rank + 1]
-            sl = views[rank] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
-            ctx.make_sa_shard(d_text, n, sl, max(hi - lo, 1), rank, world, text_rounds=64)
-            # all-gatherv of the slices: one broadcast per root, grouped (RCCL has no v-variant)
-            works = [dist.broadcast(views[g], src=g, async_op=True) for g in range(world) if bounds[g + 1] > bounds[g]]
-            for w in works:
-                w.wait()
+            mdist.build_sa_sharded(ctx, d_text, n, d_sa, rank, world, dist, bounds)
 
     def barrier():
         if dist is not None:

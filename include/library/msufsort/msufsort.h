@@ -1,0 +1,93 @@
+// Drop-in replacement for the public surface of michaelmaniscalco/msufsort, backed by the
+// MI355X engine through the C-ABI in include/msufsort_hip.h (link with -lmsufsort_hip).
+//
+// Mirrors, name for name and argument for argument:
+//   class maniscalco::msufsort                         reference src/library/msufsort/msufsort.h:42-75
+//   maniscalco::make_suffix_array<It>                  reference msufsort.h:403-445
+//   maniscalco::forward_burrows_wheeler_transform<It>  reference msufsort.h:449-462
+//   maniscalco::reverse_burrows_wheeler_transform<It>  reference msufsort.h:466-476
+// Conventions are the reference's: SA has n+1 entries with SA[0] = n; the BWT is written in place
+// and the sentinel row is returned; the inverse transforms in place.
+// Differences, all deliberate: `threads` is accepted and ignored (the work runs on the GPU);
+// n = 0 is defined (SA = {0}, BWT no-op, sentinel 0) where the reference is UB (cpp:1588);
+// n may be up to 2^31-2 (the reference corrupts its output at n >= 2^30);
+// a failure of the HIP path (no device, out of memory) throws std::runtime_error - there is
+// no CPU fallback behind this header.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../msufsort_hip.h"
+
+namespace maniscalco
+{
+
+    class msufsort
+    {
+    public:
+
+        static auto constexpr max_radix_size = (1 << 16);
+        using suffix_index = std::int32_t;
+        using suffix_array = std::vector<suffix_index>;
+
+        msufsort(std::int32_t numThreads = 1) : numThreads_(numThreads) {}
+        ~msufsort() = default;
+
+        suffix_array make_suffix_array(std::uint8_t const * inputBegin, std::uint8_t const * inputEnd)
+        {
+            auto n = static_cast<std::int64_t>(inputEnd - inputBegin);
+            suffix_array sa(static_cast<std::size_t>(n) + 1);
+            check(::msufsort_hip_make_sa_i32(inputBegin, n, sa.data(), nullptr), "make_suffix_array");
+            return sa;
+        }
+
+        std::int32_t forward_burrows_wheeler_transform(std::uint8_t * inputBegin, std::uint8_t * inputEnd)
+        {
+            std::int64_t sentinel = 0;
+            check(::msufsort_hip_forward_bwt(inputBegin, static_cast<std::int64_t>(inputEnd - inputBegin), &sentinel, nullptr),
+                  "forward_burrows_wheeler_transform");
+            return static_cast<std::int32_t>(sentinel);
+        }
+
+        static void reverse_burrows_wheeler_transform(std::uint8_t * inputBegin, std::uint8_t * inputEnd,
+                                                      std::int32_t sentinelIndex, std::int32_t /*numThreads*/)
+        {
+            check(::msufsort_hip_inverse_bwt(inputBegin, static_cast<std::int64_t>(inputEnd - inputBegin), sentinelIndex, nullptr),
+                  "reverse_burrows_wheeler_transform");
+        }
+
+    private:
+
+        static void check(int status, char const * what)
+        {
+            if (status != MSUFSORT_HIP_OK)
+                throw std::runtime_error(std::string("maniscalco::msufsort::") + what + ": " +
+                                         ::msufsort_hip_strerror(status) + " - " + ::msufsort_hip_last_error());
+        }
+
+        std::int32_t numThreads_;
+    };
+
+
+    template <typename input_iter>
+    msufsort::suffix_array make_suffix_array(input_iter begin, input_iter end, std::int32_t numThreads = 1)
+    {
+        return msufsort(numThreads).make_suffix_array((std::uint8_t const *)&*begin, (std::uint8_t const *)&*begin + (end - begin));
+    }
+
+    template <typename input_iter>
+    std::int32_t forward_burrows_wheeler_transform(input_iter begin, input_iter end, std::int32_t numThreads = 1)
+    {
+        return msufsort(numThreads).forward_burrows_wheeler_transform((std::uint8_t *)&*begin, (std::uint8_t *)&*begin + (end - begin));
+    }
+
+    template <typename input_iter>
+    void reverse_burrows_wheeler_transform(input_iter begin, input_iter end, std::int32_t sentinelIndex, std::int32_t numThreads = 1)
+    {
+        msufsort::reverse_burrows_wheeler_transform((std::uint8_t *)&*begin, (std::uint8_t *)&*begin + (end - begin), sentinelIndex, numThreads);
+    }
+
+} // namespace maniscalco

@@ -101,6 +101,11 @@ int msufsort_hip_make_sa_shard_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64
 int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
                                   int32_t n_shards, int64_t* bounds);
 
+/* Host-only helper used by the two calls above (no device work): balanced key-range cuts from the
+ * exclusive prefix bstart[65537] of the 16-bit histogram; cuts/rows have n_shards+1 entries. */
+int msufsort_hip_plan_cuts(const uint32_t* bstart, int64_t n, int64_t z, int32_t n_shards,
+                           uint32_t* cuts, int64_t* rows);
+
 /* ---- forward BWT: replaces msufsort::forward_burrows_wheeler_transform (cpp:1771-1817) ---- */
 int msufsort_hip_forward_bwt(uint8_t* inout, int64_t n, int64_t* sentinel_row,
                              const msufsort_hip_opts* opts);

@@ -16,6 +16,8 @@
 #include <string>
 #include <vector>
 
+extern "C" int msufsort_hip_plan_cuts(const uint32_t* bstart, int64_t n, int64_t z, int32_t n_shards, uint32_t* cuts, int64_t* rows);
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -235,13 +237,9 @@ int plan_shards(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64 z, u64 m, int 
     run_scan(c, 0, 65536, z);
     HIP_TRY(hipMemcpyAsync(c->h_bstart, c->bstart.p, 65537 * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int g = 1; g < n_shards; ++g) {
-        u64 target = m * (u64)g / (u64)n_shards;
-        u32 k = (u32)(std::lower_bound(c->h_bstart, c->h_bstart + 65536, (u32)target) - c->h_bstart);
-        if (k < cuts[g - 1]) k = cuts[g - 1];
-        cuts[g] = k;
-        rows[g] = 1 + z + c->h_bstart[k];
-    }
+    std::vector<int64_t> r64(n_shards + 1);
+    msufsort_hip_plan_cuts(c->h_bstart, (int64_t)n, (int64_t)z, n_shards, cuts.data(), r64.data());
+    for (int g = 0; g <= n_shards; ++g) rows[g] = (u64)r64[g];
     return MSUFSORT_HIP_OK;
 }
 
@@ -615,6 +613,26 @@ int msufsort_hip_make_sa_i32(const uint8_t* text, int64_t n, int32_t* sa_out, co
     TRY(msufsort_hip_make_sa_i32_dev(c, c->text_own.as<u8>(), n, c->sa_own.as<int32_t>(), opts));
     HIP_TRY(hipMemcpyAsync(sa_out, c->sa_own.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return MSUFSORT_HIP_OK;
+}
+
+// Host-only: split the 16-bit key space into n_shards count-balanced contiguous ranges.
+// bstart[65537] = exclusive prefix of the 16-bit histogram over the m = n - z radix-sorted suffixes.
+// cuts[n_shards+1] = first key of every shard; rows[n_shards+1] = first SA row of every shard
+// (row 0 = the empty suffix; rows 1..z = the trailing-zero-run suffixes, both owned by shard 0).
+int msufsort_hip_plan_cuts(const uint32_t* bstart, int64_t n, int64_t z, int32_t n_shards, uint32_t* cuts, int64_t* rows)
+{
+    if (!bstart || !cuts || !rows || n_shards < 1 || n < 0 || z < 0 || z > n) return MSUFSORT_HIP_ERR_BAD_ARG;
+    const u64 m = (u64)(n - z);
+    cuts[0] = 0; rows[0] = 0;
+    cuts[n_shards] = 65536; rows[n_shards] = n + 1;
+    for (int g = 1; g < n_shards; ++g) {
+        const u64 target = m * (u64)g / (u64)n_shards;
+        u32 k = (u32)(std::lower_bound(bstart, bstart + 65536, (u32)target) - bstart);
+        if (k < cuts[g - 1]) k = cuts[g - 1];
+        cuts[g] = k;
+        rows[g] = (int64_t)(1 + (u64)z + bstart[k]);
+    }
     return MSUFSORT_HIP_OK;
 }
 

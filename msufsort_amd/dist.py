@@ -1,0 +1,53 @@
+"""Multi-GPU path: one process per GPU, the 16-bit key space is split into
+`world` count-balanced contiguous ranges, every rank radix-sorts its range into its own slice of the
+full suffix array and the slices are exchanged with ONE all-gatherv.  RCCL has no v-variant, so the
+gather is a group of per-root broadcasts issued together (each peer sends its slice directly, using all
+xGMI links at once) - torch.distributed is plumbing here, the sort is the HIP path.
+
+The reference has no distributed code at all; this is the MI355X-native extension
+of its bucket-parallel first stage (reference msufsort.cpp:1652-1683 hands partitions to threads).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def plan_cuts(bstart, n: int, z: int, n_shards: int):
+    """Host-only: (cuts, rows) for `n_shards` shards from the exclusive 16-bit-key prefix bstart[65537]."""
+    b = np.ascontiguousarray(bstart, dtype=np.uint32)
+    assert b.size == 65537
+    cuts = np.zeros(n_shards + 1, dtype=np.uint32)
+    rows = np.zeros(n_shards + 1, dtype=np.int64)
+    _lib.check(_lib.lib().msufsort_hip_plan_cuts(b.ctypes.data, n, z, n_shards, cuts.ctypes.data, rows.ctypes.data), "plan_cuts")
+    return cuts.tolist(), rows.tolist()
+
+
+def allgatherv_slices(full, bounds, dist, group=None):
+    """All-gatherv of SA slices IN PLACE: rank g has filled full[bounds[g]:bounds[g+1]]; afterwards every
+    rank holds the whole array.  One broadcast per non-empty root, issued asynchronously as a group."""
+    world = len(bounds) - 1
+    works = []
+    for g in range(world):
+        lo, hi = bounds[g], bounds[g + 1]
+        if hi > lo:
+            works.append(dist.broadcast(full[lo:hi], src=g, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    return full
+
+
+def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist, bounds=None, text_rounds: int = 64):
+    """One step of the sharded build on this rank: sort my key range into my slice, then all-gatherv."""
+    import torch
+    if bounds is None:
+        bounds = ctx.shard_bounds(d_text, n, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    sl = d_sa_full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device=d_sa_full.device)
+    ctx.make_sa_shard(d_text, n, sl, max(hi - lo, 1), rank, world, text_rounds=text_rounds)
+    if world > 1:
+        allgatherv_slices(d_sa_full, bounds, dist)
+    return bounds

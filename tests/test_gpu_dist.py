@@ -1,0 +1,34 @@
+"""GPU box (1 GPU): the full N>1 flow of bench.py - shard planning, per-rank sharded HIP sort, all-gatherv,
+on-device validation - with 2 ranks sharing cuda:0 over gloo (RCCL refuses two ranks on one device; the
+driver exercises RCCL itself on the 8-GPU node)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_one_gpu():
+    env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--size", str(1 << 24), "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["valid"] is True and d["value"] > 0 and d["scaling"] == "strong"
+
+
+def test_cpp_dropin_header_builds_and_runs(tmp_path):
+    exe = str(tmp_path / "demo")
+    subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "demo.cpp"),
+                    "-L" + os.path.join(ROOT, "msufsort_amd", "lib"), "-lmsufsort_hip",
+                    "-Wl,-rpath," + os.path.join(ROOT, "msufsort_amd", "lib"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SA[0] = 11, SA[1] = 10" in r.stdout and "sentinel row = 5, round trip ok" in r.stdout
