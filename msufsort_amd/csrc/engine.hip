@@ -73,10 +73,11 @@ struct msufsort_hip_ctx {
     // workspace
     DevBuf rec[3], pool_rec[2], pool_hdr[2];
     DevBuf lists[2][3], large_round[2], lvl[2], seg0;
-    DevBuf hist_partial, hist, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
+    DevBuf seg0_base, hist_partial, hist, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
     DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, doneB, doneC;
     u32* h_counters = nullptr;   // pinned
     u32* h_bstart = nullptr;     // pinned, 65537
+    u32 nchunks = 1, chunk_len = 16384;      // text striping of the last k_hist16
     u32 list_cap[3] = {0, 0, 0};
     u32 large_cap = 0;
     u64 cap_m = 0;               // records capacity
@@ -123,7 +124,8 @@ struct msufsort_hip_ctx {
         TRY(child_cnt.ensure(65536 * 4));
         TRY(cursor.ensure(nchild * 4));
         TRY(seg_hist.ensure(nchild * 4));
-        TRY(cursor0.ensure(256 * 4));
+        TRY(cursor0.ensure(128 * 256 * 4));
+        TRY(seg0_base.ensure(256 * 4));
         TRY(tile_start.ensure(((size_t)std::max<u32>(large_cap, 256) + 1) * 4));
         TRY(trivial.ensure((size_t)std::max<u32>(large_cap, 256) * 4));
         TRY(hist_partial.ensure((size_t)128 * 65536 * 4));
@@ -142,7 +144,7 @@ struct msufsort_hip_ctx {
         for (auto& b : pool_rec) b.release();
         for (auto& b : pool_hdr) b.release();
         for (int s = 0; s < 2; ++s) { for (int c = 0; c < 3; ++c) lists[s][c].release(); large_round[s].release(); lvl[s].release(); }
-        seg0.release(); hist_partial.release(); hist.release(); bstart.release(); child_start.release(); child_cnt.release();
+        seg0.release(); seg0_base.release(); hist_partial.release(); hist.release(); bstart.release(); child_start.release(); child_cnt.release();
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release();
         cap_m = 0;
@@ -174,6 +176,12 @@ __global__ void k_last_nonzero(const u8* __restrict__ text, u64 n, unsigned long
     if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
 }
 
+__global__ void k_dbg_scan_sa(const u32* sa_local, u32 ms, u32 n, u32* out)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < ms; i += (u64)gridDim.x * blockDim.x)
+        if (sa_local[i] >= n) { u32 k = atomicAdd(&out[0], 1u); if (k < 8) { out[1 + 2 * k] = (u32)i; out[2 + 2 * k] = sa_local[i]; } }
+}
+
 inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
 struct Bench {   // event timing of phases
@@ -202,6 +210,18 @@ int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out)
     return MSUFSORT_HIP_OK;
 }
 
+// MSUFSORT_HIP_SYNC_DEBUG=1: synchronise and check after every phase so a faulting kernel is named
+#define DBG(label)                                                                                   \
+    do {                                                                                             \
+        if (g_sync_debug) {                                                                          \
+            hipError_t e_ = hipStreamSynchronize(c->stream);                                         \
+            if (e_ == hipSuccess) e_ = hipGetLastError();                                            \
+            if (e_ != hipSuccess) { set_error("after %s: %s", label, hipGetErrorString(e_)); return MSUFSORT_HIP_ERR_HIP; } \
+            if (g_sync_debug > 1) fprintf(stderr, "[dbg] %s ok\n", label);                           \
+        }                                                                                            \
+    } while (0)
+int g_sync_debug = 0;
+
 struct ShardPlan {
     u32 klo = 0, khi = 65536;
     u64 row_lo = 0, row_hi = 0;     // rows of the full SA (n+1 rows) owned by this shard
@@ -213,7 +233,8 @@ int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
     u32 nchunks = (u32)std::min<u64>(128, std::max<u64>(1, (m + 65535) / 65536));
     u64 chunk_len = (m + nchunks - 1) / nchunks;
     chunk_len = (chunk_len + 16383) / 16384 * 16384;
-    hipLaunchKernelGGL(k_hist16, dim3(2 * nchunks), dim3(1024), 131072, c->stream, d_text, (u32)m, (u32)chunk_len, c->hist_partial.as<u32>());
+    c->nchunks = nchunks; c->chunk_len = (u32)chunk_len;
+    hipLaunchKernelGGL(k_hist16, dim3(16 * cdiv(nchunks, 8)), dim3(1024), 131072, c->stream, d_text, (u32)m, (u32)chunk_len, nchunks, c->hist_partial.as<u32>());
     hipLaunchKernelGGL(k_reduce16, dim3(64), dim3(1024), 0, c->stream, c->hist_partial.as<u32>(), nchunks, c->hist.as<u32>());
     HIP_TRY(hipGetLastError());
     return MSUFSORT_HIP_OK;
@@ -222,8 +243,10 @@ int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
 void run_scan(msufsort_hip_ctx* c, u32 klo, u32 khi, u64 z)
 {
     hipLaunchKernelGGL(k_scan16, dim3(1), dim3(1024), 0, c->stream, c->hist.as<u32>(), c->bstart.as<u32>(), klo, khi,
-                       c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->cursor0.as<u32>(),
+                       c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->seg0_base.as<u32>(),
                        c->seg0.as<Desc>(), c->tile_start.as<u32>(), c->counters.as<u32>(), (u32)z);
+    hipLaunchKernelGGL(k_stripes, dim3(256), dim3(128), 0, c->stream, c->hist_partial.as<u32>(), c->nchunks, klo, khi,
+                       c->seg0_base.as<u32>(), c->cursor0.as<u32>());
 }
 
 int plan_shards(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64 z, u64 m, int n_shards, std::vector<u32>& cuts, std::vector<u64>& rows)
@@ -251,6 +274,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
              u64 z, u32 klo, u32 khi, bool with_head, const msufsort_hip_opts* opts, bool hist_done)
 {
     const int verbose = opts ? opts->verbose : 0;
+    if (const char* e = getenv("MSUFSORT_HIP_SYNC_DEBUG")) g_sync_debug = atoi(e);
     const bool sharded = opts && opts->n_shards > 1;
     int text_rounds = (opts && opts->text_rounds > 0) ? opts->text_rounds : 4;
     if (const char* e = getenv("MSUFSORT_HIP_TEXT_ROUNDS")) text_rounds = std::max(1, atoi(e));
@@ -277,11 +301,13 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
     if (klo == 0) rank0 = z;
     else { HIP_TRY(hipMemcpyAsync(c->h_bstart, c->bstart.p, 65537 * 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); rank0 = z + c->h_bstart[klo]; }
     u32* sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
-    hipLaunchKernelGGL(k_scatter0, dim3(cdiv(m, P1_TILE)), dim3(P1_THREADS), 0, st, d_text, (u32)m, klo, khi, c->cursor0.as<u32>(), bufs.p[0]);
+    hipLaunchKernelGGL(k_scatter0, dim3(cdiv(cdiv(m, P1_TILE), 8 * (c->chunk_len / P1_TILE)) * 8 * (c->chunk_len / P1_TILE)), dim3(S0_THREADS), 0, st, d_text, (u32)m, klo, khi, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0]);
     HIP_TRY(hipEventRecord(c->ev[2], st));
-    hipLaunchKernelGGL(k_partition, dim3(cdiv(m, P1_TILE) + 256), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
+    DBG("k_scatter0");
+    hipLaunchKernelGGL(k_partition, dim3(cdiv(cdiv(m, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
                        c->tile_start.as<u32>(), 24u, c->cursor.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u);
     HIP_TRY(hipEventRecord(c->ev[3], st));
+    DBG("k_partition L1");
 
     int cur = 0;                 // slot of the current round's lists / pool
     u32 sb = 1, nb = 2;          // record buffer holding the current segments / receiving next round's
@@ -303,6 +329,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                            c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), (u32)std::min<u64>(c->cap_m, 0xffffffffu),
                            make_lists(cur), c->lvl[0].as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters);
     }
+    DBG("k_children L1");
     TRY(c->read_counters());
 
     int round = 0;
@@ -325,14 +352,18 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, src_list, nl, c->tile_start.as<u32>());
                 HIP_TRY(hipMemsetAsync(c->seg_hist.p, 0, (size_t)nl * 256 * 4, st));
                 HIP_TRY(hipMemsetAsync(c->trivial.p, 0, (size_t)nl * 4, st));
-                hipLaunchKernelGGL(k_count, dim3(ntiles), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.as<u32>(), shift, c->seg_hist.as<u32>());
+                hipLaunchKernelGGL(k_count, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.as<u32>(), shift, c->seg_hist.as<u32>());
+                DBG("k_count");
                 hipLaunchKernelGGL(k_segscan, dim3(nl), dim3(256), 0, st, src_list, nl, c->seg_hist.as<u32>(), c->child_start.as<u32>(), c->cursor.as<u32>(), c->trivial.as<u32>());
-                hipLaunchKernelGGL(k_partition, dim3(ntiles), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.as<u32>(), shift,
+                DBG("k_segscan");
+                hipLaunchKernelGGL(k_partition, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.as<u32>(), shift,
                                    c->cursor.as<u32>(), c->trivial.as<u32>(), a[0], a[1], a[2]);
+                DBG("k_partition level");
                 hipLaunchKernelGGL(k_children, dim3(nl), dim3(256), 0, st, bufs, src_list, nl, c->child_start.as<u32>(), c->seg_hist.as<u32>(),
                                    c->trivial.as<u32>(), a[0], a[1], a[2], sa_local, c->isa.as<u32>(), mode,
                                    c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), cap32,
                                    make_lists(cur), c->lvl[lp].as<Desc>(), c->large_cap, cnt_idx, til_idx, counters);
+                DBG("k_children level");
                 TRY(c->read_counters());
                 src_list = c->lvl[lp].as<Desc>();
                 nl = c->h_counters[cnt_idx];
@@ -343,6 +374,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                         hipLaunchKernelGGL(k_carry, dim3(nl), dim3(256), 0, st, bufs, src_list, nl, sa_local, c->isa.as<u32>(), mode,
                                            bufs.p[nb], nb, (u32)(nxt ? C_SEG1 : C_SEG0), cap32,
                                            c->large_round[nxt].as<Desc>(), c->large_cap, (u32)((nxt ? C_LIST1 : C_LIST0) + 3), (u32)(nxt ? C_LTILES1 : C_LTILES0), counters);
+                        DBG("k_carry");
                     }
                     break;
                 }
@@ -366,10 +398,12 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 HIP_TRY(hipMemsetAsync(c->doneC.p, 0, (size_t)nC * 4, st));
                 k_sort_fast<CLS_C_THREADS, CLS_C_ITEMS, 14, false><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_fast_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS, 14>(), st>>>(
                     bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneC.as<u32>());
+                DBG("k_sort_fast C");
                 skip = c->doneC.as<u32>();
             }
-            k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(nC), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
+            k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(std::min<u32>(nC, 1024u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
                 bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, skip);
+            DBG("k_sort_mid C");
         }
         if (nB) {
             const u32* skip = nullptr;
@@ -377,16 +411,20 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 HIP_TRY(hipMemsetAsync(c->doneB.p, 0, (size_t)nB * 4, st));
                 k_sort_fast<CLS_B_THREADS, CLS_B_ITEMS, 12, true><<<dim3(std::min<u32>(nB, 256u * 4u)), dim3(CLS_B_THREADS), sort_fast_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12>(), st>>>(
                     bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneB.as<u32>());
+                DBG("k_sort_fast B");
                 skip = c->doneB.as<u32>();
             }
-            k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(nB), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
+            k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(std::min<u32>(nB, 4096u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
                 bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, skip);
+            DBG("k_sort_mid B");
         }
-        if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS><<<dim3(nA), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
+        if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS><<<dim3(std::min<u32>(nA, 1u << 16)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
                     bufs, c->lists[cur][0].as<Desc>(), nA, sa_local, c->isa.as<u32>(), mode, em, counters, (const u32*)nullptr);
+        DBG("k_sort_mid A");
         if (nP) hipLaunchKernelGGL(k_sort_tiny, dim3(cdiv(nP, 256)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(),
                                    (u32)(cur ? C_POOL1 : C_POOL0), sa_local, c->isa.as<u32>(), mode,
                                    em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32, counters);
+        DBG("k_sort_tiny");
         if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
         TRY(c->read_counters());
         const u32 nb_base = nxt ? C_LIST1 : C_LIST0;
@@ -410,13 +448,27 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
             if (sharded) { set_error("ties deeper than %llu bytes in a sharded build (prefix doubling needs the full rank array)", (unsigned long long)depth); return MSUFSORT_HIP_ERR_UNSUPPORTED; }
             // switch to prefix doubling: build the inverse suffix array
             TRY(c->isa.ensure((size_t)(n + 1) * 4));
+            if (g_sync_debug) {
+                TRY(c->aux0.ensure(256));
+                HIP_TRY(hipMemsetAsync(c->aux0.p, 0, 256, st));
+                hipLaunchKernelGGL(k_dbg_scan_sa, dim3(4096), dim3(256), 0, st, sa_local, (u32)c->h_counters[C_MS], (u32)n, c->aux0.as<u32>());
+                u32 h[32];
+                HIP_TRY(hipMemcpyAsync(h, c->aux0.p, 128, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                fprintf(stderr, "[dbg] bad SA rows before isa build: %u", h[0]);
+                for (u32 k = 0; k < std::min<u32>(h[0], 8); ++k) fprintf(stderr, " (row %u val %u)", h[1 + 2 * k], h[2 + 2 * k]);
+                fprintf(stderr, "\n");
+            }
             hipLaunchKernelGGL(k_isa_init, dim3(std::min<u32>(cdiv(m + z, 256), 65536u)), dim3(256), 0, st, sa_local, counters, c->isa.as<u32>(), (u32)n, (u32)z);
+            DBG("k_isa_init");
             if (actP) hipLaunchKernelGGL(k_isa_pool, dim3(std::min<u32>(cdiv(actP, 256), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), counters, curP, c->isa.as<u32>());
+            DBG("k_isa_pool");
             for (int k = 0; k < 3; ++k) {
                 const u32 cnt = c->h_counters[curL + k];
                 if (cnt) hipLaunchKernelGGL(k_isa_segs, dim3(cnt), dim3(256), 0, st, bufs, c->lists[cur][k].as<Desc>(), cnt, counters, c->isa.as<u32>());
             }
             if (u32 cnt = c->h_counters[curL + 3]) hipLaunchKernelGGL(k_isa_segs, dim3(cnt), dim3(256), 0, st, bufs, c->large_round[cur].as<Desc>(), cnt, counters, c->isa.as<u32>());
+            DBG("isa build");
             mode = MODE_ISA;
         }
         // refill keys of all still-tied suffixes
@@ -424,6 +476,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                                      d_text, c->isa.as<u32>(), (u32)n, depth, mode);
         if (actS) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actS, 256), 65536u)), dim3(256), 0, st, bufs.p[sb], counters, curS,
                                      d_text, c->isa.as<u32>(), (u32)n, depth, mode);
+        DBG("k_refill");
         if (mode == MODE_TEXT) depth += 4; else { depth *= 2; tm.doubling_rounds++; }
         tm.rounds++;
     }

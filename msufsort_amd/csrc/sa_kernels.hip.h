@@ -64,9 +64,17 @@ enum {
 #define CAP_B (CLS_B_THREADS * CLS_B_ITEMS)
 #define CAP_C (CLS_C_THREADS * CLS_C_ITEMS)
 
-#define P1_THREADS 512
-#define P1_ITEMS 16
+#ifndef P1_THREADS
+#define P1_THREADS 1024
+#endif
+#ifndef P1_ITEMS
+#define P1_ITEMS 8
+#endif
 #define P1_TILE (P1_THREADS * P1_ITEMS)      // 8192 records per tile
+#define CUR0_STRIDE 64                       // u32 stride of the 256 first-byte cursors: one 256-B line each,
+                                             // so the per-tile claim atomics spread over memory channels
+#define S0_POS 8                             // level-0 scatter: text positions per thread
+#define S0_THREADS (P1_TILE / S0_POS)
 
 #define MODE_TEXT 0
 #define MODE_ISA 1
@@ -89,6 +97,15 @@ struct Emit {             // where still-tied runs go (next round)
 };
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+
+// XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
+// XCD and its L2); groups of T consecutive tiles feed the same output cursors, so give a whole group to one
+// XCD: the adjacent runs its tiles claim then meet in ONE L2 and leave it as full lines.  Speed only.
+__device__ __forceinline__ u32 xcd_tile(u32 b, u32 T)
+{
+    const u32 x = b & 7u, q = b >> 3;
+    return ((q / T) * 8u + x) * T + (q % T);
+}
 
 __device__ __forceinline__ u32 wave_excl_scan(u32 v, u32& total)
 {
@@ -138,11 +155,14 @@ __device__ __forceinline__ void push_desc(const Lists& L, u32* counters, u32 cls
 // 128 KiB) over its chunk of the text; two workgroups share a chunk.  16 B per lane coalesced loads.
 // partial[chunk][65536] is reduced by k_reduce16.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u32 m, u32 chunk_len,
+__global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u32 m, u32 chunk_len, u32 nchunks,
                                                  u32* __restrict__ partial)
 {
     extern __shared__ u32 h_lds[];
-    const u32 chunk = blockIdx.x >> 1, half = blockIdx.x & 1u;
+    // blocks b and b+8 land on the same XCD (round-robin dealing): give them the two halves of ONE chunk so
+    // the second reader of every line is served by that XCD's L2 instead of HBM (speed only)
+    const u32 chunk = (blockIdx.x >> 4) * 8u + (blockIdx.x & 7u), half = (blockIdx.x >> 3) & 1u;
+    if (chunk >= nchunks) return;
     for (u32 i = threadIdx.x; i < 32768u; i += 1024u) h_lds[i] = 0;
     __syncthreads();
     const u64 cbeg = (u64)chunk * chunk_len;
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(1024) void k_reduce16(const u32* __restrict__ parti
 __global__ __launch_bounds__(1024) void k_scan16(const u32* __restrict__ hist, u32* __restrict__ bstart /*65537*/,
                                                  u32 klo, u32 khi,
                                                  u32* __restrict__ child_start, u32* __restrict__ child_cnt,
-                                                 u32* __restrict__ cursor1, u32* __restrict__ cursor0,
+                                                 u32* __restrict__ cursor1, u32* __restrict__ seg0_base,
                                                  Desc* __restrict__ seg0, u32* __restrict__ tile_start0 /*257*/,
                                                  u32* __restrict__ counters, u32 z)
 {
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(1024) void k_scan16(const u32* __restrict__ hist, u
         Desc d = {0, 0, 0, 0};
         if (lo < hi) { d.rec_off = bstart[lo] - base; d.len = bstart[hi] - bstart[lo]; d.sa_off = d.rec_off; }
         seg0[t] = d;
-        cursor0[t] = d.rec_off;
+        seg0_base[t] = d.rec_off;
         s_in[t] = (d.len + P1_TILE - 1) / P1_TILE;
     }
     __syncthreads();
@@ -237,27 +257,55 @@ __global__ __launch_bounds__(1024) void k_scan16(const u32* __restrict__ hist, u
 // Per tile: LDS histogram with returning LDS atomics gives the rank inside the tile, one global atomic
 // per (tile, bin) claims the output range, records are staged bin-sorted in LDS and written as runs.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(P1_THREADS) void k_scatter0(const u8* __restrict__ text, u32 m, u32 klo, u32 khi,
+// Level-0 cursors per text stripe: cursor0[chunk][b] = start of first-byte bucket b + number of in-range
+// suffixes with first byte b in earlier chunks (from the per-chunk histograms k_hist16 left behind).  With one
+// cursor set per stripe the 256 output streams become 256 x nchunks, which spreads the scatter's writes
+// (and its claim atomics) over all HBM channels.
+__global__ __launch_bounds__(128) void k_stripes(const u32* __restrict__ partial, u32 nchunks, u32 klo, u32 khi,
+                                                 const u32* __restrict__ seg0_base, u32* __restrict__ cursor0)
+{
+    __shared__ u32 wtot[2];
+    const u32 b = blockIdx.x, c = threadIdx.x;
+    u32 lo = b << 8, hi = (b + 1) << 8;
+    if (lo < klo) lo = klo;
+    if (hi > khi) hi = khi;
+    u32 sum = 0;
+    if (c < nchunks && lo < hi) {
+        const u32* p = partial + (u64)c * 65536u;
+        for (u32 k = lo; k < hi; ++k) sum += p[k];
+    }
+    u32 wt;
+    u32 e = wave_excl_scan(sum, wt);
+    if (lane_id() == 63) wtot[c >> 6] = wt;
+    __syncthreads();
+    if (c >= 64) e += wtot[0];
+    if (c < nchunks) cursor0[c * 256u + b] = seg0_base[b] + e;
+}
+
+__global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ text, u32 m, u32 klo, u32 khi, u32 chunk_len,
                                                          u32* __restrict__ cursor0, u64* __restrict__ out)
 {
     __shared__ u64 stage[P1_TILE];
     __shared__ u8 sbin[P1_TILE];
     __shared__ u32 hist[256], lstart[256], gbase[256];
+    __shared__ u32 s_total;
     const u32 t = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * P1_TILE + (u64)t * 16u;
+    const u64 base0 = (u64)xcd_tile(blockIdx.x, chunk_len / P1_TILE) * P1_TILE;
+    if (base0 >= m) return;
+    const u64 base = base0 + (u64)t * S0_POS;
     if (t < 256) hist[t] = 0;
     __syncthreads();
-    u32 w[6] = {0, 0, 0, 0, 0, 0};
+    u32 w[S0_POS / 4 + 2];
+#pragma unroll
+    for (int k = 0; k < S0_POS / 4 + 2; ++k) w[k] = 0;
     if (base < m) {
-        const uint4 v = *reinterpret_cast<const uint4*>(text + base);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        w[4] = *reinterpret_cast<const u32*>(text + base + 16);
-        w[5] = 0;
+#pragma unroll
+        for (int k = 0; k < S0_POS / 4 + 1; ++k) w[k] = *reinterpret_cast<const u32*>(text + base + 4 * k);
     }
-    u32 rank[16];
+    u32 rank[S0_POS];
     u32 validmask = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < S0_POS; ++j) {
         const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
         const u32 b1 = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u;
         const u32 k16 = (b0 << 8) | b1;
@@ -268,13 +316,12 @@ __global__ __launch_bounds__(P1_THREADS) void k_scatter0(const u8* __restrict__ 
     __syncthreads();
     // claim the output ranges now, consume the answer after staging (hides the atomic's latency)
     u32 claim = 0;
-    if (t < 256) { const u32 c = hist[t]; if (c) claim = atomicAdd(&cursor0[t], c); }
+    if (t < 256) { const u32 c = hist[t]; if (c) claim = atomicAdd(&cursor0[(u32)(base0 / chunk_len) * 256u + t], c); }
     const u32 total = scan256_first_wave(hist, lstart);
-    __shared__ u32 s_total;
     if (t == 0) s_total = total;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < S0_POS; ++j) {
         if (validmask & (1u << j)) {
             const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
             u32 key = 0;
@@ -289,10 +336,14 @@ __global__ __launch_bounds__(P1_THREADS) void k_scatter0(const u8* __restrict__ 
     if (t < 256) gbase[t] = claim;
     __syncthreads();
     const u32 tot = s_total;
-    for (u32 s = t; s < tot; s += P1_THREADS) {
+#ifdef EXP_NO_CLAIM   // timing experiment only: tile-contiguous output, wrong result
+    for (u32 s = t; s < tot; s += S0_THREADS) out[base0 + s] = stage[s];
+#else
+    for (u32 s = t; s < tot; s += S0_THREADS) {
         const u32 b = sbin[s];
         out[gbase[b] + (s - lstart[b])] = stage[s];
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -317,13 +368,14 @@ __global__ __launch_bounds__(P1_THREADS) void k_count(RecBufs bufs, const Desc* 
     __shared__ u32 hist[256];
     __shared__ u32 s_seg;
     const u32 t = threadIdx.x;
-    if (blockIdx.x >= tile_start[nseg]) return;
-    if (t == 0) s_seg = find_seg(tile_start, nseg, blockIdx.x);
+    const u32 tile = xcd_tile(blockIdx.x, 512u);
+    if (tile >= tile_start[nseg]) return;
+    if (t == 0) s_seg = find_seg(tile_start, nseg, tile);
     if (t < 256) hist[t] = 0;
     __syncthreads();
     const u32 s = s_seg;
     const Desc d = list[s];
-    const u32 off = (blockIdx.x - tile_start[s]) * P1_TILE;
+    const u32 off = (tile - tile_start[s]) * P1_TILE;
     const u64* src = bufs.p[d.buf] + d.rec_off;
 #pragma unroll 4
     for (int j = 0; j < P1_ITEMS; ++j) {
@@ -365,14 +417,15 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
     __shared__ u32 hist[256], lstart[256], gbase[256];
     __shared__ u32 s_seg, s_total;
     const u32 t = threadIdx.x;
-    if (blockIdx.x >= tile_start[nseg]) return;
-    if (t == 0) s_seg = find_seg(tile_start, nseg, blockIdx.x);
+    const u32 tile = xcd_tile(blockIdx.x, 512u);
+    if (tile >= tile_start[nseg]) return;
+    if (t == 0) s_seg = find_seg(tile_start, nseg, tile);
     if (t < 256) hist[t] = 0;
     __syncthreads();
     const u32 s = s_seg;
     if (trivial && trivial[s]) return;
     const Desc d = list[s];
-    const u32 off = (blockIdx.x - tile_start[s]) * P1_TILE;
+    const u32 off = (tile - tile_start[s]) * P1_TILE;
     const u64* src = bufs.p[d.buf] + d.rec_off;
     const u32 alt = d.buf == 0 ? alt0 : (d.buf == 1 ? alt1 : alt2);
     u64* dst = bufs.p[alt];
@@ -562,9 +615,9 @@ __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32
 // runs are compacted into next round's tiny pool / segment array.
 // ------------------------------------------------------------------------------------------------
 template <int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
-                                                      u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
-                                                      Emit em, u32* __restrict__ counters, const u32* __restrict__ skip)
+__device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc d,
+                                                 u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                 const Emit& em, u32* __restrict__ counters)
 {
     constexpr int CAP = THREADS * ITEMS;
     constexpr int W = THREADS / 64;
@@ -585,9 +638,6 @@ __global__ __launch_bounds__(THREADS) void k_sort_mid(RecBufs bufs, const Desc* 
     u32* pre_seg = pre_tiny + NW;                               // NW
     u32* misc = pre_seg + NW;                                   // 8
 
-    if (blockIdx.x >= nseg) return;
-    if (skip && skip[blockIdx.x]) return;           // already sorted by k_sort_fast
-    const Desc d = list[blockIdx.x];
     const u32 len = d.len;
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const u32 wbase = wv * 64u * ITEMS;
@@ -670,6 +720,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_mid(RecBufs bufs, const Desc* 
                         const u32 dg = (key[j] >> sh) & (NBIN - 1);
                         const u32 b0 = hist[dg], b1 = hist[dg + 1], my = key[j], me = pos[j];
                         u32 f = b0;
+#pragma nounroll
                         for (u32 q = b0; q < b1; ++q) { const u32 kk = ex[q]; f += (kk < my) || (kk == my && q < me); }
                         pos[j] = f;
                     }
@@ -974,6 +1025,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
                     const u32 dg = (key[j] >> sh) & (NBIN - 1);
                     const u32 b0 = v ? hist[dg] : 0u, b1 = v ? hist[dg + 1] : 0u, my = key[j], me = pos[j];
                     u32 lt = 0, eq = 0, eqb = 0;
+#pragma nounroll
                     for (u32 q = b0; q < b1; ++q) { const u32 kk = ex[q]; lt += kk < my; eq += kk == my; eqb += (kk == my) & (q < me); }
                     if (v) { pos[j] = b0 + lt + eqb; info[j] = (b0 + lt) | (eq << 16) | (eqb << 24); tie |= eq > 1; }
                 }
@@ -1039,6 +1091,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
             }
         }
         if (!more) break;
+        __syncthreads();            // everyone is done with misc[]/hist[]/ex[] of this segment before they are reset
         if (!fetched) {
             d = list[seg];
             const u64* src = bufs.p[d.buf] + d.rec_off;
@@ -1052,6 +1105,19 @@ template <int THREADS, int ITEMS, int BITS>
 constexpr size_t sort_fast_lds_bytes()
 {
     return ((size_t)THREADS * ITEMS + 64 + ((size_t)1 << BITS) + 16 + 16 + 16) * 4;
+}
+
+// persistent launch: workgroups stride over the list and skip what k_sort_fast already finished
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+                                                      u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                      Emit em, u32* __restrict__ counters, const u32* __restrict__ skip)
+{
+    for (u32 seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        if (skip && skip[seg]) continue;
+        sort_mid_segment<THREADS, ITEMS>(bufs, list[seg], sa_out, isa, mode, em, counters);
+        __syncthreads();
+    }
 }
 
 template <int THREADS, int ITEMS>

@@ -1,4 +1,5 @@
 #!/bin/bash
+ulimit -c 0
 # standard iteration: parity tests, 1 GiB bench, kernel-trace stats
 mkdir -p gpurun_out/prof
 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log

@@ -1,4 +1,5 @@
 #!/bin/bash
+ulimit -c 0
 # PMC counters for selected kernels (separate passes, no tracing domains other than kernel-trace)
 mkdir -p gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
@@ -17,7 +18,7 @@ for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0][:40]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, d in agg.items():
-    if any(s in k for s in ("sort_mid", "partition", "scatter0", "hist16")):
+    if any(s in k for s in ("sort_fast", "partition", "scatter0", "hist16")):
         print(k, {a: f"{b:.4g}" for a, b in d.items()})
 PY
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc/raw$i
