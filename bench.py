@@ -133,7 +133,7 @@ def main():
             "k_hist16": (avg("hist16_ms"), n),
             "k_scatter0": (avg("scatter0_ms"), n + 8 * m),
             "k_partition(level 1)": (avg("scatter1_ms"), 16 * m),
-            "k_sort_mid(bucket sort)": (avg("bucket_sort_ms"), 12 * m),
+            "k_sort_fast(bucket sort)": (avg("bucket_sort_ms"), 12 * m),
         }
         dom = max(kern, key=lambda k: kern[k][0])
         dms, dbytes = kern[dom]

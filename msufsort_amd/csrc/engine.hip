@@ -94,8 +94,8 @@ struct msufsort_hip_ctx {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast<CLS_C_THREADS, CLS_C_ITEMS, 14, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS, 14>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast<CLS_C_THREADS, CLS_C_ITEMS, FAST_BITS_C, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS, FAST_BITS_C>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast<CLS_B_THREADS, CLS_B_ITEMS, 12, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12>()));
         attrs_set = true;
@@ -325,7 +325,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
     {
         u32 a[3]; a[0] = 1; a[1] = 0; a[2] = 2;
         hipLaunchKernelGGL(k_children, dim3(256), dim3(256), 0, st, bufs, c->seg0.as<Desc>(), 256u, c->child_start.as<u32>(), c->child_cnt.as<u32>(),
-                           (const u32*)nullptr, a[0], a[1], a[2], sa_local, (u32*)nullptr, (u32)MODE_TEXT,
+                           (const u32*)nullptr, a[0], a[1], a[2], 24u, sa_local, (u32*)nullptr, (u32)MODE_TEXT,
                            c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), (u32)std::min<u64>(c->cap_m, 0xffffffffu),
                            make_lists(cur), c->lvl[0].as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters);
     }
@@ -360,7 +360,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                                    c->cursor.as<u32>(), c->trivial.as<u32>(), a[0], a[1], a[2]);
                 DBG("k_partition level");
                 hipLaunchKernelGGL(k_children, dim3(nl), dim3(256), 0, st, bufs, src_list, nl, c->child_start.as<u32>(), c->seg_hist.as<u32>(),
-                                   c->trivial.as<u32>(), a[0], a[1], a[2], sa_local, c->isa.as<u32>(), mode,
+                                   c->trivial.as<u32>(), a[0], a[1], a[2], shift, sa_local, c->isa.as<u32>(), mode,
                                    c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), cap32,
                                    make_lists(cur), c->lvl[lp].as<Desc>(), c->large_cap, cnt_idx, til_idx, counters);
                 DBG("k_children level");
@@ -372,7 +372,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 if (last) {
                     if (nl > 0) {
                         hipLaunchKernelGGL(k_carry, dim3(nl), dim3(256), 0, st, bufs, src_list, nl, sa_local, c->isa.as<u32>(), mode,
-                                           bufs.p[nb], nb, (u32)(nxt ? C_SEG1 : C_SEG0), cap32,
+                                           bufs.p[nb], DESC_BUF(32, nb), (u32)(nxt ? C_SEG1 : C_SEG0), cap32,
                                            c->large_round[nxt].as<Desc>(), c->large_cap, (u32)((nxt ? C_LIST1 : C_LIST0) + 3), (u32)(nxt ? C_LTILES1 : C_LTILES0), counters);
                         DBG("k_carry");
                     }
@@ -384,7 +384,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         // ---- LDS sorts of everything that fits ----
         Emit em;
         em.pool_rec = c->pool_rec[nxt].as<u64>(); em.pool_hdr = c->pool_hdr[nxt].as<u64>();
-        em.seg_rec = bufs.p[nb]; em.seg_buf = nb;
+        em.seg_rec = bufs.p[nb]; em.seg_buf = DESC_BUF(32, nb);
         em.pool_cnt_idx = nxt ? C_POOL1 : C_POOL0; em.seg_cnt_idx = nxt ? C_SEG1 : C_SEG0;
         em.pool_cap = cap32; em.seg_cap = cap32;
         em.lists = make_lists(nxt);
@@ -392,34 +392,33 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         const u32 nA = c->h_counters[base + 0], nB = c->h_counters[base + 1], nC = c->h_counters[base + 2];
         const u32 nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
         const bool use_fast = getenv("MSUFSORT_HIP_NO_FAST") == nullptr;
+        if (use_fast && (nB || nC)) hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << C_FBB) | (1u << C_FBC));
         if (nC) {
-            const u32* skip = nullptr;
+            const u32* ids = nullptr;
             if (use_fast) {
-                HIP_TRY(hipMemsetAsync(c->doneC.p, 0, (size_t)nC * 4, st));
-                k_sort_fast<CLS_C_THREADS, CLS_C_ITEMS, 14, false><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_fast_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS, 14>(), st>>>(
-                    bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneC.as<u32>());
+                k_sort_fast<CLS_C_THREADS, CLS_C_ITEMS, FAST_BITS_C, false><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_fast_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS, FAST_BITS_C>(), st>>>(
+                    bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneC.as<u32>(), (u32)C_FBC);
                 DBG("k_sort_fast C");
-                skip = c->doneC.as<u32>();
+                ids = c->doneC.as<u32>();
             }
-            k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(std::min<u32>(nC, 1024u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
-                bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, skip);
+            k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(std::min<u32>(nC, 512u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
+                bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, ids, (u32)C_FBC);
             DBG("k_sort_mid C");
         }
         if (nB) {
-            const u32* skip = nullptr;
+            const u32* ids = nullptr;
             if (use_fast) {
-                HIP_TRY(hipMemsetAsync(c->doneB.p, 0, (size_t)nB * 4, st));
                 k_sort_fast<CLS_B_THREADS, CLS_B_ITEMS, 12, true><<<dim3(std::min<u32>(nB, 256u * 4u)), dim3(CLS_B_THREADS), sort_fast_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12>(), st>>>(
-                    bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneB.as<u32>());
+                    bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneB.as<u32>(), (u32)C_FBB);
                 DBG("k_sort_fast B");
-                skip = c->doneB.as<u32>();
+                ids = c->doneB.as<u32>();
             }
-            k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(std::min<u32>(nB, 4096u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
-                bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, skip);
+            k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(std::min<u32>(nB, 2048u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
+                bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, ids, (u32)C_FBB);
             DBG("k_sort_mid B");
         }
         if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS><<<dim3(std::min<u32>(nA, 1u << 16)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
-                    bufs, c->lists[cur][0].as<Desc>(), nA, sa_local, c->isa.as<u32>(), mode, em, counters, (const u32*)nullptr);
+                    bufs, c->lists[cur][0].as<Desc>(), nA, sa_local, c->isa.as<u32>(), mode, em, counters, (const u32*)nullptr, 0u);
         DBG("k_sort_mid A");
         if (nP) hipLaunchKernelGGL(k_sort_tiny, dim3(cdiv(nP, 256)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(),
                                    (u32)(cur ? C_POOL1 : C_POOL0), sa_local, c->isa.as<u32>(), mode,

@@ -31,8 +31,10 @@ struct Desc {            // one segment = run of records that are equal on every
     u32 rec_off;         // first record (in record buffer `buf`)
     u32 len;
     u32 sa_off;          // first (shard-local) suffix-array row of the segment
-    u32 buf;             // record buffer index 0..2
+    u32 buf;             // bits 0-1: record buffer index 0..2; bits 8-15: kbits = number of low key bits that
+                         // can still differ inside the segment (32 for fresh keys, 24 after the level-1 split, ...)
 };
+#define DESC_BUF(kbits, buf) (((u32)(kbits) << 8) | (u32)(buf))
 
 struct RecBufs { u64* p[3]; };
 
@@ -49,6 +51,7 @@ enum {
     C_SENT = 19,                      // BWT sentinel row
     C_MS = 20,                        // suffixes in this shard
     C_RANK0 = 21,                     // global rank of the shard's first row
+    C_FBB = 22, C_FBC = 23,           // segments k_sort_fast handed back (class B / C)
     C_NCOUNTERS = 32
 };
 
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_count(RecBufs bufs, const Desc* 
     const u32 s = s_seg;
     const Desc d = list[s];
     const u32 off = (tile - tile_start[s]) * P1_TILE;
-    const u64* src = bufs.p[d.buf] + d.rec_off;
+    const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
 #pragma unroll 4
     for (int j = 0; j < P1_ITEMS; ++j) {
         const u32 p = off + j * P1_THREADS + t;
@@ -426,8 +429,8 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
     if (trivial && trivial[s]) return;
     const Desc d = list[s];
     const u32 off = (tile - tile_start[s]) * P1_TILE;
-    const u64* src = bufs.p[d.buf] + d.rec_off;
-    const u32 alt = d.buf == 0 ? alt0 : (d.buf == 1 ? alt1 : alt2);
+    const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
+    const u32 alt = (d.buf & 3u) == 0 ? alt0 : ((d.buf & 3u) == 1 ? alt1 : alt2);
     u64* dst = bufs.p[alt];
     u64 rec[P1_ITEMS];
     u32 rank[P1_ITEMS];
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
 // larger -> next partition level.
 __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __restrict__ parents, u32 nseg,
                                                   const u32* __restrict__ child_start, const u32* __restrict__ child_cnt,
-                                                  const u32* __restrict__ trivial, u32 alt0, u32 alt1, u32 alt2,
+                                                  const u32* __restrict__ trivial, u32 alt0, u32 alt1, u32 alt2, u32 child_kbits,
                                                   u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                   u64* __restrict__ pool_rec, u64* __restrict__ pool_hdr, u32 pool_cnt_idx, u32 pool_cap,
                                                   Lists lists, Desc* __restrict__ lvl_dst, u32 lvl_cap, u32 lvl_cnt_idx, u32 lvl_tiles_idx,
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __re
         par = parents[s];
         start = child_start[c];
         const bool triv = trivial && trivial[s];
-        buf = triv ? par.buf : (par.buf == 0 ? alt0 : (par.buf == 1 ? alt1 : alt2));
+        buf = triv ? (par.buf & 3u) : ((par.buf & 3u) == 0 ? alt0 : ((par.buf & 3u) == 1 ? alt1 : alt2));
         sa = par.sa_off + (start - par.rec_off);
     }
     const u64* src = bufs.p[buf] + start;
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __re
     // descriptors: one counter atomic per wave and class instead of one per child
     const u32 cls = cnt > TINY_MAX ? class_of(cnt) : 4u;
     const u64 lt_mask = lane_id() ? (~0ull >> (64 - lane_id())) : 0ull;
-    const Desc d = {start, cnt, sa, buf};
+    const Desc d = {start, cnt, sa, DESC_BUF(child_kbits, buf)};
 #pragma unroll
     for (u32 k = 0; k < 4; ++k) {
         const u64 m = __ballot(cls == k);
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256) void k_carry(RecBufs bufs, const Desc* __restr
     }
     __syncthreads();
     if (!s_ok) return;
-    const u64* src = bufs.p[d.buf] + d.rec_off;
+    const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
     const u32 rank0 = counters[C_RANK0];
     for (u32 p = threadIdx.x; p < d.len; p += 256u) {
         const u64 r = src[p];
@@ -641,7 +644,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     const u32 len = d.len;
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const u32 wbase = wv * 64u * ITEMS;
-    const u64* src = bufs.p[d.buf] + d.rec_off;
+    const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
     u32 key[ITEMS], idx[ITEMS], pos[ITEMS];
@@ -905,29 +908,39 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fast LDS sort for segments whose keys are spread out (the 16-bit buckets of round 0 on random-like
-// input).  Persistent workgroups (static stride over the list), the next segment's records are
-// prefetched into registers while the current one is sorted:
-//   1. one MSD split on the top varying BITS of the key into 2^BITS sub-buckets; the rank inside the
-//      sub-bucket comes from a returning LDS atomic (order inside a sub-bucket is arbitrary);
-//   2. block-wide exclusive scan of the sub-bucket counts;
-//   3. every record counts, inside its own (tiny) sub-bucket, the keys below it and the equal keys before
-//      it: that IS its final row, and the number of equal keys IS its tie-run length - no second pass,
-//      no neighbour compares;
-//   4. suffix indices are exchanged through LDS and written to the suffix array coalesced.
-// A segment with a sub-bucket above FAST_LIMIT (skewed keys) is left to k_sort_mid (done[seg] stays 0).
+// Fast LDS sort for segments whose keys are spread out (the two-byte buckets of round 0 on random-like
+// input) - the hot kernel of the whole build.  Persistent workgroups stride over the list.
+//   1. one MSD split on the top BITS of the kbits varying key bits into 2^BITS sub-buckets; the rank r
+//      inside the sub-bucket comes from a returning LDS atomic (arrival order, arbitrary);
+//   2. block-wide exclusive scan of the sub-bucket counts (+ their maximum);
+//   3. every record stores the composite c = (varying key bits << 6) | r at base + r.  Composites are
+//      distinct and globally ordered like (key, r), so a record's FINAL row is base + #{c' < c} over the
+//      next FAST_PROBE slots from its sub-bucket's base - straight-line code, no loop, no predicate: slots
+//      of later sub-buckets hold larger composites and the tail is padded with 0xffffffff.  The number of
+//      slots with (c' ^ c) < 64 is the length of the record's tie run (equal keys).
+//      Sub-buckets longer than FAST_PROBE (rare) finish in a short wave-uniform loop;
+//   4. suffix indices are exchanged through LDS and written to the suffix array coalesced; the few tie
+//      runs are compacted for the next round.
+// Needs kbits <= 26 (composite in 32 bits) and no sub-bucket above FAST_LIMIT (r < 64); other segments are
+// handed back to k_sort_mid through fb_list.
 // ------------------------------------------------------------------------------------------------
-#define FAST_LIMIT 40u
+#define FAST_LIMIT 48u
+#ifndef FAST_PROBE
+#define FAST_PROBE 6
+#endif
+#ifndef FAST_BITS_C
+#define FAST_BITS_C 14
+#endif
 template <int THREADS, int ITEMS, int BITS, bool PREFETCH>
 __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                        u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
-                                                       Emit em, u32* __restrict__ counters, u32* __restrict__ done)
+                                                       Emit em, u32* __restrict__ counters, u32* __restrict__ fb_list, u32 fb_cnt_idx)
 {
     constexpr int CAP = THREADS * ITEMS;
     constexpr int W = THREADS / 64;
     constexpr int NBIN = 1 << BITS;
     constexpr int E = NBIN / THREADS;
-    constexpr u32 TRASH_POS = CAP;            // ex slot that absorbs the lanes past the end of the segment
+    constexpr u32 TRASH_POS = CAP + 32;       // ex slot that absorbs the lanes past the end of the segment
     constexpr u32 TRASH_BIN = NBIN + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP + 64
@@ -942,14 +955,14 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
     Desc d = list[seg];
     u64 nrec[ITEMS];
     {
-        const u64* src = bufs.p[d.buf] + d.rec_off;
+        const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; nrec[j] = p < d.len ? src[p] : ~0ull; }
     }
     const u32 rank0 = counters[C_RANK0];
     for (;;) {
-        const u32 len = d.len, sa_off = d.sa_off, cur = seg;
-        u32 key[ITEMS], idx[ITEMS], pos[ITEMS];
+        const u32 len = d.len, sa_off = d.sa_off, cur = seg, kbits = (d.buf >> 8) & 255u;
+        u32 key[ITEMS], idx[ITEMS];       // key[] turns into the composite after the scan
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) { key[j] = (u32)(nrec[j] >> 32); idx[j] = (u32)nrec[j]; }
         seg += gridDim.x;
@@ -957,91 +970,97 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
         bool fetched = false;
         int rows = 0;
         if (wbase < len) { const u32 rem = len - wbase; rows = (int)((rem + 63u) / 64u); if (rows > ITEMS) rows = ITEMS; }
+        const u32 kmask = kbits >= 32 ? 0xffffffffu : ((1u << kbits) - 1u);
+        const u32 sh = kbits > (u32)BITS ? kbits - BITS : 0u;
+        bool ok = kbits <= 26u;                                  // block-uniform
 
-        if (t < 16) misc[t] = 0;
-        for (u32 i = t; i < (u32)NBIN + 16u; i += THREADS) hist[i] = 0;
-        if (t == 0) misc[5] = key[0];
-        __syncthreads();                                                            // (1)
-        u32 diff = 0;
-        { const u32 k0 = misc[5];
+        if (ok) {
+            if (t < 16) misc[t] = 0;
+            for (u32 i = t; i < (u32)NBIN + 16u; i += THREADS) hist[i] = 0;
+            if (t < 64) ex[len + t] = 0xffffffffu;               // inert tail for the probes (len + 63 < CAP + 64)
+            __syncthreads();                                                        // (1)
 #pragma unroll
-          for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; diff |= (p < len) ? (key[j] ^ k0) : 0u; } }
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = wbase + j * 64 + lane;
+                    const u32 k = key[j] & kmask;
+                    const u32 r = atomicAdd(&hist[p < len ? (k >> sh) : TRASH_BIN], 1u);
+                    key[j] = p < len ? ((k << 6) | (r & 63u)) : 0xffffffffu;      // composite (r < 64 is checked below)
+                }
+            __syncthreads();                                                        // (2)
+            {   // exclusive scan of hist[0..NBIN) in place, E consecutive bins per thread; block max of the counts
+                u32 sum = 0, mx = 0;
 #pragma unroll
-        for (int s2 = 32; s2 >= 1; s2 >>= 1) diff |= __shfl_xor(diff, s2, 64);
-        if (lane == 0 && diff) atomicOr(&misc[0], diff);
-        __syncthreads();                                                            // (2)
-        diff = misc[0];
-        const int hb = diff ? 31 - __clz((int)diff) : 0;
-        const u32 sh = hb + 1 > BITS ? (u32)(hb + 1 - BITS) : 0u;
+                for (int k = 0; k < E; ++k) { const u32 c = hist[t * E + k]; sum += c; mx = c > mx ? c : mx; }
+                u32 wt;
+                u32 e = wave_excl_scan(sum, wt);
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j)
-            if (j < rows) {
-                const u32 p = wbase + j * 64 + lane;
-                const u32 dg = p < len ? ((key[j] >> sh) & (NBIN - 1)) : TRASH_BIN;
-                pos[j] = atomicAdd(&hist[dg], 1u);
+                for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(mx, s2, 64); mx = o > mx ? o : mx; }
+                if (lane == 63) tot[wv] = wt;
+                if (lane == 0) atomicMax(&misc[1], mx);
+                __syncthreads();                                                    // (3)
+                u32 wb = 0;
+#pragma unroll
+                for (int k = 0; k < W; ++k) if (k < (int)wv) wb += tot[k];
+                e += wb;
+#pragma unroll
+                for (int k = 0; k < E; ++k) { const u32 c = hist[t * E + k]; hist[t * E + k] = e; e += c; }
+                if (t == THREADS - 1) hist[NBIN] = e;
             }
-        __syncthreads();                                                            // (3)
-        {   // exclusive scan of hist[0..NBIN) in place, E consecutive bins per thread; block max of the counts
-            u32 sum = 0, mx = 0;
-#pragma unroll
-            for (int k = 0; k < E; ++k) { const u32 c = hist[t * E + k]; sum += c; mx = c > mx ? c : mx; }
-            u32 wt;
-            u32 e = wave_excl_scan(sum, wt);
-#pragma unroll
-            for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(mx, s2, 64); mx = o > mx ? o : mx; }
-            if (lane == 63) tot[wv] = wt;
-            if (lane == 0) atomicMax(&misc[1], mx);
             __syncthreads();                                                        // (4)
-            u32 wb = 0;
-#pragma unroll
-            for (int k = 0; k < W; ++k) if (k < (int)wv) wb += tot[k];
-            e += wb;
-#pragma unroll
-            for (int k = 0; k < E; ++k) { const u32 c = hist[t * E + k]; hist[t * E + k] = e; e += c; }
-            if (t == THREADS - 1) hist[NBIN] = e;
+            ok = misc[1] <= FAST_LIMIT;
         }
-        __syncthreads();                                                            // (5)
-        const bool ok = diff != 0 && misc[1] <= FAST_LIMIT;
         if (ok) {
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j)
                 if (j < rows) {
                     const u32 p = wbase + j * 64 + lane;
-                    const bool v = p < len;
-                    const u32 dg = (key[j] >> sh) & (NBIN - 1);
-                    pos[j] = v ? hist[dg] + pos[j] : TRASH_POS;
-                    ex[pos[j]] = key[j];
+                    const u32 c = key[j];
+                    ex[p < len ? hist[c >> (6 + sh)] + (c & 63u) : TRASH_POS] = c;
                 }
-            __syncthreads();                                                        // (6)
-            // pos[] becomes the final row; info[] = run start (16 bits) | run length << 16 | my offset << 24
-            u32 info[ITEMS];
+            __syncthreads();                                                        // (5)
+            // pos[] = final row; info[] = run start (16 bits) | run length << 16 | my offset << 24
+            u32 pos[ITEMS], info[ITEMS];
             bool tie = false;
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 info[j] = 1u << 16;
+                pos[j] = TRASH_POS;
                 if (j < rows) {
                     const u32 p = wbase + j * 64 + lane;
                     const bool v = p < len;
-                    const u32 dg = (key[j] >> sh) & (NBIN - 1);
-                    const u32 b0 = v ? hist[dg] : 0u, b1 = v ? hist[dg + 1] : 0u, my = key[j], me = pos[j];
-                    u32 lt = 0, eq = 0, eqb = 0;
+                    const u32 me = key[j];
+                    const u32 dg = v ? (me >> (6 + sh)) : 0u;
+                    const u32 b0 = hist[dg];
+                    u32 lt = 0, eq = 0;
+#pragma unroll
+                    for (int q = 0; q < FAST_PROBE; ++q) { const u32 c = ex[b0 + q]; lt += c < me; eq += (c ^ me) < 64u; }
+                    const u32 b1 = hist[dg + 1];
+                    if (__ballot(v && b1 - b0 > FAST_PROBE)) {                      // rare: a long sub-bucket in this row
 #pragma nounroll
-                    for (u32 q = b0; q < b1; ++q) { const u32 kk = ex[q]; lt += kk < my; eq += kk == my; eqb += (kk == my) & (q < me); }
-                    if (v) { pos[j] = b0 + lt + eqb; info[j] = (b0 + lt) | (eq << 16) | (eqb << 24); tie |= eq > 1; }
+                        for (u32 q = b0 + FAST_PROBE; q < b1; ++q) { const u32 c = ex[q]; lt += c < me; eq += (c ^ me) < 64u; }
+                    }
+                    if (__ballot(v && eq > 1)) {                                    // rare: equal keys in this row
+                        u32 ltk = 0;
+#pragma nounroll
+                        for (u32 q = b0; q < b1; ++q) ltk += (ex[q] >> 6) < (me >> 6);
+                        if (v && eq > 1) { info[j] = (b0 + ltk) | (eq << 16) | ((lt - ltk) << 24); tie = true; }
+                    }
+                    if (v) { pos[j] = b0 + lt; if (eq <= 1) info[j] = (b0 + lt) | (1u << 16); }
                 }
             }
-            // keys are dead from here on: prefetch the next segment of this workgroup into their registers
+            // composites are dead from here on: prefetch the next segment of this workgroup
             if (PREFETCH && more) {
                 d = list[seg];
-                const u64* src = bufs.p[d.buf] + d.rec_off;
+                const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
 #pragma unroll
                 for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; nrec[j] = p < d.len ? src[p] : ~0ull; }
                 fetched = true;
             }
-            __syncthreads();                                                        // (7)
+            __syncthreads();                                                        // (6)
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[pos[j]] = idx[j];
-            __syncthreads();                                                        // (8)
+            __syncthreads();                                                        // (7)
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j)
                 if (j < rows) {
@@ -1051,8 +1070,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
                         if (mode == MODE_ISA) isa[idx[j]] = rank0 + sa_off + (info[j] & 0xffffu) + 1u;
                     }
                 }
-            if (t == 0) done[cur] = 1u;
-            if (__syncthreads_or(tie)) {                                            // (9)
+            if (__syncthreads_or(tie)) {                                            // (8)
                 // compact still-tied runs: run leader (offset 0) reserves room, members follow
 #pragma unroll
                 for (int j = 0; j < ITEMS; ++j) {
@@ -1087,14 +1105,14 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
                         }
                     }
                 }
-                __syncthreads();
             }
         }
+        if (!ok && t == 0) fb_list[atomicAdd(&counters[fb_cnt_idx], 1u)] = cur;   // leave it to k_sort_mid
         if (!more) break;
         __syncthreads();            // everyone is done with misc[]/hist[]/ex[] of this segment before they are reset
         if (!fetched) {
             d = list[seg];
-            const u64* src = bufs.p[d.buf] + d.rec_off;
+            const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; nrec[j] = p < d.len ? src[p] : ~0ull; }
         }
@@ -1111,11 +1129,12 @@ constexpr size_t sort_fast_lds_bytes()
 template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                       u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
-                                                      Emit em, u32* __restrict__ counters, const u32* __restrict__ skip)
+                                                      Emit em, u32* __restrict__ counters, const u32* __restrict__ ids, u32 ids_cnt_idx)
 {
-    for (u32 seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        if (skip && skip[seg]) continue;
-        sort_mid_segment<THREADS, ITEMS>(bufs, list[seg], sa_out, isa, mode, em, counters);
+    // ids != nullptr: only the segments k_sort_fast left behind (their count lives in the counters block)
+    const u32 total = ids ? counters[ids_cnt_idx] : nseg;
+    for (u32 i = blockIdx.x; i < total; i += gridDim.x) {
+        sort_mid_segment<THREADS, ITEMS>(bufs, list[ids ? ids[i] : i], sa_out, isa, mode, em, counters);
         __syncthreads();
     }
 }
@@ -1227,7 +1246,7 @@ __global__ __launch_bounds__(256) void k_isa_segs(RecBufs bufs, const Desc* __re
     if (blockIdx.x >= nseg) return;
     const Desc d = list[blockIdx.x];
     const u32 rank0 = counters[C_RANK0];
-    const u64* src = bufs.p[d.buf] + d.rec_off;
+    const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
     for (u32 p = threadIdx.x; p < d.len; p += 256u) isa[(u32)src[p]] = rank0 + d.sa_off + 1u;
 }
 

@@ -4,7 +4,7 @@ ulimit -c 0
 LIBV=$1; shift
 cp msufsort_amd/lib/libmsufsort_hip.so /tmp/lib_backup.so
 cp msufsort_amd/lib/$LIBV msufsort_amd/lib/libmsufsort_hip.so
-cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/expraw; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/expraw -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu "$@" > /tmp/exp.log 2>&1
 cd $GRAFT_REPO_ROOT
 cp /tmp/lib_backup.so msufsort_amd/lib/libmsufsort_hip.so
