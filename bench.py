@@ -138,6 +138,13 @@ def main():
         dom = max(kern, key=lambda k: kern[k][0])
         dms, dbytes = kern[dom]
         ach = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC run (only meaningful for the same workload size)
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt.get("n") == n and world == 1 and args.workload == "random":
+                traffic = pt["kernels"].get(dom)
+        except Exception:  # noqa: BLE001
+            traffic = None
         radix_ms = kern["k_hist16"][0] + kern["k_scatter0"][0]
         out = {
             "metric": "MB/s input for SA build on 1 GiB random bytes",
@@ -154,7 +161,7 @@ def main():
             "config": {"workload": f"{args.workload} bytes (splitmix64 seed {args.seed}), n={n}, int32 SA, 16-bit-key range sharding x{world}",
                        "n": n, "index": "int32"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launch_ms": round(dms, 4), "algorithmic_bytes": int(dbytes)},
             "radix_pass": {"read_bytes": 2 * n, "ms": round(radix_ms, 4),
                            "read_frac_of_hbm_peak": round((2 * n / (radix_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4) if radix_ms > 0 else None},

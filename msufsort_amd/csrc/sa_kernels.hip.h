@@ -668,83 +668,8 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     int rows = 0;
     if (wbase < len) { const u32 rem = len - wbase; rows = (int)((rem + 63u) / 64u); if (rows > ITEMS) rows = ITEMS; }
 
-    // ---- fast path: one MSD split on the top varying bits into NBIN sub-buckets (unstable ranks from
-    // returning LDS atomics), then every record finds its final place by counting inside its sub-bucket.
-    // Uniformly distributed keys (round 0 of random input) give sub-buckets of ~4; skewed keys trip
-    // MSD_LIMIT and take the distribution-independent LSD passes below instead.
-    bool sorted_done = (diff == 0);
-    if (diff != 0) {
-        const int hb = 31 - __clz((int)diff);
-        const u32 sh = hb + 1 > MSD_BITS ? (u32)(hb + 1 - MSD_BITS) : 0u;
-        u32* hist = wcnt;
-        for (u32 i = t; i < (u32)NBIN + 1u; i += THREADS) hist[i] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j)
-            if (j < rows) {
-                const u32 p = wbase + j * 64 + lane;
-                if (p < len) pos[j] = atomicAdd(&hist[(key[j] >> sh) & (NBIN - 1)], 1u);
-            }
-        __syncthreads();
-        {   // exclusive scan of hist[NBIN] in place, E consecutive bins per thread; block max of the counts
-            constexpr int E = NBIN / THREADS;
-            u32 c[E], sum = 0, mx = 0;
-#pragma unroll
-            for (int k = 0; k < E; ++k) { c[k] = hist[t * E + k]; sum += c[k]; mx = c[k] > mx ? c[k] : mx; }
-            u32 wt;
-            u32 e = wave_excl_scan(sum, wt);
-#pragma unroll
-            for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(mx, s2, 64); mx = o > mx ? o : mx; }
-            if (lane == 63) tot[wv] = wt;
-            if (lane == 0) atomicMax(&misc[4], mx);
-            __syncthreads();
-            u32 wb = 0;
-#pragma unroll
-            for (int k = 0; k < W; ++k) if (k < (int)wv) wb += tot[k];
-            e += wb;
-#pragma unroll
-            for (int k = 0; k < E; ++k) { hist[t * E + k] = e; e += c[k]; }
-            if (t == THREADS - 1) hist[NBIN] = e;
-        }
-        __syncthreads();
-        if (misc[4] <= MSD_LIMIT) {
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-                if (j < rows) {
-                    const u32 p = wbase + j * 64 + lane;
-                    if (p < len) { pos[j] += hist[(key[j] >> sh) & (NBIN - 1)]; ex[pos[j]] = key[j]; }
-                }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-                if (j < rows) {
-                    const u32 p = wbase + j * 64 + lane;
-                    if (p < len) {
-                        const u32 dg = (key[j] >> sh) & (NBIN - 1);
-                        const u32 b0 = hist[dg], b1 = hist[dg + 1], my = key[j], me = pos[j];
-                        u32 f = b0;
+    const bool sorted_done = (diff == 0);
 #pragma nounroll
-                        for (u32 q = b0; q < b1; ++q) { const u32 kk = ex[q]; f += (kk < my) || (kk == my && q < me); }
-                        pos[j] = f;
-                    }
-                }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) if (j < rows) { const u32 p = wbase + j * 64 + lane; if (p < len) ex[pos[j]] = key[j]; }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) if (j < rows) { const u32 p = wbase + j * 64 + lane; key[j] = p < len ? ex[p] : 0xffffffffu; }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) if (j < rows) { const u32 p = wbase + j * 64 + lane; if (p < len) ex[pos[j]] = idx[j]; }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) if (j < rows) { const u32 p = wbase + j * 64 + lane; idx[j] = p < len ? ex[p] : 0xffffffffu; }
-            __syncthreads();
-            sorted_done = true;
-        }
-    }
-
     for (u32 shift = 0; shift < 32 && !sorted_done; shift += 8) {
         if (((diff >> shift) & 255u) == 0) continue;            // byte equal everywhere: pass not needed
         for (u32 i = t; i < (u32)W * 256u; i += THREADS) wcnt[i] = 0;
