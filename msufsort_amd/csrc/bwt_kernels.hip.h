@@ -36,11 +36,74 @@ __device__ __forceinline__ u32 dev_match_length(const u8* __restrict__ text, u64
     return (u32)m;
 }
 
-// demo convention (main.cpp:66-101): out[i] = lcp(SA[i+1], SA[i+2]), i in [0, n-2]; out[n-1] = 0
-__global__ __launch_bounds__(256) void k_lcp(const u8* __restrict__ text, u64 n, const u32* __restrict__ sa, u32* __restrict__ out)
+// demo convention (main.cpp:66-101): out[i] = lcp(SA[i+1], SA[i+2]), i in [0, n-2]; out[n-1] = 0.
+// Direct compare like the demo's match_length, but capped: a pair that is still equal after `cap` bytes raises
+// *flag and the host switches to the PLCP method below (periodic inputs have LCPs of 10^4..10^5).
+__global__ __launch_bounds__(256) void k_lcp(const u8* __restrict__ text, u64 n, const u32* __restrict__ sa, u32* __restrict__ out,
+                                             u32 cap, u32* __restrict__ flag)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u) {
+        u32 v = 0;
+        if (i + 1 < n) {
+            u64 a = sa[i + 1], b = sa[i + 2];
+            if (a > b) { const u64 x = a; a = b; b = x; }
+            u64 m = 0;
+            bool open = true;
+            while (open && b + m + 8 <= n && m < cap) {
+                u64 x, y;
+                __builtin_memcpy(&x, text + a + m, 8);
+                __builtin_memcpy(&y, text + b + m, 8);
+                if (x != y) { m += (u64)(__ffsll((long long)(x ^ y)) - 1) >> 3; open = false; }
+                else m += 8;
+            }
+            if (open) {
+                if (m >= cap) *flag = 1u;
+                while (b + m < n && text[a + m] == text[b + m] && m < (u64)cap + 16) ++m;
+            }
+            v = (u32)m;
+        }
+        out[i] = v;
+    }
+}
+
+// PLCP method (Karkkainen-Manzini-Puglisi "permuted LCP"): phi[SA[r]] = SA[r-1]; PLCP[i] = lcp(i, phi[i]) obeys
+// PLCP[i] >= PLCP[i-1] - 1, so a thread that walks a chunk of consecutive text positions only pays the
+// full match once.  LCP[r] = PLCP[SA[r]].
+#define PLCP_CHUNK 128u
+__global__ __launch_bounds__(256) void k_phi(const u32* __restrict__ sa, u64 n, u32* __restrict__ phi)
+{
+    for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x + 1; r <= n; r += (u64)gridDim.x * 256u) phi[sa[r]] = sa[r - 1];
+}
+
+__global__ __launch_bounds__(256) void k_plcp(const u8* __restrict__ text, u64 n, const u32* __restrict__ phi, u32* __restrict__ plcp)
+{
+    const u64 nchunks = (n + PLCP_CHUNK - 1) / PLCP_CHUNK;
+    for (u64 c = (u64)blockIdx.x * 256u + threadIdx.x; c < nchunks; c += (u64)gridDim.x * 256u) {
+        u64 l = 0;
+        const u64 end = (c + 1) * PLCP_CHUNK < n ? (c + 1) * PLCP_CHUNK : n;
+        for (u64 i = c * PLCP_CHUNK; i < end; ++i) {
+            const u64 j = phi[i];
+            if (j >= n) { plcp[i] = 0; l = 0; continue; }        // predecessor is the empty suffix
+            l = l ? l - 1 : 0;
+            const u64 hi = i > j ? i : j;
+            bool open = true;
+            while (open && hi + l + 8 <= n) {
+                u64 x, y;
+                __builtin_memcpy(&x, text + i + l, 8);
+                __builtin_memcpy(&y, text + j + l, 8);
+                if (x != y) { l += (u64)(__ffsll((long long)(x ^ y)) - 1) >> 3; open = false; }
+                else l += 8;
+            }
+            if (open) while (hi + l < n && text[i + l] == text[j + l]) ++l;
+            plcp[i] = (u32)l;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lcp_from_plcp(const u32* __restrict__ sa, u64 n, const u32* __restrict__ plcp, u32* __restrict__ out)
 {
     for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u)
-        out[i] = (i + 1 < n) ? dev_match_length(text, n, sa[i + 1], sa[i + 2]) : 0u;
+        out[i] = (i + 1 < n) ? plcp[sa[i + 2]] : 0u;
 }
 
 // validate_suffix_array (main.cpp:236-270): SA[0] == n, adjacent suffixes strictly increasing

@@ -629,7 +629,6 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     constexpr int MSD_BITS = CAP >= 16384 ? 12 : (CAP >= 4096 ? 10 : 7);
     constexpr int NBIN = 1 << MSD_BITS;                         // sub-buckets of the MSD fast path
     constexpr int WCNT = (W * 256 > NBIN ? W * 256 : NBIN) + 8; // LSD per-wave digit counters / MSD histogram
-    constexpr u32 MSD_LIMIT = 48;                               // largest sub-bucket the counting rank accepts
     u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP
     u32* wcnt = ex + CAP;                                       // WCNT
     u32* tot = wcnt + WCNT;                                     // 256

@@ -106,6 +106,20 @@ def test_prefix_doubling_path(M, oracle_mod):
     assert oracle_mod.validate_sa(t, sa) == 0
 
 
+def test_lcp_plcp_path(M, oracle_mod, monkeypatch):
+    """LCP: the capped direct compare and the PLCP (phi) method must agree with the demo's convention."""
+    t = gen.text_bytes(300000, 13)
+    sa = oracle_mod.make_suffix_array(t)
+    want = oracle_mod.lcp(t, sa)
+    assert (M.make_lcp_array(t, sa) == want).all()
+    monkeypatch.setenv("MSUFSORT_HIP_LCP_CAP", "8")          # force the PLCP method
+    assert (M.make_lcp_array(t, sa) == want).all()
+    monkeypatch.delenv("MSUFSORT_HIP_LCP_CAP")
+    t = np.tile(gen.dna_bytes(91, 4), 3000)                  # period 91: LCPs up to ~273k, PLCP path by itself
+    sa = M.make_suffix_array(t)
+    assert (M.make_lcp_array(t, sa) == oracle_mod.lcp(t, sa)).all()
+
+
 def _dev(M, t):
     import torch
     n = t.size
