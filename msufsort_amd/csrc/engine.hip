@@ -81,6 +81,7 @@ struct msufsort_hip_ctx {
     u32 list_cap[3] = {0, 0, 0};
     u32 large_cap = 0;
     u64 cap_m = 0;               // records capacity
+    u64 cap_for_m = 0;           // largest m the workspace was sized for
     msufsort_hip_timings tm{};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
@@ -104,14 +105,14 @@ struct msufsort_hip_ctx {
 
     int ensure_workspace(u64 m)
     {
-        if (m <= cap_m) return MSUFSORT_HIP_OK;
-        u64 cap = m + 1024;
+        if (cap_for_m >= m) return MSUFSORT_HIP_OK;
+        u64 cap = m + m / 4 + (2u << 20);        // + room for the neutral tails of chunked output reservations
         for (auto& b : rec) TRY(b.ensure(cap * 8));
         for (auto& b : pool_rec) TRY(b.ensure(cap * 8));
         for (auto& b : pool_hdr) TRY(b.ensure(cap * 8));
-        list_cap[0] = (u32)(cap / (TINY_MAX + 1) + 16);
-        list_cap[1] = (u32)(cap / (CAP_A + 1) + 16);
-        list_cap[2] = (u32)(cap / (CAP_B + 1) + 16);
+        list_cap[0] = (u32)(cap / (TINY_MAX + 1) + (2u << 20));
+        list_cap[1] = (u32)(cap / (CAP_A + 1) + (2u << 20));
+        list_cap[2] = (u32)(cap / (CAP_B + 1) + (2u << 20));
         large_cap = (u32)(cap / (CAP_C + 1) + 16);
         for (int s = 0; s < 2; ++s) {
             for (int c = 0; c < 3; ++c) TRY(lists[s][c].ensure((size_t)list_cap[c] * sizeof(Desc)));
@@ -135,6 +136,7 @@ struct msufsort_hip_ctx {
         TRY(doneB.ensure((size_t)list_cap[1] * 4));
         TRY(doneC.ensure((size_t)list_cap[2] * 4));
         cap_m = cap;
+        cap_for_m = m;
         return MSUFSORT_HIP_OK;
     }
 
@@ -147,7 +149,7 @@ struct msufsort_hip_ctx {
         seg0.release(); seg0_base.release(); hist_partial.release(); hist.release(); bstart.release(); child_start.release(); child_cnt.release();
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release();
-        cap_m = 0;
+        cap_m = 0; cap_for_m = 0;
     }
 
     int read_counters()
@@ -387,6 +389,11 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         em.seg_rec = bufs.p[nb]; em.seg_buf = DESC_BUF(32, nb);
         em.pool_cnt_idx = nxt ? C_POOL1 : C_POOL0; em.seg_cnt_idx = nxt ? C_SEG1 : C_SEG0;
         em.pool_cap = cap32; em.seg_cap = cap32;
+        {   // chunk = what the persistent workgroups reserve per global atomic; slack <= active/16 per kernel
+            const u64 act = (u64)c->h_counters[cur ? C_POOL1 : C_POOL0] + c->h_counters[cur ? C_SEG1 : C_SEG0] + (round == 0 ? m : 0);
+            const u64 ch = std::min<u64>(4096, std::max<u64>(32, act / (16 * 8192)));
+            em.pool_chunk = (u32)ch; em.seg_chunk = (u32)ch;
+        }
         em.lists = make_lists(nxt);
         const u32 base = cur ? C_LIST1 : C_LIST0;
         const u32 nA = c->h_counters[base + 0], nB = c->h_counters[base + 1], nC = c->h_counters[base + 2];
@@ -401,7 +408,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 DBG("k_sort_fast C");
                 ids = c->doneC.as<u32>();
             }
-            k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(std::min<u32>(nC, 512u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
+            k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
                 bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, ids, (u32)C_FBC);
             DBG("k_sort_mid C");
         }
@@ -413,16 +420,16 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 DBG("k_sort_fast B");
                 ids = c->doneB.as<u32>();
             }
-            k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(std::min<u32>(nB, 2048u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
+            k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(std::min<u32>(nB, 768u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
                 bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, ids, (u32)C_FBB);
             DBG("k_sort_mid B");
         }
-        if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS><<<dim3(std::min<u32>(nA, 1u << 16)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
+        if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
                     bufs, c->lists[cur][0].as<Desc>(), nA, sa_local, c->isa.as<u32>(), mode, em, counters, (const u32*)nullptr, 0u);
         DBG("k_sort_mid A");
-        if (nP) hipLaunchKernelGGL(k_sort_tiny, dim3(cdiv(nP, 256)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(),
+        if (nP) hipLaunchKernelGGL(k_sort_tiny, dim3(std::min<u32>(cdiv(nP, 256), 8192u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(),
                                    (u32)(cur ? C_POOL1 : C_POOL0), sa_local, c->isa.as<u32>(), mode,
-                                   em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32, counters);
+                                   em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32, em.pool_chunk, counters);
         DBG("k_sort_tiny");
         if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
         TRY(c->read_counters());

@@ -96,6 +96,7 @@ struct Emit {             // where still-tied runs go (next round)
     u32 pool_cnt_idx;     // counter indices
     u32 seg_cnt_idx;
     u32 pool_cap, seg_cap;
+    u32 pool_chunk, seg_chunk;   // persistent workgroups reserve output room in chunks of this many slots
     Lists lists;
 };
 
@@ -497,10 +498,21 @@ __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __re
         const u32 idx = (u32)src[0];
         sa_out[sa] = idx;
         if (mode == MODE_ISA) isa[idx] = rank0 + sa + 1u;
-    } else if (cnt > 1 && cnt <= TINY_MAX) {
-        const u32 b = atomicAdd(&counters[pool_cnt_idx], cnt);
-        if (b + cnt > pool_cap) atomicOr(&counters[C_ERR], 2u);
-        else for (u32 k = 0; k < cnt; ++k) { pool_rec[b + k] = src[k]; pool_hdr[b + k] = pack_hdr(sa, cnt, k); }
+    }
+    {   // tiny children: one pool allocation per wave
+        const u32 want = (cnt > 1 && cnt <= TINY_MAX) ? cnt : 0u;
+        u32 wtot;
+        const u32 woff = wave_excl_scan(want, wtot);
+        u32 base = 0;
+        if (wtot) {
+            if (lane_id() == 0) base = atomicAdd(&counters[pool_cnt_idx], wtot);
+            base = __shfl(base, 0, 64);
+            if ((u64)base + wtot > pool_cap) { if (lane_id() == 0) atomicOr(&counters[C_ERR], 2u); }
+            else if (want) {
+                const u32 b = base + woff;
+                for (u32 k = 0; k < cnt; ++k) { pool_rec[b + k] = src[k]; pool_hdr[b + k] = pack_hdr(sa, cnt, k); }
+            }
+        }
     }
     // descriptors: one counter atomic per wave and class instead of one per child
     const u32 cls = cnt > TINY_MAX ? class_of(cnt) : 4u;
@@ -618,10 +630,24 @@ __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32
 // runs are compacted into next round's tiny pool / segment array.
 // ------------------------------------------------------------------------------------------------
 template <int THREADS, int ITEMS>
+constexpr size_t sort_mid_lds_bytes()
+{
+    constexpr int CAP = THREADS * ITEMS;
+    constexpr int NBIN = 1 << (CAP >= 16384 ? 12 : (CAP >= 4096 ? 10 : 7));
+    constexpr int WC = ((THREADS / 64) * 256 > NBIN ? (THREADS / 64) * 256 : NBIN) + 8;
+    return (size_t)(THREADS * ITEMS) * 4 + (size_t)WC * 4 + 256 * 4 * 2 +
+           (size_t)(THREADS * ITEMS / 64) * (8 * 3 + 4 * 2) + 8 * 4 + 24 * 4;
+}
+
+template <int THREADS, int ITEMS>
 __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc d,
                                                  u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                  const Emit& em, u32* __restrict__ counters)
 {
+    // Output room (tiny pool, segment array, descriptor lists) is reserved from the global counters in CHUNKS
+    // kept in LDS (ach[]): one returning global atomic per chunk instead of per segment - on text-like input
+    // millions of segments emit tie runs every round and the shared counters were the bottleneck.
+    // Unused chunk tails are overwritten with neutral entries (len 0) that every consumer skips.
     constexpr int CAP = THREADS * ITEMS;
     constexpr int W = THREADS / 64;
     constexpr int NW = CAP / 64;                    // bitmap words
@@ -639,8 +665,10 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     u32* pre_tiny = reinterpret_cast<u32*>(bm_seg + NW);        // NW
     u32* pre_seg = pre_tiny + NW;                               // NW
     u32* misc = pre_seg + NW;                                   // 8
+    u32* ach = misc + 8;                                        // 10 chunk words + 14 pending fills (see k_sort_mid)
 
     const u32 len = d.len;
+    if (len == 0) return;                           // neutral list entry (unused chunk tail)
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const u32 wbase = wv * 64u * ITEMS;
     const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
@@ -736,7 +764,45 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
             any_eq |= (bal != 0);
         }
     __syncthreads();
-    // ex <- idx is not needed: idx stays in registers.  Write rows + ranks.
+    // Run boundaries without per-element walks: the first wave scans the bitmap words once -
+    // pre_tiny[w] = 1 + last position with a 0 bit in words < w (start of a run that enters word w from the left),
+    // pre_seg[w]  = first position with a 0 bit in words > w (end of a run that leaves word w to the right).
+    // (pre_tiny/pre_seg are reused for the compaction prefix sums further down.)
+    if (t < 64) {
+        constexpr int PER = (NW + 63) / 64;
+        u32 vs[PER], ve[PER];
+        u32 mx = 0, mn = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int w = (int)t * PER + k;
+            const u64 z = w < NW ? ~bm_eq[w] : ~0ull;
+            vs[k] = z ? (u32)((w << 6) + 64 - __clzll((long long)z)) : 0u;
+            ve[k] = z ? (u32)((w << 6) + __ffsll((long long)z) - 1) : 0xffffffffu;
+            mx = vs[k] > mx ? vs[k] : mx;
+            mn = ve[k] < mn ? ve[k] : mn;
+        }
+        u32 pmx = mx, smn = mn;          // inclusive scans over lanes: prefix max, suffix min
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const u32 a = __shfl_up(pmx, dlt, 64); if ((int)lane >= dlt) pmx = a > pmx ? a : pmx;
+            const u32 c = __shfl_down(smn, dlt, 64); if ((int)lane + dlt < 64) smn = c < smn ? c : smn;
+        }
+        u32 run_s = __shfl_up(pmx, 1, 64); if (lane == 0) run_s = 0;                 // exclusive prefix max
+        u32 run_e = __shfl_down(smn, 1, 64); if (lane == 63) run_e = 0xffffffffu;    // exclusive suffix min
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int w = (int)t * PER + k;
+            if (w < NW) pre_tiny[w] = run_s;
+            run_s = vs[k] > run_s ? vs[k] : run_s;
+        }
+#pragma unroll
+        for (int k = PER - 1; k >= 0; --k) {
+            const int w = (int)t * PER + k;
+            if (w < NW) pre_seg[w] = run_e;
+            run_e = ve[k] < run_e ? ve[k] : run_e;
+        }
+    }
+    __syncthreads();
     const u32 rank0 = counters[C_RANK0];
     u32 rs[ITEMS], rl[ITEMS];        // run start / run length of each of my elements
 #pragma unroll
@@ -745,22 +811,12 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
             const u32 p = wbase + j * 64 + lane;
             rs[j] = p; rl[j] = 1;
             if (p < len) {
-                const bool eqn = (bm_eq[p >> 6] >> (p & 63)) & 1ull;
-                const bool eqp = p > 0 && ((bm_eq[(p - 1) >> 6] >> ((p - 1) & 63)) & 1ull);
-                u32 s = p, e = p;
-                if (eqp) {
-                    const u32 q = p - 1;
-                    int w = (int)(q >> 6);
-                    u64 inv = ~bm_eq[w] & (~0ull >> (63 - (q & 63)));
-                    while (inv == 0 && w > 0) { --w; inv = ~bm_eq[w]; }
-                    s = inv ? (u32)((w << 6) + 63 - __clzll((long long)inv)) + 1u : 0u;
-                }
-                if (eqn) {
-                    int w = (int)(p >> 6);
-                    u64 inv = ~bm_eq[w] & (~0ull << (p & 63));
-                    while (inv == 0) { ++w; inv = ~bm_eq[w]; }
-                    e = (u32)((w << 6) + __ffsll((long long)inv) - 1);
-                }
+                const u32 w = p >> 6, bit = p & 63u;
+                const u64 z = ~bm_eq[w];
+                const u64 below = bit ? (z & (~0ull >> (64 - bit))) : 0ull;      // 0 bits strictly below me
+                const u64 above = z & (~0ull << bit);                              // 0 bits at or above me
+                const u32 s = below ? (u32)((w << 6) + 64 - __clzll((long long)below)) : pre_tiny[w];
+                const u32 e = above ? (u32)((w << 6) + __ffsll((long long)above) - 1) : pre_seg[w];
                 rs[j] = s; rl[j] = e - s + 1;
                 sa_out[d.sa_off + p] = idx[j];
                 if (mode == MODE_ISA) isa[idx[j]] = rank0 + d.sa_off + s + 1u;
@@ -800,14 +856,57 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
             et += lt_[k]; es += ls_[k];
         }
         if (t == 0) {
-            u32 bt = 0, bs = 0;
-            if (tt) { bt = atomicAdd(&counters[em.pool_cnt_idx], tt); if ((u64)bt + tt > em.pool_cap) { atomicOr(&counters[C_ERR], 32u); tt = 0xffffffffu; } }
-            if (ts) { bs = atomicAdd(&counters[em.seg_cnt_idx], ts); if ((u64)bs + ts > em.seg_cap) { atomicOr(&counters[C_ERR], 64u); ts = 0xffffffffu; } }
-            misc[1] = bt; misc[2] = bs; misc[3] = (tt == 0xffffffffu || ts == 0xffffffffu) ? 1u : 0u;
+            u32 bt = 0, bs = 0, bad = 0;
+            u32* pf = ach + 10;                       // pending fills: (begin, end) x {pool, seg, desc A, desc B, desc C}
+#pragma unroll
+            for (int k = 0; k < 10; ++k) pf[k] = 0;
+            if (tt) {
+                if (ach[0] + tt > ach[1]) {
+                    pf[0] = ach[0]; pf[1] = ach[1];
+                    const u32 sz = tt > em.pool_chunk ? tt : em.pool_chunk;
+                    const u32 b = atomicAdd(&counters[em.pool_cnt_idx], sz);
+                    if ((u64)b + sz > em.pool_cap) { atomicOr(&counters[C_ERR], 32u); bad = 1; }
+                    ach[0] = b; ach[1] = b + sz;
+                }
+                bt = ach[0]; ach[0] += tt;
+            }
+            if (ts) {
+                if (ach[2] + ts > ach[3]) {
+                    pf[2] = ach[2]; pf[3] = ach[3];
+                    const u32 sz = ts > em.seg_chunk ? ts : em.seg_chunk;
+                    const u32 b = atomicAdd(&counters[em.seg_cnt_idx], sz);
+                    if ((u64)b + sz > em.seg_cap) { atomicOr(&counters[C_ERR], 64u); bad = 1; }
+                    ach[2] = b; ach[3] = b + sz;
+                }
+                bs = ach[2]; ach[2] += ts;
+                // descriptor room for every run head this segment can produce (classes up to my own)
+                constexpr u32 MAXH = CAP / (TINY_MAX + 1) + 1;
+                constexpr u32 NCLS = CAP <= CAP_A ? 1 : (CAP <= CAP_B ? 2 : 3);
+#pragma unroll
+                for (u32 k = 0; k < NCLS; ++k) {
+                    if (ach[5 + 2 * k] - ach[4 + 2 * k] < MAXH) {
+                        pf[4 + 2 * k] = ach[4 + 2 * k]; pf[5 + 2 * k] = ach[5 + 2 * k];
+                        const u32 sz = MAXH + 32u;
+                        const u32 b = atomicAdd(&counters[em.lists.cnt_idx + k], sz);
+                        if ((u64)b + sz > em.lists.cap[k]) { atomicOr(&counters[C_ERR], 1u); bad = 1; }
+                        ach[4 + 2 * k] = b; ach[5 + 2 * k] = b + sz;
+                    }
+                }
+            }
+            misc[1] = bt; misc[2] = bs; misc[3] = bad;
         }
     }
     __syncthreads();
     if (misc[3]) return;
+    // neutral-fill the chunk tails that were just abandoned
+    {
+        const u32* pf = ach + 10;
+        for (u32 i = pf[0] + t; i < pf[1]; i += THREADS) { em.pool_rec[i] = 0; em.pool_hdr[i] = 0; }
+        for (u32 i = pf[2] + t; i < pf[3]; i += THREADS) em.seg_rec[i] = 0;
+#pragma unroll
+        for (u32 k = 0; k < 3; ++k)
+            for (u32 i = pf[4 + 2 * k] + t; i < pf[5 + 2 * k]; i += THREADS) { const Desc z = {0, 0, 0, 0}; em.lists.cls[k][i] = z; }
+    }
     const u32 base_t = misc[1], base_s = misc[2];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
@@ -824,7 +923,8 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                     em.seg_rec[o] = (u64)idx[j];
                     if (p == rs[j]) {
                         const Desc nd = {o, rl[j], d.sa_off + rs[j], em.seg_buf};
-                        push_desc(em.lists, counters, class_of(rl[j]), nd);
+                        const u32 cls = class_of(rl[j]);
+                        em.lists.cls[cls][atomicAdd(&ach[4 + 2 * cls], 1u)] = nd;      // room was reserved above
                     }
                 }
             }
@@ -896,7 +996,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
         if (wbase < len) { const u32 rem = len - wbase; rows = (int)((rem + 63u) / 64u); if (rows > ITEMS) rows = ITEMS; }
         const u32 kmask = kbits >= 32 ? 0xffffffffu : ((1u << kbits) - 1u);
         const u32 sh = kbits > (u32)BITS ? kbits - BITS : 0u;
-        bool ok = kbits <= 26u;                                  // block-uniform
+        bool ok = kbits <= 26u && len != 0;                      // block-uniform (len 0 = neutral list entry)
 
         if (ok) {
             if (t < 16) misc[t] = 0;
@@ -1031,7 +1131,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
                 }
             }
         }
-        if (!ok && t == 0) fb_list[atomicAdd(&counters[fb_cnt_idx], 1u)] = cur;   // leave it to k_sort_mid
+        if (!ok && len != 0 && t == 0) fb_list[atomicAdd(&counters[fb_cnt_idx], 1u)] = cur;   // leave it to k_sort_mid
         if (!more) break;
         __syncthreads();            // everyone is done with misc[]/hist[]/ex[] of this segment before they are reset
         if (!fetched) {
@@ -1056,22 +1156,23 @@ __global__ __launch_bounds__(THREADS) void k_sort_mid(RecBufs bufs, const Desc* 
                                                       Emit em, u32* __restrict__ counters, const u32* __restrict__ ids, u32 ids_cnt_idx)
 {
     // ids != nullptr: only the segments k_sort_fast left behind (their count lives in the counters block)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_k[];
+    u32* ach = reinterpret_cast<u32*>(smem_k + sort_mid_lds_bytes<THREADS, ITEMS>()) - 24;
+    if (threadIdx.x < 24) ach[threadIdx.x] = 0;
+    __syncthreads();
     const u32 total = ids ? counters[ids_cnt_idx] : nseg;
     for (u32 i = blockIdx.x; i < total; i += gridDim.x) {
         sort_mid_segment<THREADS, ITEMS>(bufs, list[ids ? ids[i] : i], sa_out, isa, mode, em, counters);
         __syncthreads();
     }
+    // give back what is left of my chunks as neutral entries
+    for (u32 i = ach[0] + threadIdx.x; i < ach[1]; i += THREADS) { em.pool_rec[i] = 0; em.pool_hdr[i] = 0; }
+    for (u32 i = ach[2] + threadIdx.x; i < ach[3]; i += THREADS) em.seg_rec[i] = 0;
+#pragma unroll
+    for (u32 k = 0; k < 3; ++k)
+        for (u32 i = ach[4 + 2 * k] + threadIdx.x; i < ach[5 + 2 * k]; i += THREADS) { const Desc z = {0, 0, 0, 0}; em.lists.cls[k][i] = z; }
 }
 
-template <int THREADS, int ITEMS>
-constexpr size_t sort_mid_lds_bytes()
-{
-    constexpr int CAP = THREADS * ITEMS;
-    constexpr int NBIN = 1 << (CAP >= 16384 ? 12 : (CAP >= 4096 ? 10 : 7));
-    constexpr int WC = ((THREADS / 64) * 256 > NBIN ? (THREADS / 64) * 256 : NBIN) + 8;
-    return (size_t)(THREADS * ITEMS) * 4 + (size_t)WC * 4 + 256 * 4 * 2 +
-           (size_t)(THREADS * ITEMS / 64) * (8 * 3 + 4 * 2) + 8 * 4;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Tiny runs (2..32 records), millions of them on text/DNA inputs: flat pool, one lane per record,
@@ -1081,65 +1182,76 @@ constexpr size_t sort_mid_lds_bytes()
 __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_rec, const u64* __restrict__ pool_hdr,
                                                    u32 cnt_idx, u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                    u64* __restrict__ next_rec, u64* __restrict__ next_hdr, u32 next_cnt_idx, u32 next_cap,
-                                                   u32* __restrict__ counters)
+                                                   u32 chunk, u32* __restrict__ counters)
 {
     constexpr int WIN = 256, HALO = 32, TOT = WIN + HALO;
     __shared__ u32 lkey[TOT], lrun[TOT];
-    __shared__ u32 s_total, s_base;
+    __shared__ u32 s_total, s_base, s_cb, s_ce, s_fb, s_fe;      // window total / base; chunk [cb, ce); pending fill [fb, fe)
     const u32 count = counters[cnt_idx];
-    const u64 b0 = (u64)blockIdx.x * WIN;
-    if (b0 >= count) return;
     const u32 t = threadIdx.x;
-    if (t == 0) s_total = 0;
-    u64 rec[2] = {0, 0}, hdr[2] = {0, 0};
-    bool have[2] = {false, false};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const u32 e = t + k * WIN;
-        if (e < TOT && b0 + e < count) { rec[k] = pool_rec[b0 + e]; hdr[k] = pool_hdr[b0 + e]; have[k] = true; lkey[e] = (u32)(rec[k] >> 32); }
-    }
-    __syncthreads();
     const u32 rank0 = counters[C_RANK0];
-    u32 n_lt[2], n_eq[2], n_eqb[2], lead[2];
-    bool owned[2] = {false, false};
+    if (t == 0) { s_cb = 0; s_ce = 0; }
+    for (u64 b0 = (u64)blockIdx.x * WIN; b0 < count; b0 += (u64)gridDim.x * WIN) {
+        __syncthreads();
+        if (t == 0) { s_total = 0; s_fb = 0; s_fe = 0; }
+        u64 rec[2] = {0, 0}, hdr[2] = {0, 0};
+        bool have[2] = {false, false};
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const u32 e = t + k * WIN;
-        n_lt[k] = n_eq[k] = n_eqb[k] = 0; lead[k] = 0;
-        if (have[k]) {
-            const u32 sa_start = (u32)hdr[k], len = (u32)(hdr[k] >> 32) & 255u, off = (u32)(hdr[k] >> 40) & 255u;
-            if (e >= off && e - off < WIN) {
-                owned[k] = true;
-                const u32 ls = e - off, my = lkey[e];
-                bool found = false;
-                for (u32 q = 0; q < len; ++q) {
-                    const u32 kk = lkey[ls + q];
-                    n_lt[k] += kk < my;
-                    if (kk == my) { if (!found) { found = true; lead[k] = ls + q; } n_eq[k]++; n_eqb[k] += q < off; }
+        for (int k = 0; k < 2; ++k) {
+            const u32 e = t + k * WIN;
+            if (e < TOT && b0 + e < count) { rec[k] = pool_rec[b0 + e]; hdr[k] = pool_hdr[b0 + e]; have[k] = true; lkey[e] = (u32)(rec[k] >> 32); }
+        }
+        __syncthreads();
+        u32 n_lt[2], n_eq[2], n_eqb[2], lead[2];
+        bool owned[2] = {false, false};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const u32 e = t + k * WIN;
+            n_lt[k] = n_eq[k] = n_eqb[k] = 0; lead[k] = 0;
+            if (have[k]) {
+                const u32 sa_start = (u32)hdr[k], len = (u32)(hdr[k] >> 32) & 255u, off = (u32)(hdr[k] >> 40) & 255u;
+                if (len != 0 && e >= off && e - off < WIN) {      // len 0 = neutral entry (unused chunk tail)
+                    owned[k] = true;
+                    const u32 ls = e - off, my = lkey[e];
+                    bool found = false;
+                    for (u32 q = 0; q < len; ++q) {
+                        const u32 kk = lkey[ls + q];
+                        n_lt[k] += kk < my;
+                        if (kk == my) { if (!found) { found = true; lead[k] = ls + q; } n_eq[k]++; n_eqb[k] += q < off; }
+                    }
+                    const u32 row = sa_start + n_lt[k] + n_eqb[k];
+                    sa_out[row] = (u32)rec[k];
+                    if (mode == MODE_ISA) isa[(u32)rec[k]] = rank0 + sa_start + n_lt[k] + 1u;
+                    if (n_eq[k] > 1 && n_eqb[k] == 0) lrun[e] = atomicAdd(&s_total, n_eq[k]);
                 }
-                const u32 row = sa_start + n_lt[k] + n_eqb[k];
-                sa_out[row] = (u32)rec[k];
-                if (mode == MODE_ISA) isa[(u32)rec[k]] = rank0 + sa_start + n_lt[k] + 1u;
-                if (n_eq[k] > 1 && n_eqb[k] == 0) lrun[e] = atomicAdd(&s_total, n_eq[k]);
             }
         }
-    }
-    __syncthreads();
-    if (t == 0 && s_total) {
-        const u32 b = atomicAdd(&counters[next_cnt_idx], s_total);
-        s_base = b;
-        if ((u64)b + s_total > next_cap) { atomicOr(&counters[C_ERR], 128u); s_base = 0xffffffffu; }
-    }
-    __syncthreads();
-    if (s_total == 0 || s_base == 0xffffffffu) return;
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        if (owned[k] && n_eq[k] > 1) {
-            const u32 sa_start = (u32)hdr[k];
-            const u32 o = s_base + lrun[lead[k]] + n_eqb[k];
-            next_rec[o] = (u64)(u32)rec[k];
-            next_hdr[o] = pack_hdr(sa_start + n_lt[k], n_eq[k], n_eqb[k]);
+        __syncthreads();
+        if (t == 0 && s_total) {
+            const u32 need = s_total;
+            if (s_cb + need > s_ce) {
+                s_fb = s_cb; s_fe = s_ce;
+                const u32 sz = need > chunk ? need : chunk;
+                const u32 b = atomicAdd(&counters[next_cnt_idx], sz);
+                if ((u64)b + sz > next_cap) { atomicOr(&counters[C_ERR], 128u); s_cb = 0; s_ce = 0; s_base = 0xffffffffu; }
+                else { s_cb = b; s_ce = b + sz; }
+            }
+            if (s_cb + need <= s_ce) { s_base = s_cb; s_cb += need; }
         }
+        __syncthreads();
+        for (u32 i = s_fb + t; i < s_fe; i += 256u) { next_rec[i] = 0; next_hdr[i] = 0; }
+        if (s_total == 0 || s_base == 0xffffffffu) continue;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (owned[k] && n_eq[k] > 1) {
+                const u32 sa_start = (u32)hdr[k];
+                const u32 o = s_base + lrun[lead[k]] + n_eqb[k];
+                next_rec[o] = (u64)(u32)rec[k];
+                next_hdr[o] = pack_hdr(sa_start + n_lt[k], n_eq[k], n_eqb[k]);
+            }
+    }
+    __syncthreads();
+    for (u32 i = s_cb + t; i < s_ce; i += 256u) { next_rec[i] = 0; next_hdr[i] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1161,7 +1273,7 @@ __global__ __launch_bounds__(256) void k_isa_pool(const u64* __restrict__ pool_r
 {
     const u32 count = counters[cnt_idx], rank0 = counters[C_RANK0];
     for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < count; i += (u64)gridDim.x * 256u)
-        isa[(u32)pool_rec[i]] = rank0 + (u32)pool_hdr[i] + 1u;
+        if ((pool_hdr[i] >> 32) & 255u) isa[(u32)pool_rec[i]] = rank0 + (u32)pool_hdr[i] + 1u;      // len 0 = neutral entry
 }
 
 __global__ __launch_bounds__(256) void k_isa_segs(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
