@@ -33,21 +33,25 @@ namespace maniscalco
         using suffix_index = std::int32_t;
         using suffix_array = std::vector<suffix_index>;
 
+        // The reference constructor spawns its worker pool (msufsort.h:315-341); this one owns a GPU context
+        // (stream + workspace), created on first use and reused by every call on the instance.
         msufsort(std::int32_t numThreads = 1) : numThreads_(numThreads) {}
-        ~msufsort() = default;
+        ~msufsort() { if (ctx_) ::msufsort_hip_ctx_destroy(ctx_); }
+        msufsort(msufsort const &) = delete;
+        msufsort & operator = (msufsort const &) = delete;
 
         suffix_array make_suffix_array(std::uint8_t const * inputBegin, std::uint8_t const * inputEnd)
         {
             auto n = static_cast<std::int64_t>(inputEnd - inputBegin);
             suffix_array sa(static_cast<std::size_t>(n) + 1);
-            check(::msufsort_hip_make_sa_i32(inputBegin, n, sa.data(), nullptr), "make_suffix_array");
+            check(::msufsort_hip_make_sa_i32_ctx(ctx(), inputBegin, n, sa.data(), nullptr), "make_suffix_array");
             return sa;
         }
 
         std::int32_t forward_burrows_wheeler_transform(std::uint8_t * inputBegin, std::uint8_t * inputEnd)
         {
             std::int64_t sentinel = 0;
-            check(::msufsort_hip_forward_bwt(inputBegin, static_cast<std::int64_t>(inputEnd - inputBegin), &sentinel, nullptr),
+            check(::msufsort_hip_forward_bwt_ctx(ctx(), inputBegin, static_cast<std::int64_t>(inputEnd - inputBegin), &sentinel, nullptr),
                   "forward_burrows_wheeler_transform");
             return static_cast<std::int32_t>(sentinel);
         }
@@ -59,6 +63,16 @@ namespace maniscalco
                   "reverse_burrows_wheeler_transform");
         }
 
+        // Extension (the reference keeps its LCP in the demo executable, main.cpp:143-159):
+        // out[i] = lcp(suffix SA[i+1], suffix SA[i+2]) for i in [0, n-2], out[n-1] = 0.
+        std::vector<std::int32_t> make_lcp_array(std::uint8_t const * inputBegin, std::uint8_t const * inputEnd, suffix_array const & sa)
+        {
+            auto n = static_cast<std::int64_t>(inputEnd - inputBegin);
+            std::vector<std::int32_t> lcp(static_cast<std::size_t>(n));
+            check(::msufsort_hip_lcp_i32_ctx(ctx(), inputBegin, n, sa.data(), lcp.data()), "make_lcp_array");
+            return lcp;
+        }
+
     private:
 
         static void check(int status, char const * what)
@@ -68,7 +82,14 @@ namespace maniscalco
                                          ::msufsort_hip_strerror(status) + " - " + ::msufsort_hip_last_error());
         }
 
+        ::msufsort_hip_ctx * ctx()
+        {
+            if (!ctx_) check(::msufsort_hip_ctx_create(&ctx_, 0, 0), "context");
+            return ctx_;
+        }
+
         std::int32_t numThreads_;
+        ::msufsort_hip_ctx * ctx_ = nullptr;
     };
 
 

@@ -86,6 +86,17 @@ int msufsort_hip_last_timings(msufsort_hip_ctx* ctx, msufsort_hip_timings* out);
  *      first_stage_its cpp:1559-1726 + second_stage_its cpp:1021-1057) ---- */
 int msufsort_hip_make_sa_i32(const uint8_t* text, int64_t n, int32_t* sa_out /* n+1 */,
                              const msufsort_hip_opts* opts);
+/* Host-pointer variants that reuse a context (stream + workspace) instead of building a temporary one -
+ * what a long-lived maniscalco::msufsort instance uses (the reference keeps its worker pool per instance,
+ * msufsort.h:311-388). */
+int msufsort_hip_make_sa_i32_ctx(msufsort_hip_ctx* ctx, const uint8_t* text, int64_t n, int32_t* sa_out,
+                                 const msufsort_hip_opts* opts);
+int msufsort_hip_forward_bwt_ctx(msufsort_hip_ctx* ctx, uint8_t* inout, int64_t n, int64_t* sentinel_row,
+                                 const msufsort_hip_opts* opts);
+int msufsort_hip_inverse_bwt_ctx(msufsort_hip_ctx* ctx, uint8_t* inout, int64_t n, int64_t sentinel_row,
+                                 const msufsort_hip_opts* opts);
+int msufsort_hip_lcp_i32_ctx(msufsort_hip_ctx* ctx, const uint8_t* text, int64_t n, const int32_t* sa,
+                             int32_t* lcp_out);
 /* d_text must have at least n + MSUFSORT_HIP_TEXT_PAD readable bytes; the pad is zeroed by the call. */
 #define MSUFSORT_HIP_TEXT_PAD 64
 int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,

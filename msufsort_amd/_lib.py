@@ -36,6 +36,7 @@ SYMBOLS = [
     "msufsort_hip_forward_bwt_dev", "msufsort_hip_bwt_from_sa_dev", "msufsort_hip_inverse_bwt",
     "msufsort_hip_inverse_bwt_dev", "msufsort_hip_lcp_i32", "msufsort_hip_lcp_i32_dev",
     "msufsort_hip_validate_sa_dev", "msufsort_hip_debug_hist16_dev",
+    "msufsort_hip_make_sa_i32_ctx", "msufsort_hip_forward_bwt_ctx", "msufsort_hip_inverse_bwt_ctx", "msufsort_hip_lcp_i32_ctx",
 ]
 
 _lib = None
@@ -88,6 +89,10 @@ def lib():
     L.msufsort_hip_lcp_i32_dev.argtypes = [vp, vp, i64, vp, vp]
     L.msufsort_hip_validate_sa_dev.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
     L.msufsort_hip_debug_hist16_dev.argtypes = [vp, vp, i64, vp]
+    L.msufsort_hip_make_sa_i32_ctx.argtypes = [vp, vp, i64, vp, C.POINTER(Opts)]
+    L.msufsort_hip_forward_bwt_ctx.argtypes = [vp, vp, i64, C.POINTER(i64), C.POINTER(Opts)]
+    L.msufsort_hip_inverse_bwt_ctx.argtypes = [vp, vp, i64, i64, C.POINTER(Opts)]
+    L.msufsort_hip_lcp_i32_ctx.argtypes = [vp, vp, i64, vp, vp]
     _lib = L
     return L
 

@@ -658,14 +658,12 @@ int msufsort_hip_make_sa_shard_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t
     return build_sa(c, d_text, (u64)n, reinterpret_cast<u32*>(d_slice_out), lo, z, cuts[g], cuts[g + 1], g == 0, opts, hist_done);
 }
 
-int msufsort_hip_make_sa_i32(const uint8_t* text, int64_t n, int32_t* sa_out, const msufsort_hip_opts* opts)
+int msufsort_hip_make_sa_i32_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64_t n, int32_t* sa_out, const msufsort_hip_opts* opts)
 {
-    if (!sa_out || (n > 0 && !text)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    if (!c || !sa_out || (n > 0 && !text)) return MSUFSORT_HIP_ERR_BAD_ARG;
     TRY(check_n(n));
     if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
-    TmpCtx t;
-    TRY(msufsort_hip_ctx_create(&t.c, opts ? opts->device : 0, 0));
-    msufsort_hip_ctx* c = t.c;
+    HIP_TRY(hipSetDevice(c->device));
     TRY(c->text_own.ensure((size_t)n + MSUFSORT_HIP_TEXT_PAD));
     TRY(c->sa_own.ensure(((size_t)n + 1) * 4));
     HIP_TRY(hipMemcpyAsync(c->text_own.p, text, (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -673,6 +671,16 @@ int msufsort_hip_make_sa_i32(const uint8_t* text, int64_t n, int32_t* sa_out, co
     HIP_TRY(hipMemcpyAsync(sa_out, c->sa_own.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_make_sa_i32(const uint8_t* text, int64_t n, int32_t* sa_out, const msufsort_hip_opts* opts)
+{
+    if (!sa_out || (n > 0 && !text)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n(n));
+    if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
+    TmpCtx t;
+    TRY(msufsort_hip_ctx_create(&t.c, opts ? opts->device : 0, 0));
+    return msufsort_hip_make_sa_i32_ctx(t.c, text, n, sa_out, opts);
 }
 
 // Host-only: split the 16-bit key space into n_shards count-balanced contiguous ranges.

@@ -32,3 +32,21 @@ def test_cpp_dropin_header_builds_and_runs(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "SA[0] = 11, SA[1] = 10" in r.stdout and "sentinel row = 5, round trip ok" in r.stdout
+
+
+def test_demo_cli_modes(tmp_path):
+    """CLI parity with the reference demo (reference main.cpp:290-502): modes s, l, b on a file, t self test."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from msufsort_amd import gen
+    exe = str(tmp_path / "msufsort_demo")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "msufsort_demo.cpp"),
+                    "-L" + os.path.join(ROOT, "msufsort_amd", "lib"), "-lmsufsort_hip",
+                    "-Wl,-rpath," + os.path.join(ROOT, "msufsort_amd", "lib"), "-o", exe], check=True)
+    f = tmp_path / "in.bin"
+    gen.text_bytes(200000, 17).tofile(f)
+    for mode, must in (("s", "suffix array validated"), ("l", "lcp array validated"), ("b", "BWT validated")):
+        r = subprocess.run([exe, mode, str(f), "4"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and must in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe, "t"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 errors" in r.stdout, r.stdout + r.stderr
