@@ -973,7 +973,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
     u32* misc = tot + 16;                                       // 16
 
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
-    const u32 wbase = wv * 64u * ITEMS;
+    // rows of 64 consecutive records are dealt round-robin to the waves (row = j * W + wave): every wave
+    // gets the same number of rows whatever the segment length, and global accesses stay coalesced per row
+#define FAST_P(j) ((((u32)(j) * W + wv) << 6) + lane)
     u32 seg = blockIdx.x;
     if (seg >= nseg) return;
     Desc d = list[seg];
@@ -981,32 +983,36 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
     {
         const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; nrec[j] = p < d.len ? src[p] : ~0ull; }
+        for (int j = 0; j < ITEMS; ++j) { const u32 p = FAST_P(j); nrec[j] = p < d.len ? src[p] : ~0ull; }
     }
     const u32 rank0 = counters[C_RANK0];
     for (;;) {
         const u32 len = d.len, sa_off = d.sa_off, cur = seg, kbits = (d.buf >> 8) & 255u;
-        u32 key[ITEMS], idx[ITEMS];       // key[] turns into the composite after the scan
+        u32 key[ITEMS], idx[ITEMS];       // key[] turns into the composite after the atomics
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) { key[j] = (u32)(nrec[j] >> 32); idx[j] = (u32)nrec[j]; }
         seg += gridDim.x;
         const bool more = seg < nseg;
         bool fetched = false;
-        int rows = 0;
-        if (wbase < len) { const u32 rem = len - wbase; rows = (int)((rem + 63u) / 64u); if (rows > ITEMS) rows = ITEMS; }
+        const u32 nrows = (len + 63u) >> 6;
+        const int rows = nrows > wv ? (int)((nrows - wv + W - 1) / W) : 0;      // <= ITEMS because len <= CAP
         const u32 kmask = kbits >= 32 ? 0xffffffffu : ((1u << kbits) - 1u);
         const u32 sh = kbits > (u32)BITS ? kbits - BITS : 0u;
         bool ok = kbits <= 26u && len != 0;                      // block-uniform (len 0 = neutral list entry)
 
         if (ok) {
             if (t < 16) misc[t] = 0;
-            for (u32 i = t; i < (u32)NBIN + 16u; i += THREADS) hist[i] = 0;
+            {
+                uint4* h4 = reinterpret_cast<uint4*>(hist);
+                const uint4 z4 = {0u, 0u, 0u, 0u};
+                for (u32 i = t; i < ((u32)NBIN + 16u) / 4u; i += THREADS) h4[i] = z4;
+            }
             if (t < 64) ex[len + t] = 0xffffffffu;               // inert tail for the probes (len + 63 < CAP + 64)
             __syncthreads();                                                        // (1)
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j)
                 if (j < rows) {
-                    const u32 p = wbase + j * 64 + lane;
+                    const u32 p = FAST_P(j);
                     const u32 k = key[j] & kmask;
                     const u32 r = atomicAdd(&hist[p < len ? (k >> sh) : TRASH_BIN], 1u);
                     key[j] = p < len ? ((k << 6) | (r & 63u)) : 0xffffffffu;      // composite (r < 64 is checked below)
@@ -1035,50 +1041,63 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
             ok = misc[1] <= FAST_LIMIT;
         }
         if (ok) {
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-                if (j < rows) {
-                    const u32 p = wbase + j * 64 + lane;
-                    const u32 c = key[j];
-                    ex[p < len ? hist[c >> (6 + sh)] + (c & 63u) : TRASH_POS] = c;
-                }
-            __syncthreads();                                                        // (5)
-            // pos[] = final row; info[] = run start (16 bits) | run length << 16 | my offset << 24
-            u32 pos[ITEMS], info[ITEMS];
-            bool tie = false;
+            // bc[] = sub-bucket base | sub-bucket size << 16 : fetched once, all rows in flight, used twice
+            u32 bc[ITEMS];
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
-                info[j] = 1u << 16;
+                bc[j] = 0;
+                if (j < rows) {
+                    const u32 c = key[j];
+                    const bool v = c != 0xffffffffu;
+                    const u32 dg = v ? (c >> (6 + sh)) : 0u;
+                    const u32 b0 = hist[dg], b1 = hist[dg + 1];
+                    bc[j] = b0 | ((b1 - b0) << 16);
+                    ex[v ? b0 + (c & 63u) : TRASH_POS] = c;
+                }
+            }
+            __syncthreads();                                                        // (5)
+            // pos[] = final row (bit 31: needs the slow path); straight-line probes, no branches
+            u32 pos[ITEMS];
+            bool anyslow = false;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
                 pos[j] = TRASH_POS;
                 if (j < rows) {
-                    const u32 p = wbase + j * 64 + lane;
-                    const bool v = p < len;
-                    const u32 me = key[j];
-                    const u32 dg = v ? (me >> (6 + sh)) : 0u;
-                    const u32 b0 = hist[dg];
+                    const u32 me = key[j], b0 = bc[j] & 0xffffu;
                     u32 lt = 0, eq = 0;
 #pragma unroll
                     for (int q = 0; q < FAST_PROBE; ++q) { const u32 c = ex[b0 + q]; lt += c < me; eq += (c ^ me) < 64u; }
-                    const u32 b1 = hist[dg + 1];
-                    if (__ballot(v && b1 - b0 > FAST_PROBE)) {                      // rare: a long sub-bucket in this row
-#pragma nounroll
-                        for (u32 q = b0 + FAST_PROBE; q < b1; ++q) { const u32 c = ex[q]; lt += c < me; eq += (c ^ me) < 64u; }
-                    }
-                    if (__ballot(v && eq > 1)) {                                    // rare: equal keys in this row
-                        u32 ltk = 0;
-#pragma nounroll
-                        for (u32 q = b0; q < b1; ++q) ltk += (ex[q] >> 6) < (me >> 6);
-                        if (v && eq > 1) { info[j] = (b0 + ltk) | (eq << 16) | ((lt - ltk) << 24); tie = true; }
-                    }
-                    if (v) { pos[j] = b0 + lt; if (eq <= 1) info[j] = (b0 + lt) | (1u << 16); }
+                    const bool v = me != 0xffffffffu;
+                    const bool slow = v && ((bc[j] >> 16) > FAST_PROBE || eq > 1);
+                    anyslow |= slow;
+                    if (v) pos[j] = (b0 + lt) | (slow ? 0x80000000u : 0u);
                 }
             }
+            // info[] = run start (16 bits) | run length << 16 | my offset << 24 ; rare: long sub-bucket or equal keys
+            u32 info[ITEMS];
+            bool tie = false;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                info[j] = (pos[j] & 0xffffu) | (1u << 16);
+                if (j < rows && __ballot(pos[j] >> 31)) {
+                    if (pos[j] >> 31) {
+                        const u32 me = key[j], b0 = bc[j] & 0xffffu, b1 = b0 + (bc[j] >> 16);
+                        u32 lt = 0, eq = 0, ltk = 0;
+#pragma nounroll
+                        for (u32 q = b0; q < b1; ++q) { const u32 c = ex[q]; lt += c < me; eq += (c ^ me) < 64u; ltk += (c >> 6) < (me >> 6); }
+                        pos[j] = b0 + lt;
+                        info[j] = (b0 + ltk) | (eq << 16) | ((lt - ltk) << 24);
+                        tie |= eq > 1;
+                    }
+                }
+            }
+            (void)anyslow;
             // composites are dead from here on: prefetch the next segment of this workgroup
             if (PREFETCH && more) {
                 d = list[seg];
                 const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
 #pragma unroll
-                for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; nrec[j] = p < d.len ? src[p] : ~0ull; }
+                for (int j = 0; j < ITEMS; ++j) { const u32 p = FAST_P(j); nrec[j] = p < d.len ? src[p] : ~0ull; }
                 fetched = true;
             }
             __syncthreads();                                                        // (6)
@@ -1088,7 +1107,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j)
                 if (j < rows) {
-                    const u32 p = wbase + j * 64 + lane;
+                    const u32 p = FAST_P(j);
                     if (p < len) {
                         sa_out[sa_off + p] = ex[p];
                         if (mode == MODE_ISA) isa[idx[j]] = rank0 + sa_off + (info[j] & 0xffffu) + 1u;
@@ -1138,9 +1157,10 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
             d = list[seg];
             const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; nrec[j] = p < d.len ? src[p] : ~0ull; }
+            for (int j = 0; j < ITEMS; ++j) { const u32 p = FAST_P(j); nrec[j] = p < d.len ? src[p] : ~0ull; }
         }
     }
+#undef FAST_P
 }
 
 template <int THREADS, int ITEMS, int BITS>
