@@ -92,12 +92,13 @@ def main():
     ctx = M.DeviceContext(local, n)
 
     bounds = ctx.shard_bounds(d_text, n, world) if world > 1 else None
+    d_grp = torch.empty(n + 1, dtype=torch.int32, device=dev) if world > 1 else None
 
     def step():
         if world == 1:
             ctx.make_sa(d_text, n, d_sa)
         else:
-            mdist.build_sa_sharded(ctx, d_text, n, d_sa, rank, world, dist, bounds)
+            mdist.build_sa_sharded(ctx, d_text, n, d_sa, rank, world, dist, bounds, d_grp_full=d_grp)
 
     def barrier():
         if dist is not None:

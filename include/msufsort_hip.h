@@ -108,6 +108,20 @@ int msufsort_hip_make_sa_shard_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64
                                    int32_t* d_slice_out, int64_t slice_capacity,
                                    int64_t* slice_lo, int64_t* slice_hi,
                                    const msufsort_hip_opts* opts);
+/* Same, for inputs whose ties may run deeper than the key-gather rounds allow (long repeats): also fills
+ * d_grp_slice_out[row - lo] = first row of the tie group of that row (the row itself when it is final).
+ * Returns 0 when the slice is completely sorted, 1 (MSUFSORT_HIP_UNRESOLVED_GROUPS) when groups remain;
+ * *depth_out = number of bytes the members of every remaining group share.  After the all-gatherv of the SA
+ * and group slices, every rank calls msufsort_hip_finish_sa_dev on the complete arrays if ANY rank returned 1. */
+#define MSUFSORT_HIP_UNRESOLVED_GROUPS 1
+int msufsort_hip_make_sa_shard_groups_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
+                                          int32_t* d_slice_out, int32_t* d_grp_slice_out, int64_t slice_capacity,
+                                          int64_t* slice_lo, int64_t* slice_hi, int64_t* depth_out,
+                                          const msufsort_hip_opts* opts);
+/* Finishes a gathered sharded build by prefix doubling (replaces the reference's tandem-repeat path,
+ * msufsort.cpp:316-484): d_sa_full / d_grp_full hold all n+1 rows; the result is the final suffix array. */
+int msufsort_hip_finish_sa_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n, int32_t* d_sa_full,
+                               int32_t* d_grp_full, int64_t depth, const msufsort_hip_opts* opts);
 /* Slice bounds only (all shards), without sorting: bounds[n_shards + 1], in SA rows. */
 int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
                                   int32_t n_shards, int64_t* bounds);

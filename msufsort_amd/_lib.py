@@ -32,7 +32,8 @@ SYMBOLS = [
     "msufsort_hip_device_count", "msufsort_hip_strerror", "msufsort_hip_last_error",
     "msufsort_hip_ctx_create", "msufsort_hip_ctx_destroy", "msufsort_hip_ctx_stream", "msufsort_hip_ctx_sync",
     "msufsort_hip_last_timings", "msufsort_hip_make_sa_i32", "msufsort_hip_make_sa_i32_dev",
-    "msufsort_hip_make_sa_shard_dev", "msufsort_hip_shard_bounds_dev", "msufsort_hip_plan_cuts", "msufsort_hip_forward_bwt",
+    "msufsort_hip_make_sa_shard_dev", "msufsort_hip_shard_bounds_dev", "msufsort_hip_plan_cuts",
+    "msufsort_hip_make_sa_shard_groups_dev", "msufsort_hip_finish_sa_dev", "msufsort_hip_forward_bwt",
     "msufsort_hip_forward_bwt_dev", "msufsort_hip_bwt_from_sa_dev", "msufsort_hip_inverse_bwt",
     "msufsort_hip_inverse_bwt_dev", "msufsort_hip_lcp_i32", "msufsort_hip_lcp_i32_dev",
     "msufsort_hip_validate_sa_dev", "msufsort_hip_debug_hist16_dev",
@@ -78,6 +79,8 @@ def lib():
     L.msufsort_hip_make_sa_i32.argtypes = [vp, i64, vp, C.POINTER(Opts)]
     L.msufsort_hip_make_sa_i32_dev.argtypes = [vp, vp, i64, vp, C.POINTER(Opts)]
     L.msufsort_hip_make_sa_shard_dev.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(Opts)]
+    L.msufsort_hip_make_sa_shard_groups_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(Opts)]
+    L.msufsort_hip_finish_sa_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.POINTER(Opts)]
     L.msufsort_hip_shard_bounds_dev.argtypes = [vp, vp, i64, i32, C.POINTER(i64)]
     L.msufsort_hip_plan_cuts.argtypes = [vp, i64, i64, i32, vp, vp]
     L.msufsort_hip_forward_bwt.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(Opts)]

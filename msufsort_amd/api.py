@@ -153,6 +153,20 @@ class DeviceContext:
                                                           C.byref(lo), C.byref(hi), C.byref(o)), "make_sa_shard")
         return int(lo.value), int(hi.value)
 
+    def make_sa_shard_groups(self, d_text, n: int, d_slice, d_grp_slice, capacity: int, shard: int, n_shards: int, *, verbose=0, text_rounds=0):
+        """Like make_sa_shard, plus the tie-group heads of the slice rows.  Returns (lo, hi, unresolved, depth)."""
+        o = _opts(self.device, verbose, text_rounds, shard, n_shards)
+        lo, hi, depth = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        r = self._L.msufsort_hip_make_sa_shard_groups_dev(self._h, self._ptr(d_text), n, self._ptr(d_slice), self._ptr(d_grp_slice), capacity,
+                                                          C.byref(lo), C.byref(hi), C.byref(depth), C.byref(o))
+        if r not in (0, 1):
+            _lib.check(r, "make_sa_shard_groups")
+        return int(lo.value), int(hi.value), r == 1, int(depth.value)
+
+    def finish_sa(self, d_text, n: int, d_sa_full, d_grp_full, depth: int, *, verbose=0):
+        o = _opts(self.device, verbose)
+        _lib.check(self._L.msufsort_hip_finish_sa_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa_full), self._ptr(d_grp_full), depth, C.byref(o)), "finish_sa")
+
     def bwt_from_sa(self, d_text, n: int, d_sa, d_bwt) -> int:
         s = C.c_int64(0)
         _lib.check(self._L.msufsort_hip_bwt_from_sa_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa), self._ptr(d_bwt), C.byref(s)), "bwt_from_sa")

@@ -272,8 +272,14 @@ int plan_shards(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64 z, u64 m, int 
 // The suffix-array build for one shard.  d_sa_local points at the row of the shard's first radix-sorted
 // suffix (global row 1 + z + bstart[klo]); `with_head` also writes SA[0] and the trailing-zero rows.
 // ------------------------------------------------------------------------------------------------
+// d_grp_rows (optional, same indexing as d_sa_rows): receives the tie-group head row of every slice row when a
+// sharded build stops with unresolved groups (return value MSUFSORT_HIP_UNRESOLVED).
+// resume_depth > 0: d_sa_rows / d_grp_rows hold the COMPLETE arrays of such builds; rebuild the state from them
+// and finish with prefix doubling from that depth.
+#define MSUFSORT_HIP_UNRESOLVED 1
 int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of this shard's slice */, u64 slice_row_lo,
-             u64 z, u32 klo, u32 khi, bool with_head, const msufsort_hip_opts* opts, bool hist_done)
+             u64 z, u32 klo, u32 khi, bool with_head, const msufsort_hip_opts* opts, bool hist_done,
+             u32* d_grp_rows = nullptr, u64 resume_depth = 0, u64 slice_rows = 0)
 {
     const int verbose = opts ? opts->verbose : 0;
     if (const char* e = getenv("MSUFSORT_HIP_SYNC_DEBUG")) g_sync_debug = atoi(e);
@@ -288,29 +294,36 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
     TRY(c->set_attrs());
     HIP_TRY(hipEventRecord(c->ev[0], st));
     if (with_head) hipLaunchKernelGGL(k_sa_head, dim3(cdiv(std::max<u64>(z, 1), 256)), dim3(256), 0, st, d_sa_rows, (u32)n, (u32)z);
-    if (m == 0) { HIP_TRY(hipEventRecord(c->ev[5], st)); HIP_TRY(hipStreamSynchronize(st)); return MSUFSORT_HIP_OK; }
+    if (m == 0) {
+        if (d_grp_rows && resume_depth == 0 && slice_rows) hipLaunchKernelGGL(k_grp_iota, dim3(cdiv(slice_rows, 256)), dim3(256), 0, st, d_grp_rows, slice_rows, (u32)slice_row_lo);
+        HIP_TRY(hipEventRecord(c->ev[5], st)); HIP_TRY(hipStreamSynchronize(st)); return MSUFSORT_HIP_OK;
+    }
     TRY(c->ensure_workspace(m));
     u32* counters = c->counters.as<u32>();
     HIP_TRY(hipMemsetAsync(counters, 0, C_NCOUNTERS * 4, st));
     RecBufs bufs{{c->rec[0].as<u64>(), c->rec[1].as<u64>(), c->rec[2].as<u64>()}};
 
-    // ---- round 0: 16-bit histogram, offsets, two 8-bit scatter levels ----
-    if (!hist_done) TRY(run_hist(c, d_text, m));
-    HIP_TRY(hipEventRecord(c->ev[1], st));
-    run_scan(c, klo, khi, z);
-    // rows of this shard's radix-sorted suffixes start at global row 1 + z + bstart[klo]
-    u64 rank0;
-    if (klo == 0) rank0 = z;
-    else { HIP_TRY(hipMemcpyAsync(c->h_bstart, c->bstart.p, 65537 * 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); rank0 = z + c->h_bstart[klo]; }
-    u32* sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
-    hipLaunchKernelGGL(k_scatter0, dim3(cdiv(cdiv(m, P1_TILE), 8 * (c->chunk_len / P1_TILE)) * 8 * (c->chunk_len / P1_TILE)), dim3(S0_THREADS), 0, st, d_text, (u32)m, klo, khi, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0]);
-    HIP_TRY(hipEventRecord(c->ev[2], st));
-    DBG("k_scatter0");
-    hipLaunchKernelGGL(k_partition, dim3(cdiv(cdiv(m, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
-                       c->tile_start.as<u32>(), 24u, c->cursor.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u);
-    HIP_TRY(hipEventRecord(c->ev[3], st));
-    DBG("k_partition L1");
+    const bool resume = resume_depth > 0;
+    u64 rank0 = z;
+    u32* sa_local = d_sa_rows + (1 + z - slice_row_lo);
+    if (!resume) {
+        // ---- round 0: 16-bit histogram, offsets, two 8-bit scatter levels ----
+        if (!hist_done) TRY(run_hist(c, d_text, m));
+        HIP_TRY(hipEventRecord(c->ev[1], st));
+        run_scan(c, klo, khi, z);
+        // rows of this shard's radix-sorted suffixes start at global row 1 + z + bstart[klo]
+        if (klo == 0) rank0 = z;
+        else { HIP_TRY(hipMemcpyAsync(c->h_bstart, c->bstart.p, 65537 * 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); rank0 = z + c->h_bstart[klo]; }
+        sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
+        hipLaunchKernelGGL(k_scatter0, dim3(cdiv(cdiv(m, P1_TILE), 8 * (c->chunk_len / P1_TILE)) * 8 * (c->chunk_len / P1_TILE)), dim3(S0_THREADS), 0, st, d_text, (u32)m, klo, khi, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0]);
+        HIP_TRY(hipEventRecord(c->ev[2], st));
+        DBG("k_scatter0");
+        hipLaunchKernelGGL(k_partition, dim3(cdiv(cdiv(m, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
+                           c->tile_start.as<u32>(), 24u, c->cursor.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u);
+        HIP_TRY(hipEventRecord(c->ev[3], st));
+        DBG("k_partition L1");
 
+    }
     int cur = 0;                 // slot of the current round's lists / pool
     u32 sb = 1, nb = 2;          // record buffer holding the current segments / receiving next round's
     u32 mode = MODE_TEXT;
@@ -323,18 +336,43 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
     };
     auto alts = [&](u32 s, u32 nx, u32 a[3]) { u32 third = 3 - s - nx; a[s] = third; a[third] = s; a[nx] = nx; };
 
-    // children of the 65,536 two-byte buckets
-    {
-        u32 a[3]; a[0] = 1; a[1] = 0; a[2] = 2;
-        hipLaunchKernelGGL(k_children, dim3(256), dim3(256), 0, st, bufs, c->seg0.as<Desc>(), 256u, c->child_start.as<u32>(), c->child_cnt.as<u32>(),
-                           (const u32*)nullptr, a[0], a[1], a[2], 24u, sa_local, (u32*)nullptr, (u32)MODE_TEXT,
-                           c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), (u32)std::min<u64>(c->cap_m, 0xffffffffu),
-                           make_lists(cur), c->lvl[0].as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters);
-    }
-    DBG("k_children L1");
-    TRY(c->read_counters());
-
     int round = 0;
+    if (!resume) {
+        // children of the 65,536 two-byte buckets
+        {
+            u32 a[3]; a[0] = 1; a[1] = 0; a[2] = 2;
+            hipLaunchKernelGGL(k_children, dim3(256), dim3(256), 0, st, bufs, c->seg0.as<Desc>(), 256u, c->child_start.as<u32>(), c->child_cnt.as<u32>(),
+                               (const u32*)nullptr, a[0], a[1], a[2], 24u, sa_local, (u32*)nullptr, (u32)MODE_TEXT,
+                               c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), (u32)std::min<u64>(c->cap_m, 0xffffffffu),
+                               make_lists(cur), c->lvl[0].as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters);
+        }
+        DBG("k_children L1");
+        TRY(c->read_counters());
+
+    } else {
+        // ---- resume: complete (SA, grp) arrays of a sharded build -> state of a round that is about to start ----
+        u32* grp_local = d_grp_rows + (1 + z);
+        const u32 hv[2] = {(u32)m, (u32)z};
+        HIP_TRY(hipMemcpyAsync(counters + C_MS, hv, 8, hipMemcpyHostToDevice, st));      // C_MS, C_RANK0
+        TRY(c->isa.ensure((size_t)(n + 1) * 4));
+        const u32 g = std::min<u32>(cdiv(m + z, 256), 65536u);
+        hipLaunchKernelGGL(k_isa_from_grp, dim3(g), dim3(256), 0, st, sa_local, grp_local, (u32)m, c->isa.as<u32>(), (u32)n, (u32)z);
+        cur = 0; sb = 2; nb = 0; mode = MODE_ISA; depth = resume_depth; round = 1;
+        hipLaunchKernelGGL(k_import_groups, dim3(cdiv(m, 256)), dim3(256), 0, st, sa_local, grp_local, (u32)m, (u32)(1 + z),
+                           bufs.p[sb], sb, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)C_POOL0, (u32)std::min<u64>(c->cap_m, 0xffffffffu),
+                           make_lists(cur), c->large_round[cur].as<Desc>(), c->large_cap, (u32)(C_LIST0 + 3), (u32)C_LTILES0, counters);
+        const u32 mm = (u32)m;
+        HIP_TRY(hipMemcpyAsync(counters + C_SEG0, &mm, 4, hipMemcpyHostToDevice, st));
+        DBG("import");
+        TRY(c->read_counters());
+        const u64 actP = c->h_counters[C_POOL0];
+        if (actP) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actP, 256), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, (u32)C_POOL0,
+                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode);
+        hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(m, 256), 65536u)), dim3(256), 0, st, bufs.p[sb], counters, (u32)C_SEG0,
+                           d_text, c->isa.as<u32>(), (u32)n, depth, mode);
+        depth *= 2; tm.doubling_rounds++; tm.rounds++;
+        HIP_TRY(hipEventRecord(c->ev[1], st)); HIP_TRY(hipEventRecord(c->ev[2], st)); HIP_TRY(hipEventRecord(c->ev[3], st)); HIP_TRY(hipEventRecord(c->ev[4], st));
+    }
     for (;; ++round) {
         const int nxt = cur ^ 1;
         u32 a[3];
@@ -451,7 +489,24 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters,
                            (1u << oP) | (1u << oS) | (0xfu << oL) | (1u << oT));
         if (mode == MODE_TEXT && round + 1 > text_rounds) {
-            if (sharded) { set_error("ties deeper than %llu bytes in a sharded build (prefix doubling needs the full rank array)", (unsigned long long)depth); return MSUFSORT_HIP_ERR_UNSUPPORTED; }
+            if (sharded) {
+                if (!d_grp_rows) { set_error("ties deeper than %llu bytes in a sharded build and no group buffer was given", (unsigned long long)depth); return MSUFSORT_HIP_ERR_UNSUPPORTED; }
+                // publish the tie groups of my slice; the caller gathers (SA, grp) and finishes with msufsort_hip_finish_sa_dev
+                u32* grp_local = d_grp_rows + (1 + rank0 - slice_row_lo);
+                const u32 row0 = (u32)(1 + rank0);
+                hipLaunchKernelGGL(k_grp_iota, dim3(std::min<u32>(cdiv(std::max<u64>(slice_rows, 1), 256), 65536u)), dim3(256), 0, st, d_grp_rows, slice_rows, (u32)slice_row_lo);
+                if (actP) hipLaunchKernelGGL(k_grp_pool, dim3(std::min<u32>(cdiv(actP, 256), 65536u)), dim3(256), 0, st, c->pool_hdr[cur].as<u64>(), counters, curP, grp_local, row0);
+                for (int k = 0; k < 3; ++k) {
+                    const u32 cnt = c->h_counters[curL + k];
+                    if (cnt) hipLaunchKernelGGL(k_grp_segs, dim3(cnt), dim3(256), 0, st, c->lists[cur][k].as<Desc>(), cnt, grp_local, row0);
+                }
+                if (u32 cnt = c->h_counters[curL + 3]) hipLaunchKernelGGL(k_grp_segs, dim3(cnt), dim3(256), 0, st, c->large_round[cur].as<Desc>(), cnt, grp_local, row0);
+                HIP_TRY(hipEventRecord(c->ev[5], st));
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipGetLastError());
+                tm.reserved[0] = (int64_t)depth;
+                return MSUFSORT_HIP_UNRESOLVED;
+            }
             // switch to prefix doubling: build the inverse suffix array
             TRY(c->isa.ensure((size_t)(n + 1) * 4));
             if (g_sync_debug) {
@@ -486,6 +541,8 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         if (mode == MODE_TEXT) depth += 4; else { depth *= 2; tm.doubling_rounds++; }
         tm.rounds++;
     }
+    if (d_grp_rows && !resume)
+        hipLaunchKernelGGL(k_grp_iota, dim3(std::min<u32>(cdiv(std::max<u64>(slice_rows, 1), 256), 65536u)), dim3(256), 0, st, d_grp_rows, slice_rows, (u32)slice_row_lo);
     HIP_TRY(hipEventRecord(c->ev[5], st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -629,8 +686,43 @@ int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t 
     return MSUFSORT_HIP_OK;
 }
 
+static int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_slice_out, int32_t* d_grp_slice_out,
+                              int64_t slice_capacity, int64_t* slice_lo, int64_t* slice_hi, const msufsort_hip_opts* opts);
+
 int msufsort_hip_make_sa_shard_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_slice_out, int64_t slice_capacity,
                                    int64_t* slice_lo, int64_t* slice_hi, const msufsort_hip_opts* opts)
+{
+    return make_sa_shard_impl(c, d_text, n, d_slice_out, nullptr, slice_capacity, slice_lo, slice_hi, opts);
+}
+
+int msufsort_hip_make_sa_shard_groups_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_slice_out, int32_t* d_grp_slice_out,
+                                          int64_t slice_capacity, int64_t* slice_lo, int64_t* slice_hi, int64_t* depth_out,
+                                          const msufsort_hip_opts* opts)
+{
+    if (!d_grp_slice_out) return MSUFSORT_HIP_ERR_BAD_ARG;
+    const int r = make_sa_shard_impl(c, d_text, n, d_slice_out, d_grp_slice_out, slice_capacity, slice_lo, slice_hi, opts);
+    if (depth_out) *depth_out = (r == MSUFSORT_HIP_UNRESOLVED) ? c->tm.reserved[0] : 0;
+    return r;
+}
+
+int msufsort_hip_finish_sa_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_sa_full, int32_t* d_grp_full, int64_t depth,
+                               const msufsort_hip_opts* opts)
+{
+    if (!c || !d_text || !d_sa_full || !d_grp_full || n <= 0 || depth <= 0) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n(n));
+    HIP_TRY(hipSetDevice(c->device));
+    TRY(zero_pad(c, d_text, (u64)n));
+    u64 z = 0;
+    TRY(trailing_zeros(c, d_text, (u64)n, &z));
+    msufsort_hip_opts o{};
+    if (opts) o = *opts;
+    o.n_shards = 1; o.shard = 0;
+    return build_sa(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_full), 0, z, 0, 65536, false, &o, true,
+                    reinterpret_cast<u32*>(d_grp_full), (u64)depth, (u64)n + 1);
+}
+
+static int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_slice_out, int32_t* d_grp_slice_out,
+                              int64_t slice_capacity, int64_t* slice_lo, int64_t* slice_hi, const msufsort_hip_opts* opts)
 {
     if (!c || !d_slice_out || !opts || opts->n_shards < 1 || opts->shard < 0 || opts->shard >= opts->n_shards || (n > 0 && !d_text)) return MSUFSORT_HIP_ERR_BAD_ARG;
     TRY(check_n(n));
@@ -655,7 +747,8 @@ int msufsort_hip_make_sa_shard_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t
     if ((int64_t)(hi - lo) > slice_capacity) { set_error("slice needs %llu rows, capacity %lld", (unsigned long long)(hi - lo), (long long)slice_capacity); return MSUFSORT_HIP_ERR_BAD_ARG; }
     if (hi == lo) return MSUFSORT_HIP_OK;
     const bool hist_done = (m > 0 && opts->n_shards > 1);
-    return build_sa(c, d_text, (u64)n, reinterpret_cast<u32*>(d_slice_out), lo, z, cuts[g], cuts[g + 1], g == 0, opts, hist_done);
+    return build_sa(c, d_text, (u64)n, reinterpret_cast<u32*>(d_slice_out), lo, z, cuts[g], cuts[g + 1], g == 0, opts, hist_done,
+                    reinterpret_cast<u32*>(d_grp_slice_out), 0, hi - lo);
 }
 
 int msufsort_hip_make_sa_i32_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64_t n, int32_t* sa_out, const msufsort_hip_opts* opts)

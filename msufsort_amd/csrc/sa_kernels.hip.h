@@ -1306,6 +1306,95 @@ __global__ __launch_bounds__(256) void k_isa_segs(RecBufs bufs, const Desc* __re
     for (u32 p = threadIdx.x; p < d.len; p += 256u) isa[(u32)src[p]] = rank0 + d.sa_off + 1u;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sharded builds with deep ties: a shard that runs out of key-gather rounds publishes, next to
+// its slice of the suffix array, grp[row] = first row of the tie group the row belongs to (its own row when
+// the row is final).  After the all-gatherv every rank rebuilds the complete state from (SA, grp) with
+// k_import_groups / k_isa_from_grp and finishes with prefix doubling (replicated - ranks are global there).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grp_iota(u32* __restrict__ grp_rows, u64 nrows, u32 first_row)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < nrows; i += (u64)gridDim.x * 256u) grp_rows[i] = first_row + (u32)i;
+}
+
+__global__ __launch_bounds__(256) void k_grp_pool(const u64* __restrict__ pool_hdr, const u32* __restrict__ counters, u32 cnt_idx,
+                                                  u32* __restrict__ grp_local, u32 row0)
+{
+    const u32 count = counters[cnt_idx];
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < count; i += (u64)gridDim.x * 256u) {
+        const u64 h = pool_hdr[i];
+        const u32 len = (u32)(h >> 32) & 255u, off = (u32)(h >> 40) & 255u, start = (u32)h;
+        if (len) grp_local[start + off] = row0 + start;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_grp_segs(const Desc* __restrict__ list, u32 nseg, u32* __restrict__ grp_local, u32 row0)
+{
+    if (blockIdx.x >= nseg) return;
+    const Desc d = list[blockIdx.x];
+    for (u32 p = threadIdx.x; p < d.len; p += 256u) grp_local[d.sa_off + p] = row0 + d.sa_off;
+}
+
+// isa[suffix] = 1 + rank of its group head = the group's first ROW (row r holds rank r-1)
+__global__ __launch_bounds__(256) void k_isa_from_grp(const u32* __restrict__ sa_local, const u32* __restrict__ grp_local, u32 m,
+                                                      u32* __restrict__ isa, u32 n, u32 z)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < (u64)m + z; i += (u64)gridDim.x * 256u) {
+        if (i < m) isa[sa_local[i]] = grp_local[i];
+        else { const u32 j = (u32)(i - m); isa[n - 1 - j] = j + 1u; }
+    }
+}
+
+// Rebuild pool / segment array / descriptor lists from (SA, grp): the LAST row of every group emits it.
+// Segment records use identity placement (record of row r at rec[r]).
+__global__ __launch_bounds__(256) void k_import_groups(const u32* __restrict__ sa_local, const u32* __restrict__ grp_local, u32 m, u32 row0,
+                                                       u64* __restrict__ seg_rec, u32 seg_buf,
+                                                       u64* __restrict__ pool_rec, u64* __restrict__ pool_hdr, u32 pool_cnt_idx, u32 pool_cap,
+                                                       Lists lists, Desc* __restrict__ large, u32 large_cap, u32 large_cnt_idx, u32 large_tiles_idx,
+                                                       u32* __restrict__ counters)
+{
+    const u64 lp64 = (u64)blockIdx.x * 256u + threadIdx.x;
+    const bool live = lp64 < m;
+    const u32 lp = live ? (u32)lp64 : 0u;
+    u32 g = 0, len = 0;
+    if (live) {
+        seg_rec[lp] = (u64)sa_local[lp];
+        g = grp_local[lp] - row0;
+        const bool tail = (lp + 1 == m) || (grp_local[lp + 1] != grp_local[lp]);
+        len = tail ? lp - g + 1 : 0u;
+    }
+    {   // tiny groups: one pool allocation per wave
+        const u32 want = (len >= 2 && len <= TINY_MAX) ? len : 0u;
+        u32 wtot;
+        const u32 woff = wave_excl_scan(want, wtot);
+        u32 base = 0;
+        if (wtot) {
+            if (lane_id() == 0) base = atomicAdd(&counters[pool_cnt_idx], wtot);
+            base = __shfl(base, 0, 64);
+            if ((u64)base + wtot > pool_cap) { if (lane_id() == 0) atomicOr(&counters[C_ERR], 2u); }
+            else if (want) for (u32 k = 0; k < len; ++k) { pool_rec[base + woff + k] = (u64)sa_local[g + k]; pool_hdr[base + woff + k] = pack_hdr(g, len, k); }
+        }
+    }
+    const u32 cls = len > TINY_MAX ? class_of(len) : 4u;
+    const u64 lt_mask = lane_id() ? (~0ull >> (64 - lane_id())) : 0ull;
+    const Desc d = {g, len, g, DESC_BUF(32, seg_buf)};
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+        const u64 mk = __ballot(cls == k);
+        if (mk == 0) continue;
+        const int leader = __ffsll((long long)mk) - 1;
+        u32 base = 0;
+        if ((int)lane_id() == leader) base = atomicAdd(&counters[k < 3 ? lists.cnt_idx + k : large_cnt_idx], (u32)__popcll(mk));
+        base = __shfl(base, leader, 64);
+        if (cls == k) {
+            const u32 i = base + (u32)__popcll(mk & lt_mask);
+            if (k < 3) { if (i < lists.cap[k]) lists.cls[k][i] = d; else atomicOr(&counters[C_ERR], 1u); }
+            else { if (i < large_cap) large[i] = d; else atomicOr(&counters[C_ERR], 4u); }
+        }
+    }
+    if (cls == 3) atomicAdd(&counters[large_tiles_idx], (len + P1_TILE - 1) / P1_TILE);
+}
+
 // SA[0] = n and the trailing-zero-run rows (descending index)
 __global__ __launch_bounds__(256) void k_sa_head(u32* __restrict__ sa, u32 n, u32 z)
 {

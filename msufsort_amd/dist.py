@@ -40,14 +40,35 @@ def allgatherv_slices(full, bounds, dist, group=None):
     return full
 
 
-def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist, bounds=None, text_rounds: int = 64):
-    """One step of the sharded build on this rank: sort my key range into my slice, then all-gatherv."""
+def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist, bounds=None, text_rounds: int = 8,
+                     d_grp_full=None):
+    """One step of the sharded build on this rank: sort my key range into my slice, all-gatherv the slices.
+
+    Deep ties (long repeats) cannot be finished shard-locally - prefix doubling needs the ranks of ALL suffixes.
+    With `d_grp_full` (int32, n+1) every rank also publishes the tie groups of its slice; if any rank stopped with
+    unresolved groups the group slices are gathered too and every rank finishes the complete array by prefix
+    doubling (replicated).  Without it such inputs raise (MSUFSORT_HIP_ERR_UNSUPPORTED)."""
     import torch
     if bounds is None:
         bounds = ctx.shard_bounds(d_text, n, world)
     lo, hi = bounds[rank], bounds[rank + 1]
-    sl = d_sa_full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device=d_sa_full.device)
-    ctx.make_sa_shard(d_text, n, sl, max(hi - lo, 1), rank, world, text_rounds=text_rounds)
+    dev = d_sa_full.device
+    sl = d_sa_full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
+    if d_grp_full is None:
+        ctx.make_sa_shard(d_text, n, sl, max(hi - lo, 1), rank, world, text_rounds=text_rounds)
+        if world > 1:
+            allgatherv_slices(d_sa_full, bounds, dist)
+        return bounds
+    gl = d_grp_full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
+    _, _, unresolved, depth = ctx.make_sa_shard_groups(d_text, n, sl, gl, max(hi - lo, 1), rank, world, text_rounds=text_rounds)
+    flag = torch.tensor([depth if unresolved else 0], dtype=torch.int64, device=dev)
     if world > 1:
+        w = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)       # rides along with the slice exchange
         allgatherv_slices(d_sa_full, bounds, dist)
+        w.wait()
+    depth = int(flag.item())
+    if depth > 0:
+        if world > 1:
+            allgatherv_slices(d_grp_full, bounds, dist)
+        ctx.finish_sa(d_text, n, d_sa_full, d_grp_full, depth)
     return bounds

@@ -24,6 +24,18 @@ def test_bench_two_ranks_one_gpu():
     assert d["n_gpus"] == 2 and d["valid"] is True and d["value"] > 0 and d["scaling"] == "strong"
 
 
+def test_bench_two_ranks_deep_ties():
+    """Same flow on DNA with planted tandem repeats: the shards stop unresolved, groups are gathered, every rank finishes."""
+    env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29612", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--size", str(3 << 20), "--workload", "dna_tandem", "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+    assert json.loads(lines[-1])["valid"] is True
+
+
 def test_cpp_dropin_header_builds_and_runs(tmp_path):
     exe = str(tmp_path / "demo")
     subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "demo.cpp"),

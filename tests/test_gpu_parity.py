@@ -170,6 +170,36 @@ def test_logical_shards_concatenate(M, oracle_mod, shards):
         assert (full.cpu().numpy() == want).all()
 
 
+@pytest.mark.parametrize("shards", [2, 5])
+def test_logical_shards_deep_ties_finish(M, oracle_mod, shards):
+    """Sharded build on inputs with long repeats: shards stop with unresolved tie groups, publish them, and the
+    gathered (SA, grp) arrays are finished by prefix doubling - bit-exact against the oracle."""
+    import torch
+    inputs = [gen.dna_tandem_bytes(300000, 9), np.tile(gen.dna_bytes(37, 9), 3000), gen.text_bytes(400000, 21),
+              np.frombuffer(b"ab" * 40000 + b"\x00" * 50, dtype=np.uint8)]
+    for t in inputs:
+        n = t.size
+        d = _dev(M, t)
+        full = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        grp = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        ctxs = [M.DeviceContext(0) for _ in range(shards)]
+        bounds = ctxs[0].shard_bounds(d, n, shards)
+        depth = 0
+        for g in range(shards):
+            lo, hi = bounds[g], bounds[g + 1]
+            sl = full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device="cuda")
+            gl = grp[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device="cuda")
+            l2, h2, unres, dp = ctxs[g].make_sa_shard_groups(d, n, sl, gl, max(hi - lo, 1), g, shards, text_rounds=1)
+            assert (l2, h2) == (lo, hi)
+            depth = max(depth, dp if unres else 0)
+        want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+        assert depth == 9                                   # 5 bytes from round 0 + one 4-byte key round
+        g_host = grp.cpu().numpy()
+        assert (g_host <= np.arange(n + 1)).all() and (g_host >= 0).all()
+        ctxs[-1].finish_sa(d, n, full, grp, depth)
+        assert (full.cpu().numpy() == want).all()
+
+
 def test_large_random_properties(M):
     """256 MiB uniform random (BASELINE config 2): on-device checker (order + permutation),
     BWT -> inverse BWT round trip, all in HBM."""
