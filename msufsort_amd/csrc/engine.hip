@@ -284,7 +284,9 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
     const int verbose = opts ? opts->verbose : 0;
     if (const char* e = getenv("MSUFSORT_HIP_SYNC_DEBUG")) g_sync_debug = atoi(e);
     const bool sharded = opts && opts->n_shards > 1;
-    int text_rounds = (opts && opts->text_rounds > 0) ? opts->text_rounds : 4;
+    const bool auto_switch = !(opts && opts->text_rounds > 0) && !getenv("MSUFSORT_HIP_TEXT_ROUNDS");
+    int text_rounds = (opts && opts->text_rounds > 0) ? opts->text_rounds : 24;
+    u64 prev_active = 0;
     if (const char* e = getenv("MSUFSORT_HIP_TEXT_ROUNDS")) text_rounds = std::max(1, atoi(e));
     const u64 m = n - z;
     hipStream_t st = c->stream;
@@ -411,9 +413,12 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 lp ^= 1;
                 if (last) {
                     if (nl > 0) {
-                        hipLaunchKernelGGL(k_carry, dim3(nl), dim3(256), 0, st, bufs, src_list, nl, sa_local, c->isa.as<u32>(), mode,
-                                           bufs.p[nb], DESC_BUF(32, nb), (u32)(nxt ? C_SEG1 : C_SEG0), cap32,
+                        hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, src_list, nl, c->tile_start.as<u32>());
+                        hipLaunchKernelGGL(k_carry_alloc, dim3(cdiv(nl, 256)), dim3(256), 0, st, src_list, nl, c->trivial.as<u32>(),
+                                           DESC_BUF(32, nb), (u32)(nxt ? C_SEG1 : C_SEG0), cap32,
                                            c->large_round[nxt].as<Desc>(), c->large_cap, (u32)((nxt ? C_LIST1 : C_LIST0) + 3), (u32)(nxt ? C_LTILES1 : C_LTILES0), counters);
+                        hipLaunchKernelGGL(k_carry_copy, dim3(ntiles), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.as<u32>(), c->trivial.as<u32>(),
+                                           sa_local, c->isa.as<u32>(), mode, bufs.p[nb], counters);
                         DBG("k_carry");
                     }
                     break;
@@ -488,7 +493,12 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         const u32 oP = cur ? C_POOL0 : C_POOL1, oS = cur ? C_SEG0 : C_SEG1, oL = cur ? C_LIST0 : C_LIST1, oT = cur ? C_LTILES0 : C_LTILES1;
         hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters,
                            (1u << oP) | (1u << oS) | (0xfu << oL) | (1u << oT));
-        if (mode == MODE_TEXT && round + 1 > text_rounds) {
+        // Switch from key gathers to prefix doubling after text_rounds rounds, or (default policy) as soon as the
+        // tied set stops shrinking: a round that keeps > 70 % of the previous round's ties means long repeats,
+        // where every further 4-byte round is wasted and doubling (log2 LCP rounds) wins despite the ISA build.
+        const bool stalled = auto_switch && !sharded && round >= 2 && (actP + actS) * 10 > prev_active * 7;
+        prev_active = actP + actS;
+        if (mode == MODE_TEXT && (round + 1 > text_rounds || stalled)) {
             if (sharded) {
                 if (!d_grp_rows) { set_error("ties deeper than %llu bytes in a sharded build and no group buffer was given", (unsigned long long)depth); return MSUFSORT_HIP_ERR_UNSUPPORTED; }
                 // publish the tie groups of my slice; the caller gathers (SA, grp) and finishes with msufsort_hip_finish_sa_dev
@@ -533,9 +543,9 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
             mode = MODE_ISA;
         }
         // refill keys of all still-tied suffixes
-        if (actP) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actP, 256), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
+        if (actP) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
                                      d_text, c->isa.as<u32>(), (u32)n, depth, mode);
-        if (actS) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actS, 256), 65536u)), dim3(256), 0, st, bufs.p[sb], counters, curS,
+        if (actS) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actS, 1024), 65536u)), dim3(256), 0, st, bufs.p[sb], counters, curS,
                                      d_text, c->isa.as<u32>(), (u32)n, depth, mode);
         DBG("k_refill");
         if (mode == MODE_TEXT) depth += 4; else { depth *= 2; tm.doubling_rounds++; }

@@ -561,39 +561,54 @@ __global__ __launch_bounds__(1024) void k_tiles(const Desc* __restrict__ list, u
     if (t == 0) tile_start[nseg] = s_carry;
 }
 
-// Segments that stayed larger than CAP_C after all four key bytes: all keys equal, carry them to the
-// next round unchanged (one workgroup per segment).
-__global__ __launch_bounds__(256) void k_carry(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
-                                               u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
-                                               u64* __restrict__ seg_rec, u32 seg_buf, u32 seg_cnt_idx, u32 seg_cap,
-                                               Desc* __restrict__ large_next, u32 large_cap, u32 large_cnt_idx, u32 large_tiles_idx,
-                                               u32* __restrict__ counters)
+// Segments that stayed larger than CAP_C after all four key bytes: all keys equal, carry them to the next round
+// unchanged.  k_carry_alloc reserves their room (one lane per segment), k_carry_copy moves the records by tiles
+// (a 10^7-record segment must not be copied by one workgroup).
+__global__ __launch_bounds__(256) void k_carry_alloc(const Desc* __restrict__ list, u32 nseg, u32* __restrict__ carry_base,
+                                                     u32 seg_buf, u32 seg_cnt_idx, u32 seg_cap,
+                                                     Desc* __restrict__ large_next, u32 large_cap, u32 large_cnt_idx, u32 large_tiles_idx,
+                                                     u32* __restrict__ counters)
 {
-    __shared__ u32 s_base, s_ok;
-    const u32 s = blockIdx.x;
+    const u32 s = blockIdx.x * 256u + threadIdx.x;
     if (s >= nseg) return;
     const Desc d = list[s];
-    if (threadIdx.x == 0) {
-        const u32 b = atomicAdd(&counters[seg_cnt_idx], d.len);
-        s_base = b;
-        s_ok = 1;
-        if ((u64)b + d.len > seg_cap) { atomicOr(&counters[C_ERR], 8u); s_ok = 0; }
-        else {
-            const u32 i = atomicAdd(&counters[large_cnt_idx], 1u);
-            if (i < large_cap) { const Desc nd = {b, d.len, d.sa_off, seg_buf}; large_next[i] = nd; }
-            else { atomicOr(&counters[C_ERR], 16u); s_ok = 0; }
-            atomicAdd(&counters[large_tiles_idx], (d.len + P1_TILE - 1) / P1_TILE);
-        }
-    }
+    const u32 b = atomicAdd(&counters[seg_cnt_idx], d.len);
+    carry_base[s] = 0xffffffffu;
+    if ((u64)b + d.len > seg_cap) { atomicOr(&counters[C_ERR], 8u); return; }
+    const u32 i = atomicAdd(&counters[large_cnt_idx], 1u);
+    if (i >= large_cap) { atomicOr(&counters[C_ERR], 16u); return; }
+    const Desc nd = {b, d.len, d.sa_off, seg_buf};
+    large_next[i] = nd;
+    atomicAdd(&counters[large_tiles_idx], (d.len + P1_TILE - 1) / P1_TILE);
+    carry_base[s] = b;
+}
+
+__global__ __launch_bounds__(P1_THREADS) void k_carry_copy(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+                                                           const u32* __restrict__ tile_start, const u32* __restrict__ carry_base,
+                                                           u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                           u64* __restrict__ seg_rec, const u32* __restrict__ counters)
+{
+    __shared__ u32 s_seg;
+    const u32 t = threadIdx.x;
+    if (blockIdx.x >= tile_start[nseg]) return;
+    if (t == 0) s_seg = find_seg(tile_start, nseg, blockIdx.x);
     __syncthreads();
-    if (!s_ok) return;
+    const u32 s = s_seg;
+    const u32 base = carry_base[s];
+    if (base == 0xffffffffu) return;
+    const Desc d = list[s];
+    const u32 off = (blockIdx.x - tile_start[s]) * P1_TILE;
     const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
     const u32 rank0 = counters[C_RANK0];
-    for (u32 p = threadIdx.x; p < d.len; p += 256u) {
-        const u64 r = src[p];
-        seg_rec[s_base + p] = r;
-        sa_out[d.sa_off + p] = (u32)r;
-        if (mode == MODE_ISA) isa[(u32)r] = rank0 + d.sa_off + 1u;
+#pragma unroll
+    for (int j = 0; j < P1_ITEMS; ++j) {
+        const u32 p = off + j * P1_THREADS + t;
+        if (p < d.len) {
+            const u64 r = src[p];
+            seg_rec[base + p] = r;
+            sa_out[d.sa_off + p] = (u32)r;
+            if (mode == MODE_ISA) isa[(u32)r] = rank0 + d.sa_off + 1u;
+        }
     }
 }
 
@@ -606,18 +621,26 @@ __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32
                                                 u32 n, u64 depth, u32 mode)
 {
     const u32 count = counters[cnt_idx];
-    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < count; i += (u64)gridDim.x * 256u) {
-        const u32 idx = (u32)rec[i];
-        const u64 pos = (u64)idx + depth;
-        u32 key = 0;
-        if (pos < n) {
-            if (mode == MODE_TEXT) {
-                u32 v;
-                __builtin_memcpy(&v, text + pos, 4);      // text is padded with >= 64 zero bytes
-                key = __builtin_bswap32(v);
-            } else key = isa[pos];
+    constexpr int U = 4;                       // independent gathers in flight per lane (latency bound otherwise)
+    for (u64 base = (u64)blockIdx.x * 256u * U + threadIdx.x; base < count; base += (u64)gridDim.x * 256u * U) {
+        u32 idx[U], key[U];
+        bool v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) { const u64 i = base + (u64)k * 256u; v[k] = i < count; idx[k] = v[k] ? (u32)rec[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const u64 pos = (u64)idx[k] + depth;
+            key[k] = 0;
+            if (v[k] && pos < n) {
+                if (mode == MODE_TEXT) {
+                    u32 w;
+                    __builtin_memcpy(&w, text + pos, 4);      // text is padded with >= 64 zero bytes
+                    key[k] = __builtin_bswap32(w);
+                } else key[k] = isa[pos];
+            }
         }
-        rec[i] = ((u64)key << 32) | idx;
+#pragma unroll
+        for (int k = 0; k < U; ++k) if (v[k]) rec[base + (u64)k * 256u] = ((u64)key[k] << 32) | idx[k];
     }
 }
 
@@ -670,7 +693,10 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     const u32 len = d.len;
     if (len == 0) return;                           // neutral list entry (unused chunk tail)
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
-    const u32 wbase = wv * 64u * ITEMS;
+    // every wave takes the same number of consecutive 64-record rows (wave-major order keeps the LSD passes stable);
+    // with a fixed ITEMS rows per wave a short segment would be sorted by one wave while the others idle
+    const u32 rpw = ((len + 63u) / 64u + W - 1) / W;            // rows per wave, <= ITEMS because len <= CAP
+    const u32 wbase = wv * 64u * rpw;
     const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
@@ -681,7 +707,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     for (int j = 0; j < ITEMS; ++j) {
         const u32 p = wbase + j * 64 + lane;
         key[j] = 0xffffffffu; idx[j] = 0xffffffffu;
-        if (p < len) { const u64 r = src[p]; key[j] = (u32)(r >> 32); idx[j] = (u32)r; diff |= key[j] ^ key0; }
+        if ((u32)j < rpw && p < len) { const u64 r = src[p]; key[j] = (u32)(r >> 32); idx[j] = (u32)r; diff |= key[j] ^ key0; }
     }
     // block-wide OR of diff
 #pragma unroll
@@ -693,7 +719,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     diff = misc[0];
     // number of item rows this wave takes part in (rows with at least one valid element)
     int rows = 0;
-    if (wbase < len) { const u32 rem = len - wbase; rows = (int)((rem + 63u) / 64u); if (rows > ITEMS) rows = ITEMS; }
+    if (wbase < len) { const u32 rem = len - wbase; rows = (int)((rem + 63u) / 64u); if (rows > (int)rpw) rows = (int)rpw; }
 
     const bool sorted_done = (diff == 0);
 #pragma nounroll
@@ -1009,15 +1035,19 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
             }
             if (t < 64) ex[len + t] = 0xffffffffu;               // inert tail for the probes (len + 63 < CAP + 64)
             __syncthreads();                                                        // (1)
+            bool skew = false;
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j)
                 if (j < rows) {
                     const u32 p = FAST_P(j);
                     const u32 k = key[j] & kmask;
                     const u32 r = atomicAdd(&hist[p < len ? (k >> sh) : TRASH_BIN], 1u);
+                    skew |= (p < len) & (r >= FAST_LIMIT);
                     key[j] = p < len ? ((k << 6) | (r & 63u)) : 0xffffffffu;      // composite (r < 64 is checked below)
                 }
-            __syncthreads();                                                        // (2)
+            if (__syncthreads_or(skew)) ok = false;                                 // (2) a sub-bucket is too long: hand back now
+        }
+        if (ok) {
             {   // exclusive scan of hist[0..NBIN) in place, E consecutive bins per thread; block max of the counts
                 u32 sum = 0, mx = 0;
 #pragma unroll
