@@ -8,6 +8,7 @@
 #include "../../include/msufsort_hip.h"
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -441,7 +442,12 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         const u32 base = cur ? C_LIST1 : C_LIST0;
         const u32 nA = c->h_counters[base + 0], nB = c->h_counters[base + 1], nC = c->h_counters[base + 2];
         const u32 nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
-        const bool use_fast = getenv("MSUFSORT_HIP_NO_FAST") == nullptr;
+        // k_sort_fast needs spread-out keys.  The 16-bit histogram already tells: if its largest bucket is far
+        // above the mean the input is text-like and every attempt (reading the records, a serialised LDS-atomic
+        // phase, rejection) would be wasted work - go straight to the LSD sort.
+        const u64 ms_shard = c->h_counters[C_MS];
+        const bool spread = (u64)c->h_counters[C_HMAX] * (u64)(khi - klo) <= 8ull * std::max<u64>(ms_shard, 1);   // max <= 8 x mean
+        const bool use_fast = getenv("MSUFSORT_HIP_NO_FAST") == nullptr && (spread || getenv("MSUFSORT_HIP_FORCE_FAST"));
         if (use_fast && (nB || nC)) hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << C_FBB) | (1u << C_FBC));
         if (nC) {
             const u32* ids = nullptr;
@@ -496,7 +502,13 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         // Switch from key gathers to prefix doubling after text_rounds rounds, or (default policy) as soon as the
         // tied set stops shrinking: a round that keeps > 70 % of the previous round's ties means long repeats,
         // where every further 4-byte round is wasted and doubling (log2 LCP rounds) wins despite the ISA build.
-        const bool stalled = auto_switch && !sharded && round >= 2 && (actP + actS) * 10 > prev_active * 7;
+        // ... but only once the depth is past what the alphabet needs anyway: ~log_sigma(m) characters separate
+        // random suffixes (sigma^2 ~ number of non-empty 16-bit buckets), and a low-entropy alphabet (DNA) keeps
+        // everything tied for the first rounds without any repeats being involved.
+        const double sigma2 = std::max<double>(4.0, (double)c->h_counters[C_HNZ]);
+        const double need = 2.0 * std::log((double)std::max<u64>(m, 2)) / std::log(sigma2);
+        const bool stalled = auto_switch && !sharded && round >= 2 && (double)depth >= std::max(13.0, 1.3 * need) &&
+                             (actP + actS) * 10 > prev_active * 7;
         prev_active = actP + actS;
         if (mode == MODE_TEXT && (round + 1 > text_rounds || stalled)) {
             if (sharded) {

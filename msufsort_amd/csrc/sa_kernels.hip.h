@@ -52,6 +52,8 @@ enum {
     C_MS = 20,                        // suffixes in this shard
     C_RANK0 = 21,                     // global rank of the shard's first row
     C_FBB = 22, C_FBC = 23,           // segments k_sort_fast handed back (class B / C)
+    C_HMAX = 24,                      // largest 16-bit bucket of this shard (skew forecast)
+    C_HNZ = 25,                       // number of non-empty 16-bit buckets (alphabet-size estimate)
     C_NCOUNTERS = 32
 };
 
@@ -227,13 +229,21 @@ __global__ __launch_bounds__(1024) void k_scan16(const u32* __restrict__ hist, u
     for (u32 k = 0; k < 64; ++k) { bstart[t * 64 + k] = run; run += hist[t * 64 + k]; }
     __syncthreads();
     const u32 base = bstart[klo];
+    u32 hmax = 0, hnz = 0;
     for (u32 key = t; key < 65536u; key += 1024u) {
         const bool in = key >= klo && key < khi;
         const u32 s = in ? bstart[key] - base : 0u;
         child_start[key] = s;
         cursor1[key] = s;
-        child_cnt[key] = in ? hist[key] : 0u;
+        const u32 c = in ? hist[key] : 0u;
+        child_cnt[key] = c;
+        hmax = c > hmax ? c : hmax;
+        if (c) ++hnz;
     }
+    if (hnz) atomicAdd(&counters[C_HNZ], hnz);
+#pragma unroll
+    for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(hmax, s2, 64); hmax = o > hmax ? o : hmax; }
+    if (lane_id() == 0) atomicMax(&counters[C_HMAX], hmax);
     if (t < 256) {
         u32 lo = t << 8, hi = (t + 1) << 8;
         if (lo < klo) lo = klo;
