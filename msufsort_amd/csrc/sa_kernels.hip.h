@@ -731,6 +731,12 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     int rows = 0;
     if (wbase < len) { const u32 rem = len - wbase; rows = (int)((rem + 63u) / 64u); if (rows > (int)rpw) rows = (int)rpw; }
 
+    const u32 rank0 = counters[C_RANK0];
+    u32 rs[ITEMS], rl[ITEMS];        // run start / run length of each of my (sorted) elements
+    bool any_eq = false;
+    // One-wave segments of up to 128 records (the bulk of class A on text): all-pairs counting instead of LSD passes.
+    const bool small = (THREADS == 64) && len <= 128u;
+    if (!small) {
     const bool sorted_done = (diff == 0);
 #pragma nounroll
     for (u32 shift = 0; shift < 32 && !sorted_done; shift += 8) {
@@ -789,7 +795,6 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[wbase + j * 64 + lane] = key[j];
     for (u32 i = t; i < (u32)NW; i += THREADS) { bm_eq[i] = 0; bm_tiny[i] = 0; bm_seg[i] = 0; }
     __syncthreads();
-    bool any_eq = false;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
         if (j < rows) {
@@ -839,8 +844,6 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
         }
     }
     __syncthreads();
-    const u32 rank0 = counters[C_RANK0];
-    u32 rs[ITEMS], rl[ITEMS];        // run start / run length of each of my elements
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
         if (j < rows) {
@@ -858,6 +861,42 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                 if (mode == MODE_ISA) isa[idx[j]] = rank0 + d.sa_off + s + 1u;
             }
         }
+    } else {
+        // rank = #smaller keys + #equal keys before me; the equal keys are my tie run.  Every lane reads the same
+        // LDS word per step (broadcast), no barriers inside the loop.
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const u32 p = j * 64 + lane; if (p < len) ex[p] = key[j]; }
+        __syncthreads();
+        u32 c_lt[2] = {0, 0}, c_eq[2] = {0, 0}, c_eqb[2] = {0, 0};
+        for (u32 q = 0; q < len; ++q) {
+            const u32 kk = ex[q];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool e = kk == key[j];
+                c_lt[j] += kk < key[j]; c_eq[j] += e; c_eqb[j] += e & (q < (u32)j * 64u + lane);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const u32 p = j * 64 + lane;
+            if (p < len) { const u32 f = c_lt[j] + c_eqb[j]; ex[f] = idx[j]; ex[128 + f] = c_lt[j]; ex[256 + f] = c_eq[j]; }
+        }
+        for (u32 i = t; i < (u32)NW; i += THREADS) { bm_eq[i] = 0; bm_tiny[i] = 0; bm_seg[i] = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 p = j * 64 + lane;
+            rs[j] = p; rl[j] = 1;
+            if (j < 2 && p < len) {
+                idx[j] = ex[p]; rs[j] = ex[128 + p]; rl[j] = ex[256 + p];
+                sa_out[d.sa_off + p] = idx[j];
+                if (mode == MODE_ISA) isa[idx[j]] = rank0 + d.sa_off + rs[j] + 1u;
+                any_eq |= rl[j] > 1;
+            }
+        }
+    }
     if (!__syncthreads_or(any_eq)) return;
 
     // ---- compact still-tied runs into next round's structures ----
