@@ -427,7 +427,6 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
                                                           u32 alt0, u32 alt1, u32 alt2)
 {
     __shared__ u64 stage[P1_TILE];
-    __shared__ u8 sbin[P1_TILE];
     __shared__ u32 hist[256], lstart[256], gbase[256];
     __shared__ u32 s_seg, s_total;
     const u32 t = threadIdx.x;
@@ -466,15 +465,15 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
             const u32 b = (u32)(rec[j] >> (32 + shift)) & 255u;
             const u32 slot = lstart[b] + rank[j];
             stage[slot] = rec[j];
-            sbin[slot] = (u8)b;
         }
     }
     if (t < 256) gbase[t] = claim;
     __syncthreads();
     const u32 tot = s_total;
     for (u32 q = t; q < tot; q += P1_THREADS) {
-        const u32 b = sbin[q];
-        dst[gbase[b] + (q - lstart[b])] = stage[q];
+        const u64 r = stage[q];
+        const u32 b = (u32)(r >> (32 + shift)) & 255u;      // the bin is in the record itself
+        dst[gbase[b] + (q - lstart[b])] = r;
     }
 }
 
