@@ -7,7 +7,7 @@ A "step" is one complete suffix-array build (16-bit radix histogram, two 8-bit s
 sorts, refinement rounds) of one synthetic input that is already resident in HBM.  N = 1: the whole
 array on one MI355X.  N > 1 (launched by torch.distributed.run, one rank per GPU): the 16-bit key space
 is split into N count-balanced ranges, every rank sorts its range into its slice of the full array and
-the slices are exchanged with one all-gatherv (grouped per-root broadcasts over RCCL/xGMI); total work
+the slices are exchanged with one all-gatherv (one group of direct sends/receives over RCCL/xGMI); total work
 is fixed, so "scaling" is "strong".  Rank 0 prints ONE JSON line.
 """
 import argparse

@@ -1,8 +1,8 @@
 """Multi-GPU path: one process per GPU, the 16-bit key space is split into
 `world` count-balanced contiguous ranges, every rank radix-sorts its range into its own slice of the
 full suffix array and the slices are exchanged with ONE all-gatherv.  RCCL has no v-variant, so the
-gather is a group of per-root broadcasts issued together (each peer sends its slice directly, using all
-xGMI links at once) - torch.distributed is plumbing here, the sort is the HIP path.
+gather is ONE group of point-to-point sends/receives (each peer sends its slice directly to every other peer,
+using all xGMI links at once) - torch.distributed is plumbing here, the sort is the HIP path.
 
 The reference has no distributed code at all; this is the MI355X-native extension
 of its bucket-parallel first stage (reference msufsort.cpp:1652-1683 hands partitions to threads).
@@ -27,16 +27,25 @@ def plan_cuts(bstart, n: int, z: int, n_shards: int):
 
 
 def allgatherv_slices(full, bounds, dist, group=None):
-    """All-gatherv of SA slices IN PLACE: rank g has filled full[bounds[g]:bounds[g+1]]; afterwards every
-    rank holds the whole array.  One broadcast per non-empty root, issued asynchronously as a group."""
+    """All-gatherv of SA slices IN PLACE: rank g has filled full[bounds[g]:bounds[g+1]]; afterwards every rank
+    holds the whole array.  RCCL has no v-variant: every rank posts, as ONE group (ncclGroupStart/End through
+    batch_isend_irecv), a send of its slice to each peer and a receive of each peer's slice straight into its
+    place - all xGMI links of the fully connected node carry one slice each way at the same time (per-root
+    broadcasts issued one after another would serialise on the communicator's stream)."""
     world = len(bounds) - 1
-    works = []
-    for g in range(world):
-        lo, hi = bounds[g], bounds[g + 1]
+    rank = dist.get_rank(group)
+    ops = []
+    lo, hi = bounds[rank], bounds[rank + 1]
+    for step in range(1, world):
+        dst = (rank + step) % world
+        src = (rank - step) % world
         if hi > lo:
-            works.append(dist.broadcast(full[lo:hi], src=g, group=group, async_op=True))
-    for w in works:
-        w.wait()
+            ops.append(dist.P2POp(dist.isend, full[lo:hi], dst, group))
+        if bounds[src + 1] > bounds[src]:
+            ops.append(dist.P2POp(dist.irecv, full[bounds[src]:bounds[src + 1]], src, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
     return full
 
 
