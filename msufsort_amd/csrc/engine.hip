@@ -187,11 +187,6 @@ __global__ void k_dbg_scan_sa(const u32* sa_local, u32 ms, u32 n, u32* out)
 
 inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
-struct Bench {   // event timing of phases
-    hipStream_t s;
-    hipEvent_t a, b;
-};
-
 // number of trailing 0x00 bytes of the device text
 int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out)
 {
