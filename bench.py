@@ -89,6 +89,7 @@ def main():
     d_text = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
     d_text[:n] = torch.from_numpy(t).to(dev)
     d_sa = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)          # the engine works on its own HIP stream: the upload must have landed
     ctx = M.DeviceContext(local, n)
 
     bounds = ctx.shard_bounds(d_text, n, world) if world > 1 else None

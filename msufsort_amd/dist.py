@@ -46,6 +46,11 @@ def allgatherv_slices(full, bounds, dist, group=None):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    if full.is_cuda:
+        # work.wait() only orders torch's current stream behind the communicator's; the engine runs on its own
+        # HIP stream, so make the received rows visible to it (and to the host) before anything else touches them
+        import torch
+        torch.cuda.synchronize(full.device)
     return full
 
 
