@@ -134,7 +134,14 @@ class DeviceContext:
 
     @staticmethod
     def _ptr(x) -> int:
-        return int(x.data_ptr()) if hasattr(x, "data_ptr") else int(x)
+        """Raw device pointer of a torch tensor (or an int).  The engine runs on its own HIP stream, so pending
+        work on torch's current stream (the upload that filled the tensor) is drained first."""
+        if hasattr(x, "data_ptr"):
+            if getattr(x, "is_cuda", False):
+                import torch
+                torch.cuda.current_stream(x.device).synchronize()
+            return int(x.data_ptr())
+        return int(x)
 
     def make_sa(self, d_text, n: int, d_sa, *, verbose=0, text_rounds=0):
         """d_text: >= n+64 bytes in HBM; d_sa: n+1 int32 in HBM."""
