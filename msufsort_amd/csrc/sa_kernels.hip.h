@@ -174,6 +174,10 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u3
     const u64 cbeg = (u64)chunk * chunk_len;
     u64 cend = cbeg + chunk_len;
     if (cend > m) cend = m;
+    // Keys are counted in their MEMORY byte order k' = T[i] | T[i+1] << 8 (one v_alignbyte + one mask per key);
+    // k_reduce16 transposes to the big-endian key T[i] << 8 | T[i+1] the rest of the pipeline uses.  A block
+    // counts the keys whose bit 15 (top bit of T[i+1]) equals `half`.
+    const u32 hsel = half << 15;
     for (u64 base = cbeg + (u64)threadIdx.x * 16u; base < cend; base += 1024u * 16u) {
         const uint4 v = *reinterpret_cast<const uint4*>(text + base);
         const u32 nxt = text[base + 16];
@@ -181,10 +185,9 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u3
         const u32 lim = (u32)((cend - base) < 16 ? (cend - base) : 16);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
-            const u32 b1 = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u;
-            const u32 key = (b0 << 8) | b1;
-            if ((u32)j < lim && (key >> 15) == half) atomicAdd(&h_lds[key & 0x7fffu], 1u);
+            const u32 lo = w[j >> 2], hi = w[(j >> 2) + 1];
+            const u32 key = ((j & 3) == 3 ? __builtin_amdgcn_alignbyte(hi, lo, 3) : (lo >> (8 * (j & 3)))) & 0xffffu;
+            if ((u32)j < lim && (key & 0x8000u) == hsel) atomicAdd(&h_lds[key & 0x7fffu], 1u);
         }
     }
     __syncthreads();
@@ -192,12 +195,13 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u3
     for (u32 i = threadIdx.x; i < 32768u; i += 1024u) out[i] = h_lds[i];
 }
 
+// sums the per-chunk partials (indexed by the memory-order key) and stores them under the big-endian key
 __global__ __launch_bounds__(1024) void k_reduce16(const u32* __restrict__ partial, u32 nchunks, u32* __restrict__ hist)
 {
-    const u32 key = blockIdx.x * 1024u + threadIdx.x;
+    const u32 kle = blockIdx.x * 1024u + threadIdx.x;          // T[i] | T[i+1] << 8
     u32 s = 0;
-    for (u32 c = 0; c < nchunks; ++c) s += partial[(u64)c * 65536u + key];
-    hist[key] = s;
+    for (u32 c = 0; c < nchunks; ++c) s += partial[(u64)c * 65536u + kle];
+    hist[((kle & 255u) << 8) | (kle >> 8)] = s;
 }
 
 // Exclusive scan of the 65,536 counts (bucket offsets, cpp:1603-1630) + set-up of the two scatter
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(128) void k_stripes(const u32* __restrict__ partial
     u32 sum = 0;
     if (c < nchunks && lo < hi) {
         const u32* p = partial + (u64)c * 65536u;
-        for (u32 k = lo; k < hi; ++k) sum += p[k];
+        for (u32 k = lo; k < hi; ++k) sum += p[(k >> 8) | ((k & 255u) << 8)];      // partials are indexed in memory byte order
     }
     u32 wt;
     u32 e = wave_excl_scan(sum, wt);
