@@ -74,7 +74,7 @@ struct msufsort_hip_ctx {
     // workspace
     DevBuf rec[3], pool_rec[2], pool_hdr[2];
     DevBuf lists[2][3], large_round[2], lvl[2], seg0;
-    DevBuf seg0_base, hist_partial, hist, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
+    DevBuf seg0_base, stripe_sums, hist_partial, hist, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
     DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, doneB, doneC;
     u32* h_counters = nullptr;   // pinned
     u32* h_bstart = nullptr;     // pinned, 65537
@@ -128,6 +128,7 @@ struct msufsort_hip_ctx {
         TRY(seg_hist.ensure(nchild * 4));
         TRY(cursor0.ensure(128 * 256 * 4));
         TRY(seg0_base.ensure(256 * 4));
+        TRY(stripe_sums.ensure(128 * 256 * 4));
         TRY(tile_start.ensure(((size_t)std::max<u32>(large_cap, 256) + 1) * 4));
         TRY(trivial.ensure((size_t)std::max<u32>(large_cap, 256) * 4));
         TRY(hist_partial.ensure((size_t)128 * 65536 * 4));
@@ -147,7 +148,7 @@ struct msufsort_hip_ctx {
         for (auto& b : pool_rec) b.release();
         for (auto& b : pool_hdr) b.release();
         for (int s = 0; s < 2; ++s) { for (int c = 0; c < 3; ++c) lists[s][c].release(); large_round[s].release(); lvl[s].release(); }
-        seg0.release(); seg0_base.release(); hist_partial.release(); hist.release(); bstart.release(); child_start.release(); child_cnt.release();
+        seg0.release(); seg0_base.release(); stripe_sums.release(); hist_partial.release(); hist.release(); bstart.release(); child_start.release(); child_cnt.release();
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release();
         cap_m = 0; cap_for_m = 0;
@@ -243,7 +244,8 @@ void run_scan(msufsort_hip_ctx* c, u32 klo, u32 khi, u64 z)
     hipLaunchKernelGGL(k_scan16, dim3(1), dim3(1024), 0, c->stream, c->hist.as<u32>(), c->bstart.as<u32>(), klo, khi,
                        c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->seg0_base.as<u32>(),
                        c->seg0.as<Desc>(), c->tile_start.as<u32>(), c->counters.as<u32>(), (u32)z);
-    hipLaunchKernelGGL(k_stripes, dim3(256), dim3(128), 0, c->stream, c->hist_partial.as<u32>(), c->nchunks, klo, khi,
+    hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks), dim3(1024), 0, c->stream, c->hist_partial.as<u32>(), klo, khi, c->stripe_sums.as<u32>());
+    hipLaunchKernelGGL(k_stripes, dim3(256), dim3(128), 0, c->stream, c->stripe_sums.as<u32>(), c->nchunks,
                        c->seg0_base.as<u32>(), c->cursor0.as<u32>());
 }
 

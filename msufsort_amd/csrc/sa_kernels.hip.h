@@ -279,19 +279,32 @@ __global__ __launch_bounds__(1024) void k_scan16(const u32* __restrict__ hist, u
 // suffixes with first byte b in earlier chunks (from the per-chunk histograms k_hist16 left behind).  With one
 // cursor set per stripe the 256 output streams become 256 x nchunks, which spreads the scatter's writes
 // (and its claim atomics) over all HBM channels.
-__global__ __launch_bounds__(128) void k_stripes(const u32* __restrict__ partial, u32 nchunks, u32 klo, u32 khi,
+__global__ __launch_bounds__(1024) void k_stripe_sums(const u32* __restrict__ partial, u32 klo, u32 khi, u32* __restrict__ sums)
+{
+    // sums[chunk][b] = in-range suffixes of this chunk whose first byte is b.  partial[] is indexed in memory
+    // byte order (first byte in the low 8 bits), so row b1 of a chunk is contiguous over b: coalesced reads.
+    __shared__ u32 acc[4][256];
+    const u32 c = blockIdx.x, b = threadIdx.x & 255u, q = threadIdx.x >> 8;
+    const u32* p = partial + (u64)c * 65536u;
+    u32 sum = 0;
+#pragma unroll 16
+    for (u32 i = 0; i < 64u; ++i) {
+        const u32 b1 = q * 64u + i;
+        const u32 k = (b << 8) | b1;
+        const u32 v = p[b1 * 256u + b];
+        sum += (k >= klo && k < khi) ? v : 0u;
+    }
+    acc[q][b] = sum;
+    __syncthreads();
+    if (q == 0) sums[c * 256u + b] = acc[0][b] + acc[1][b] + acc[2][b] + acc[3][b];
+}
+
+__global__ __launch_bounds__(128) void k_stripes(const u32* __restrict__ sums, u32 nchunks,
                                                  const u32* __restrict__ seg0_base, u32* __restrict__ cursor0)
 {
     __shared__ u32 wtot[2];
     const u32 b = blockIdx.x, c = threadIdx.x;
-    u32 lo = b << 8, hi = (b + 1) << 8;
-    if (lo < klo) lo = klo;
-    if (hi > khi) hi = khi;
-    u32 sum = 0;
-    if (c < nchunks && lo < hi) {
-        const u32* p = partial + (u64)c * 65536u;
-        for (u32 k = lo; k < hi; ++k) sum += p[(k >> 8) | ((k & 255u) << 8)];      // partials are indexed in memory byte order
-    }
+    const u32 sum = c < nchunks ? sums[c * 256u + b] : 0u;
     u32 wt;
     u32 e = wave_excl_scan(sum, wt);
     if (lane_id() == 63) wtot[c >> 6] = wt;
