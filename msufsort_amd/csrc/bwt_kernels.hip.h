@@ -276,23 +276,52 @@ __device__ __forceinline__ bool ibwt_marked(u32 row, u32 sent) { return (row & (
 __device__ __forceinline__ u32 ibwt_id(u32 row, u32 sent, u32 kreg) { return (row == sent && (sent & (IBWT_S - 1))) ? kreg : row / IBWT_S; }
 __device__ __forceinline__ u32 ibwt_start(u32 id, u32 sent, u32 kreg) { return id == kreg ? sent : id * IBWT_S; }
 
-// pass A: length and successor of every chain (chain 0 = row 0 is the terminal)
-__global__ __launch_bounds__(256) void k_ibwt_walk_a(const u64* __restrict__ packed, u32 sent, u32 kreg, u32 K,
-                                                     u32* __restrict__ queue, u32* __restrict__ nxt, u32* __restrict__ dist)
+// ONE walk: lanes pull chains from a queue and store the text bytes they meet into the chain's own fixed-size
+// buffer (sequential per chain, so L2 merges the byte stores).  A chain that reaches IBWT_CW hops without meeting a
+// marker row is cut there: the same lane continues into a freshly numbered segment (ids >= K) and links the two.
+// Afterwards nxt/dist describe a linked list of segments of at most IBWT_CW bytes each; list ranking gives every
+// segment its text position and k_ibwt_assemble copies the buffers out with coalesced stores - n dependent
+// random reads in total instead of the 2n of a count-then-write scheme.
+#define IBWT_CW 512u
+__global__ __launch_bounds__(256) void k_ibwt_walk(const u64* __restrict__ packed, u32 sent, u32 kreg, u32 K, u32 kt_cap,
+                                                   u32* __restrict__ queue /* [0] static head, [1] dynamic count */,
+                                                   u32* __restrict__ nxt, u32* __restrict__ dist, u8* __restrict__ segbuf)
 {
-    u32 id = atomicAdd(queue, 1u) + 1u;
-    u32 cur = 0, len = 0;
-    if (id < K) cur = ibwt_start(id, sent, kreg);
+    u32 id = atomicAdd(&queue[0], 1u) + 1u;
+    u32 cur = 0, len = 0, my = id;
+    if (id < K) cur = (u32)packed[ibwt_start(id, sent, kreg)];
     while (id < K) {
-        cur = (u32)packed[cur];
+        const u64 e = packed[cur];
+        segbuf[(u64)my * IBWT_CW + len] = (u8)(e >> 32);
         ++len;
         if (ibwt_marked(cur, sent)) {
-            nxt[id] = ibwt_id(cur, sent, kreg);
-            dist[id] = len;
-            id = atomicAdd(queue, 1u) + 1u;
-            if (id < K) { cur = ibwt_start(id, sent, kreg); len = 0; }
+            nxt[my] = ibwt_id(cur, sent, kreg);
+            dist[my] = len;
+            id = atomicAdd(&queue[0], 1u) + 1u;
+            my = id; len = 0;
+            if (id < K) cur = (u32)packed[ibwt_start(id, sent, kreg)];
+        } else {
+            if (len == IBWT_CW) {
+                const u32 fresh = K + atomicAdd(&queue[1], 1u);
+                if (fresh >= kt_cap) { queue[2] = 1u; return; }          // cannot happen (capacity covers every cut)
+                nxt[my] = fresh; dist[my] = len;
+                my = fresh; len = 0;
+            }
+            cur = (u32)e;
         }
     }
+}
+
+// out[pos .. pos + len) = segment buffer; one wave per segment, 64 contiguous bytes per store instruction
+__global__ __launch_bounds__(256) void k_ibwt_assemble(const u8* __restrict__ segbuf, const u32* __restrict__ len0,
+                                                       const u32* __restrict__ dist_to_end, u32 KT, u32 n, u8* __restrict__ out)
+{
+    const u32 seg = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seg >= KT || seg == 0) return;
+    const u32 len = len0[seg];
+    const u64 pos = (u64)n - dist_to_end[seg];
+    const u8* src = segbuf + (u64)seg * IBWT_CW;
+    for (u32 o = lane; o < len; o += 64u) out[pos + o] = src[o];
 }
 
 __global__ __launch_bounds__(256) void k_ibwt_jump(const u32* __restrict__ nxt, const u32* __restrict__ dist, u32 K,
@@ -305,19 +334,3 @@ __global__ __launch_bounds__(256) void k_ibwt_jump(const u32* __restrict__ nxt, 
     nxt2[j] = nxt[x];
 }
 
-// pass B: walk again, now writing text bytes at their final positions
-__global__ __launch_bounds__(256) void k_ibwt_walk_b(const u64* __restrict__ packed, u32 sent, u32 kreg, u32 K, u32 n,
-                                                     u32* __restrict__ queue, const u32* __restrict__ dist, u8* __restrict__ out)
-{
-    u32 id = atomicAdd(queue, 1u) + 1u;
-    u32 cur = 0, p = 0;
-    if (id < K) { cur = (u32)packed[ibwt_start(id, sent, kreg)]; p = n - dist[id]; }
-    while (id < K) {
-        const u64 e = packed[cur];
-        out[p++] = (u8)(e >> 32);
-        if (ibwt_marked(cur, sent)) {
-            id = atomicAdd(queue, 1u) + 1u;
-            if (id < K) { cur = (u32)packed[ibwt_start(id, sent, kreg)]; p = n - dist[id]; }
-        } else cur = (u32)e;
-    }
-}

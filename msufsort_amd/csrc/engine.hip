@@ -75,7 +75,7 @@ struct msufsort_hip_ctx {
     DevBuf rec[3], pool_rec[2], pool_hdr[2];
     DevBuf lists[2][3], large_round[2], lvl[2], seg0;
     DevBuf seg0_base, stripe_sums, hist_partial, hist, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
-    DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, doneB, doneC;
+    DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, aux3, doneB, doneC;
     u32* h_counters = nullptr;   // pinned
     u32* h_bstart = nullptr;     // pinned, 65537
     u32 nchunks = 1, chunk_len = 16384;      // text striping of the last k_hist16
@@ -150,7 +150,7 @@ struct msufsort_hip_ctx {
         for (int s = 0; s < 2; ++s) { for (int c = 0; c < 3; ++c) lists[s][c].release(); large_round[s].release(); lvl[s].release(); }
         seg0.release(); seg0_base.release(); stripe_sums.release(); hist_partial.release(); hist.release(); bstart.release(); child_start.release(); child_cnt.release();
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
-        isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release();
+        isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
         cap_m = 0; cap_for_m = 0;
     }
 
