@@ -364,17 +364,10 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
             sbin[slot] = (u8)b0;
         }
     }
-    if (t < 256) gbase[t] = claim;
+    if (t < 256) gbase[t] = claim - lstart[t];            // slot -> output index is one add: out[gbase[bin] + slot]
     __syncthreads();
     const u32 tot = s_total;
-#ifdef EXP_NO_CLAIM   // timing experiment only: tile-contiguous output, wrong result
-    for (u32 s = t; s < tot; s += S0_THREADS) out[base0 + s] = stage[s];
-#else
-    for (u32 s = t; s < tot; s += S0_THREADS) {
-        const u32 b = sbin[s];
-        out[gbase[b] + (s - lstart[b])] = stage[s];
-    }
-#endif
+    for (u32 s = t; s < tot; s += S0_THREADS) out[gbase[sbin[s]] + s] = stage[s];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -484,13 +477,12 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
             stage[slot] = rec[j];
         }
     }
-    if (t < 256) gbase[t] = claim;
+    if (t < 256) gbase[t] = claim - lstart[t];            // slot -> output index is one add: dst[gbase[bin] + slot]
     __syncthreads();
     const u32 tot = s_total;
     for (u32 q = t; q < tot; q += P1_THREADS) {
         const u64 r = stage[q];
-        const u32 b = (u32)(r >> (32 + shift)) & 255u;      // the bin is in the record itself
-        dst[gbase[b] + (q - lstart[b])] = r;
+        dst[gbase[(u32)(r >> (32 + shift)) & 255u] + q] = r;      // the bin is in the record itself
     }
 }
 
