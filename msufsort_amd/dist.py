@@ -26,12 +26,14 @@ def plan_cuts(bstart, n: int, z: int, n_shards: int):
     return cuts.tolist(), rows.tolist()
 
 
-def allgatherv_slices(full, bounds, dist, group=None):
+def allgatherv_slices(full, bounds, dist, group=None, wait=True):
     """All-gatherv of SA slices IN PLACE: rank g has filled full[bounds[g]:bounds[g+1]]; afterwards every rank
     holds the whole array.  RCCL has no v-variant: every rank posts, as ONE group (ncclGroupStart/End through
     batch_isend_irecv), a send of its slice to each peer and a receive of each peer's slice straight into its
     place - all xGMI links of the fully connected node carry one slice each way at the same time (per-root
-    broadcasts issued one after another would serialise on the communicator's stream)."""
+    broadcasts issued one after another would serialise on the communicator's stream).
+    wait=False returns the pending work handles (finish them with `wait_all`) so that the next build can run
+    while the links are busy."""
     world = len(bounds) - 1
     rank = dist.get_rank(group)
     ops = []
@@ -43,25 +45,35 @@ def allgatherv_slices(full, bounds, dist, group=None):
             ops.append(dist.P2POp(dist.isend, full[lo:hi], dst, group))
         if bounds[src + 1] > bounds[src]:
             ops.append(dist.P2POp(dist.irecv, full[bounds[src]:bounds[src + 1]], src, group))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-    if full.is_cuda:
-        # work.wait() only orders torch's current stream behind the communicator's; the engine runs on its own
-        # HIP stream, so make the received rows visible to it (and to the host) before anything else touches them
-        import torch
-        torch.cuda.synchronize(full.device)
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if not wait:
+        return works
+    wait_all(works, full)
     return full
 
 
+def wait_all(works, full=None):
+    """Completes pending exchange work.  work.wait() only orders torch's current stream behind the communicator's;
+    the engine runs on its own HIP stream, so the device is synchronised before anything else touches the rows."""
+    for w in works:
+        w.wait()
+    if full is not None and full.is_cuda:
+        import torch
+        torch.cuda.synchronize(full.device)
+
+
 def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist, bounds=None, text_rounds: int = 8,
-                     d_grp_full=None):
+                     d_grp_full=None, overlap=False):
     """One step of the sharded build on this rank: sort my key range into my slice, all-gatherv the slices.
 
     Deep ties (long repeats) cannot be finished shard-locally - prefix doubling needs the ranks of ALL suffixes.
     With `d_grp_full` (int32, n+1) every rank also publishes the tie groups of its slice; if any rank stopped with
     unresolved groups the group slices are gathered too and every rank finishes the complete array by prefix
-    doubling (replicated).  Without it such inputs raise (MSUFSORT_HIP_ERR_UNSUPPORTED)."""
+    doubling (replicated).  Without it such inputs raise (MSUFSORT_HIP_ERR_UNSUPPORTED).
+
+    overlap=True: returns the pending exchange handles instead of waiting, so the caller can start the next build
+    (into ANOTHER output buffer) while the slices travel; finish with `wait_all(works, d_sa_full)`.  If the build
+    turns out to need the finishing pass the exchange is completed here and [] is returned."""
     import torch
     if bounds is None:
         bounds = ctx.shard_bounds(d_text, n, world)
@@ -71,18 +83,25 @@ def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist
     if d_grp_full is None:
         ctx.make_sa_shard(d_text, n, sl, max(hi - lo, 1), rank, world, text_rounds=text_rounds)
         if world > 1:
-            allgatherv_slices(d_sa_full, bounds, dist)
-        return bounds
+            works = allgatherv_slices(d_sa_full, bounds, dist, wait=not overlap)
+            return works if overlap else []
+        return []
     gl = d_grp_full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
     _, _, unresolved, depth = ctx.make_sa_shard_groups(d_text, n, sl, gl, max(hi - lo, 1), rank, world, text_rounds=text_rounds)
     flag = torch.tensor([depth if unresolved else 0], dtype=torch.int64, device=dev)
+    works = []
     if world > 1:
         w = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)       # rides along with the slice exchange
-        allgatherv_slices(d_sa_full, bounds, dist)
+        works = allgatherv_slices(d_sa_full, bounds, dist, wait=False)
         w.wait()
     depth = int(flag.item())
     if depth > 0:
+        wait_all(works, d_sa_full)
         if world > 1:
             allgatherv_slices(d_grp_full, bounds, dist)
         ctx.finish_sa(d_text, n, d_sa_full, d_grp_full, depth)
-    return bounds
+        return []
+    if overlap:
+        return works
+    wait_all(works, d_sa_full)
+    return []
