@@ -93,6 +93,7 @@ def main():
     ctx = M.DeviceContext(local, n)
 
     bounds = ctx.shard_bounds(d_text, n, world) if world > 1 else None
+    exchange = mdist.select_exchange(dist, dev) if world > 1 else None
     d_grp = torch.empty(n + 1, dtype=torch.int32, device=dev) if world > 1 else None
     # N > 1: two output buffers, so the all-gatherv of build k can travel while build k+1 is being sorted
     # (every build and every exchange is complete before the closing barrier of the timed region)
@@ -175,7 +176,7 @@ def main():
             "data": "synthetic",
             "valid": bool(ok),
             "config": {"workload": f"{args.workload} bytes (splitmix64 seed {args.seed}), n={n}, int32 SA, 16-bit-key range sharding x{world}",
-                       "n": n, "index": "int32"},
+                       "n": n, "index": "int32", "allgatherv": exchange},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launch_ms": round(dms, 4), "algorithmic_bytes": int(dbytes)},

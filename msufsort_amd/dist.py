@@ -26,6 +26,34 @@ def plan_cuts(bstart, n: int, z: int, n_shards: int):
     return cuts.tolist(), rows.tolist()
 
 
+_MODE = {"mode": "p2p"}
+
+
+def select_exchange(dist, device):
+    """Picks the all-gatherv flavour once per process group: grouped point-to-point (default) unless
+    MSUFSORT_ALLGATHERV=bcast is set or a tiny trial exchange fails on ANY rank (all ranks then agree on bcast)."""
+    import os
+    import torch
+    if os.environ.get("MSUFSORT_ALLGATHERV", "p2p") == "bcast":
+        _MODE["mode"] = "bcast"
+        return "bcast"
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ok = 1
+    try:
+        probe = torch.zeros(world * 4, dtype=torch.int32, device=device)
+        probe[rank * 4:(rank + 1) * 4] = rank + 1
+        _MODE["mode"] = "p2p"
+        allgatherv_slices(probe, [4 * g for g in range(world + 1)], dist)
+        if not bool((probe.view(world, 4) == torch.arange(1, world + 1, device=device, dtype=torch.int32)[:, None]).all()):
+            ok = 0
+    except Exception:  # noqa: BLE001
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    _MODE["mode"] = "p2p" if int(flag.item()) == 1 else "bcast"
+    return _MODE["mode"]
+
+
 def allgatherv_slices(full, bounds, dist, group=None, wait=True):
     """All-gatherv of SA slices IN PLACE: rank g has filled full[bounds[g]:bounds[g+1]]; afterwards every rank
     holds the whole array.  RCCL has no v-variant: every rank posts, as ONE group (ncclGroupStart/End through
@@ -36,6 +64,13 @@ def allgatherv_slices(full, bounds, dist, group=None, wait=True):
     while the links are busy."""
     world = len(bounds) - 1
     rank = dist.get_rank(group)
+    if _MODE["mode"] == "bcast":                     # fallback: one broadcast per root (serialised on the communicator)
+        works = [dist.broadcast(full[bounds[g]:bounds[g + 1]], src=g, group=group, async_op=True)
+                 for g in range(world) if bounds[g + 1] > bounds[g]]
+        if not wait:
+            return works
+        wait_all(works, full)
+        return full
     ops = []
     lo, hi = bounds[rank], bounds[rank + 1]
     for step in range(1, world):
