@@ -48,7 +48,8 @@ typedef struct msufsort_hip_opts {
     int32_t device;            /* HIP device ordinal (default 0) */
     int32_t shard;             /* this call builds shard `shard` of `n_shards` (16-bit-key range split); */
     int32_t n_shards;          /*   0 or 1 = whole array */
-    int32_t text_rounds;       /* key-gather rounds before switching to prefix doubling (0 = default) */
+    int32_t text_rounds;       /* key-gather rounds before switching to prefix doubling; 0 = adaptive (switch when the
+                                  tied set stops shrinking past the depth the alphabet needs, at the latest after 24) */
     int32_t verbose;           /* 1: per-round statistics on stderr */
     int32_t reserved[11];
 } msufsort_hip_opts;
