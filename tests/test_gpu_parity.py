@@ -139,10 +139,21 @@ def test_device_api_and_checker(M, oracle_mod):
     assert ctx.validate_sa(d, n, sa) == 0
     want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
     assert (sa.cpu().numpy() == want).all()
-    # the on-device checker must see a broken array
+    # the on-device checker must see a broken array: swapped neighbours, a duplicate, a wrong head
     bad = sa.clone()
     bad[1000], bad[1001] = sa[1001].item(), sa[1000].item()
     assert ctx.validate_sa(d, n, bad) > 0
+    bad = sa.clone(); bad[5] = sa[6]
+    assert ctx.validate_sa(d, n, bad) > 0
+    bad = sa.clone(); bad[0] = 0
+    assert ctx.validate_sa(d, n, bad) > 0
+    # ... and a fully periodic input in linear time (the demo's checker is O(n * LCP) there)
+    tp = np.full(1 << 22, 65, dtype=np.uint8)
+    dp = _dev(M, tp)
+    sap = torch.empty(tp.size + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(dp, tp.size, sap)
+    assert ctx.validate_sa(dp, tp.size, sap) == 0
+    assert (sap.cpu().numpy() == np.arange(tp.size, -1, -1)).all()
     # hist16 probe against numpy
     h = torch.zeros(65536, dtype=torch.int32, device="cuda")
     ctx.debug_hist16(d, n, h)
