@@ -78,7 +78,8 @@ struct msufsort_hip_ctx {
     DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, aux3, doneB, doneC;
     u32* h_counters = nullptr;   // pinned
     u32* h_bstart = nullptr;     // pinned, 65537
-    u32 nchunks = 1, chunk_len = 16384;      // text striping of the last k_hist16
+    u32 nchunks = 1, chunk_len = 32768;      // text striping of the last k_hist16 (scatter stripes)
+    u32 hist_per = 1;                        // histogram chunks per stripe
     u32 list_cap[3] = {0, 0, 0};
     u32 large_cap = 0;
     u64 cap_m = 0;               // records capacity
@@ -89,7 +90,7 @@ struct msufsort_hip_ctx {
     int set_attrs()
     {
         if (attrs_set) return MSUFSORT_HIP_OK;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS>),
@@ -131,7 +132,7 @@ struct msufsort_hip_ctx {
         TRY(stripe_sums.ensure(128 * 256 * 4));
         TRY(tile_start.ensure(((size_t)std::max<u32>(large_cap, 256) + 1) * 4));
         TRY(trivial.ensure((size_t)std::max<u32>(large_cap, 256) * 4));
-        TRY(hist_partial.ensure((size_t)128 * 65536 * 4));
+        TRY(hist_partial.ensure((size_t)256 * 65536 * 4));
         TRY(hist.ensure(65536 * 4));
         TRY(bstart.ensure(65537 * 4));
         TRY(counters.ensure(C_NCOUNTERS * 4));
@@ -229,12 +230,16 @@ struct ShardPlan {
 // hist16 + reduce (+ scan for the given key range).  Leaves hist/bstart and the level-0/1 set-up on the device.
 int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
 {
+    // scatter stripes: at most 128, each a multiple of 32 KiB; histogram chunks: 1 or 2 per stripe, so that
+    // large inputs give every CU a workgroup (one workgroup per chunk, 136 KiB of LDS each)
     u32 nchunks = (u32)std::min<u64>(128, std::max<u64>(1, (m + 65535) / 65536));
     u64 chunk_len = (m + nchunks - 1) / nchunks;
-    chunk_len = (chunk_len + 16383) / 16384 * 16384;
-    c->nchunks = nchunks; c->chunk_len = (u32)chunk_len;
-    hipLaunchKernelGGL(k_hist16, dim3(16 * cdiv(nchunks, 8)), dim3(1024), 131072, c->stream, d_text, (u32)m, (u32)chunk_len, nchunks, c->hist_partial.as<u32>());
-    hipLaunchKernelGGL(k_reduce16, dim3(64), dim3(1024), 0, c->stream, c->hist_partial.as<u32>(), nchunks, c->hist.as<u32>());
+    chunk_len = (chunk_len + 32767) / 32768 * 32768;
+    const u32 per = chunk_len >= 131072 ? 2 : 1;
+    const u32 hchunks = nchunks * per;
+    c->nchunks = nchunks; c->chunk_len = (u32)chunk_len; c->hist_per = per;
+    hipLaunchKernelGGL(k_hist16, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, (u32)m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>());
+    hipLaunchKernelGGL(k_reduce16, dim3(64), dim3(1024), 0, c->stream, c->hist_partial.as<u32>(), hchunks, c->hist.as<u32>());
     HIP_TRY(hipGetLastError());
     return MSUFSORT_HIP_OK;
 }
@@ -244,7 +249,7 @@ void run_scan(msufsort_hip_ctx* c, u32 klo, u32 khi, u64 z)
     hipLaunchKernelGGL(k_scan16, dim3(1), dim3(1024), 0, c->stream, c->hist.as<u32>(), c->bstart.as<u32>(), klo, khi,
                        c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->seg0_base.as<u32>(),
                        c->seg0.as<Desc>(), c->tile_start.as<u32>(), c->counters.as<u32>(), (u32)z);
-    hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks), dim3(1024), 0, c->stream, c->hist_partial.as<u32>(), klo, khi, c->stripe_sums.as<u32>());
+    hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks), dim3(1024), 0, c->stream, c->hist_partial.as<u32>(), c->hist_per, klo, khi, c->stripe_sums.as<u32>());
     hipLaunchKernelGGL(k_stripes, dim3(256), dim3(128), 0, c->stream, c->stripe_sums.as<u32>(), c->nchunks,
                        c->seg0_base.as<u32>(), c->cursor0.as<u32>());
 }

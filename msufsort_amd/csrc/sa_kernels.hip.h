@@ -125,6 +125,13 @@ __device__ __forceinline__ u32 wave_excl_scan(u32 v, u32& total)
     return x - v;
 }
 
+__device__ __forceinline__ u32 wave_sum(u32 v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
 // exclusive scan of 256 LDS values by the FIRST wave of the block (4 per lane); other waves skip.
 // caller: __syncthreads() before (inputs ready) and after (outputs ready).
 __device__ __forceinline__ u32 scan256_first_wave(const u32* in, u32* out)
@@ -156,43 +163,125 @@ __device__ __forceinline__ void push_desc(const Lists& L, u32* counters, u32 cls
 }
 
 // ------------------------------------------------------------------------------------------------
-// 16-bit radix histogram (count_suffixes, cpp:1496-1521).  A 65,536-bin u32 histogram is 256 KiB and
-// does not fit the 160 KiB LDS, so each workgroup counts one HALF of the key space (32,768 bins =
-// 128 KiB) over its chunk of the text; two workgroups share a chunk.  16 B per lane coalesced loads.
-// partial[chunk][65536] is reduced by k_reduce16.
+// 16-bit radix histogram (count_suffixes, cpp:1496-1521).  One workgroup per text chunk keeps ALL 65,536 bins in
+// LDS as 16-bit counters, two per word (128 KiB): word = key' & 0x7fff, half-word = bit 15 of key', where
+// key' = T[i] | T[i+1] << 8 is the key in MEMORY byte order (k_reduce16 transposes to the big-endian key the rest
+// of the pipeline uses).  16 B per lane coalesced loads, next load in flight while the current one is counted,
+// one non-returning LDS atomic per key.
+//
+// 16-bit counters can wrap.  Pass 0 counts the whole chunk without looking; every add contributes exactly 1 or
+// 65536 to its word, so with true counts (L, H) the two stored halves sum to L + H - 65535 a - 65536 b with
+// a = L / 65536 and b = (H + a) / 65536: the halves of all words add up to the number of keys of the chunk if and
+// only if no counter wrapped.  When that check fails (a key with >= 65536 occurrences in one chunk: text, DNA,
+// periodic data) pass 1 recounts the chunk in sub-chunks of H16_SUB keys: a counter below H16_FLUSH at the start of
+// a sub-chunk cannot wrap inside it (H16_FLUSH + H16_SUB <= 65536), and after every sub-chunk a sweep over the LDS
+// moves counters >= H16_FLUSH to an overflow list (at most chunk_len / H16_FLUSH entries ever), which is added to
+// the output at the end.  partial[chunk][65536] is reduced by k_reduce16.
 // ------------------------------------------------------------------------------------------------
+#define H16_SUB 49152u       // bytes (= keys) per sub-chunk: 3 iterations of 1024 lanes x 16 B
+#define H16_FLUSH 16384u
+#define H16_OVF_CAP 1024u    // >= max chunk_len / H16_FLUSH (chunk_len <= 16 MiB)
+#define H16_LDS_BYTES (131072u + H16_OVF_CAP * 8u + 64u)
+
+__device__ __forceinline__ void h16_add(u32* h_lds, u32 lo, u32 hi, int j)
+{
+    const int s = j & 3;                                     // key' = bytes j, j+1 of the stream lo | hi << 32
+    const u32 k = s == 3 ? __builtin_amdgcn_alignbyte(hi, lo, 3) : (lo >> (8 * s));
+    atomicAdd(&h_lds[k & 0x7fffu], ((k >> 15) & 1u) * 0xffffu + 1u);      // + 1 or + 0x10000
+}
+
 __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u32 m, u32 chunk_len, u32 nchunks,
                                                  u32* __restrict__ partial)
 {
     extern __shared__ u32 h_lds[];
-    // blocks b and b+8 land on the same XCD (round-robin dealing): give them the two halves of ONE chunk so
-    // the second reader of every line is served by that XCD's L2 instead of HBM (speed only)
-    const u32 chunk = (blockIdx.x >> 4) * 8u + (blockIdx.x & 7u), half = (blockIdx.x >> 3) & 1u;
+    u64* ovf = reinterpret_cast<u64*>(h_lds + 32768);
+    u32* ovf_n = h_lds + 32768 + H16_OVF_CAP * 2;            // [0] list length, [1] checksum
+    const u32 chunk = blockIdx.x, t = threadIdx.x;
     if (chunk >= nchunks) return;
-    for (u32 i = threadIdx.x; i < 32768u; i += 1024u) h_lds[i] = 0;
-    __syncthreads();
+    uint4* h4 = reinterpret_cast<uint4*>(h_lds);
     const u64 cbeg = (u64)chunk * chunk_len;
     u64 cend = cbeg + chunk_len;
     if (cend > m) cend = m;
-    // Keys are counted in their MEMORY byte order k' = T[i] | T[i+1] << 8 (one v_alignbyte + one mask per key);
-    // k_reduce16 transposes to the big-endian key T[i] << 8 | T[i+1] the rest of the pipeline uses.  A block
-    // counts the keys whose bit 15 (top bit of T[i+1]) equals `half`.
-    const u32 hsel = half << 15;
-    for (u64 base = cbeg + (u64)threadIdx.x * 16u; base < cend; base += 1024u * 16u) {
-        const uint4 v = *reinterpret_cast<const uint4*>(text + base);
-        const u32 nxt = text[base + 16];
-        const u32 w[5] = {v.x, v.y, v.z, v.w, nxt};
-        const u32 lim = (u32)((cend - base) < 16 ? (cend - base) : 16);
+    if (cend < cbeg) cend = cbeg;
+#pragma unroll 1
+    for (u32 pass = 0; pass < 2; ++pass) {
+        for (u32 i = t; i < 8192u; i += 1024u) h4[i] = make_uint4(0, 0, 0, 0);
+        if (t < 2) ovf_n[t] = 0;
+        __syncthreads();
+        u64 base = cbeg + (u64)t * 16u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        u32 nx = 0;
+        if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = text[base + 16]; }
+#pragma unroll 1
+        for (u64 sub = cbeg; sub < cend; sub += H16_SUB) {
+#pragma unroll 1
+            for (u32 it = 0; it < H16_SUB / 16384u; ++it) {
+                if (base >= cend) break;
+                const uint4 cv = v;
+                const u32 cn = nx;
+                const u64 cb = base;
+                base += 16384u;
+                if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = text[base + 16]; }   // prefetch
+                const u32 w[5] = {cv.x, cv.y, cv.z, cv.w, cn};
+                if (cend - cb >= 16) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const u32 lo = w[j >> 2], hi = w[(j >> 2) + 1];
-            const u32 key = ((j & 3) == 3 ? __builtin_amdgcn_alignbyte(hi, lo, 3) : (lo >> (8 * (j & 3)))) & 0xffffu;
-            if ((u32)j < lim && (key & 0x8000u) == hsel) atomicAdd(&h_lds[key & 0x7fffu], 1u);
+                    for (int j = 0; j < 16; ++j) h16_add(h_lds, w[j >> 2], w[(j >> 2) + 1], j);
+                } else {
+                    const u32 lim = (u32)(cend - cb);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) if ((u32)j < lim) h16_add(h_lds, w[j >> 2], w[(j >> 2) + 1], j);
+                }
+            }
+            if (pass == 0 || sub + H16_SUB >= cend) continue;      // the last sub-chunk needs no sweep
+            __syncthreads();
+#pragma unroll 1
+            for (u32 i = t; i < 8192u; i += 1024u) {
+                uint4 q = h4[i];
+                if (((q.x | q.y | q.z | q.w) & 0xC000C000u) == 0) continue;
+                u32 ww[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u32 word = i * 4u + e;
+                    if ((ww[e] & 0xffffu) >= H16_FLUSH) {
+                        const u32 slot = atomicAdd(ovf_n, 1u);
+                        if (slot < H16_OVF_CAP) { ovf[slot] = ((u64)word << 32) | (ww[e] & 0xffffu); ww[e] &= 0xffff0000u; }
+                    }
+                    if ((ww[e] >> 16) >= H16_FLUSH) {
+                        const u32 slot = atomicAdd(ovf_n, 1u);
+                        if (slot < H16_OVF_CAP) { ovf[slot] = ((u64)(word | 0x8000u) << 32) | (ww[e] >> 16); ww[e] &= 0xffffu; }
+                    }
+                }
+                h4[i] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+            }
+            __syncthreads();
         }
+        __syncthreads();
+        if (pass == 1) break;
+        // pass 0: did any counter wrap?
+        u32 sum = 0;
+        for (u32 i = t; i < 8192u; i += 1024u) {
+            const uint4 q = h4[i];
+            sum += (q.x & 0xffffu) + (q.x >> 16) + (q.y & 0xffffu) + (q.y >> 16) + (q.z & 0xffffu) + (q.z >> 16) + (q.w & 0xffffu) + (q.w >> 16);
+        }
+        sum = wave_sum(sum);
+        if (lane_id() == 0) atomicAdd(&ovf_n[1], sum);
+        __syncthreads();
+        const bool clean = ovf_n[1] == (u32)(cend - cbeg);
+        __syncthreads();
+        if (clean) break;
     }
-    __syncthreads();
-    u32* out = partial + (u64)chunk * 65536u + half * 32768u;
-    for (u32 i = threadIdx.x; i < 32768u; i += 1024u) out[i] = h_lds[i];
+    u32* out = partial + (u64)chunk * 65536u;
+    for (u32 i = t; i < 32768u; i += 1024u) {
+        const u32 q = h_lds[i];
+        out[i] = q & 0xffffu;
+        out[i + 32768u] = q >> 16;
+    }
+    const u32 no = ovf_n[0] < H16_OVF_CAP ? ovf_n[0] : H16_OVF_CAP;
+    if (no) {                                           // uniform
+        __threadfence();
+        __syncthreads();
+        for (u32 i = t; i < no; i += 1024u) atomicAdd(&out[(u32)(ovf[i] >> 32)], (u32)ovf[i]);
+    }
 }
 
 // sums the per-chunk partials (indexed by the memory-order key) and stores them under the big-endian key
@@ -275,24 +364,27 @@ __global__ __launch_bounds__(1024) void k_scan16(const u32* __restrict__ hist, u
 // Per tile: LDS histogram with returning LDS atomics gives the rank inside the tile, one global atomic
 // per (tile, bin) claims the output range, records are staged bin-sorted in LDS and written as runs.
 // ------------------------------------------------------------------------------------------------
-// Level-0 cursors per text stripe: cursor0[chunk][b] = start of first-byte bucket b + number of in-range
-// suffixes with first byte b in earlier chunks (from the per-chunk histograms k_hist16 left behind).  With one
+// Level-0 cursors per text stripe: cursor0[stripe][b] = start of first-byte bucket b + number of in-range
+// suffixes with first byte b in earlier stripes (from the per-chunk histograms k_hist16 left behind).  With one
 // cursor set per stripe the 256 output streams become 256 x nchunks, which spreads the scatter's writes
 // (and its claim atomics) over all HBM channels.
-__global__ __launch_bounds__(1024) void k_stripe_sums(const u32* __restrict__ partial, u32 klo, u32 khi, u32* __restrict__ sums)
+__global__ __launch_bounds__(1024) void k_stripe_sums(const u32* __restrict__ partial, u32 per, u32 klo, u32 khi, u32* __restrict__ sums)
 {
-    // sums[chunk][b] = in-range suffixes of this chunk whose first byte is b.  partial[] is indexed in memory
-    // byte order (first byte in the low 8 bits), so row b1 of a chunk is contiguous over b: coalesced reads.
+    // sums[stripe][b] = in-range suffixes of this stripe (= `per` histogram chunks) whose first byte is b.
+    // partial[] is indexed in memory byte order (first byte in the low 8 bits), so row b1 of a chunk is
+    // contiguous over b: coalesced reads.
     __shared__ u32 acc[4][256];
     const u32 c = blockIdx.x, b = threadIdx.x & 255u, q = threadIdx.x >> 8;
-    const u32* p = partial + (u64)c * 65536u;
     u32 sum = 0;
+    for (u32 h = 0; h < per; ++h) {
+        const u32* p = partial + (u64)(c * per + h) * 65536u;
 #pragma unroll 16
-    for (u32 i = 0; i < 64u; ++i) {
-        const u32 b1 = q * 64u + i;
-        const u32 k = (b << 8) | b1;
-        const u32 v = p[b1 * 256u + b];
-        sum += (k >= klo && k < khi) ? v : 0u;
+        for (u32 i = 0; i < 64u; ++i) {
+            const u32 b1 = q * 64u + i;
+            const u32 k = (b << 8) | b1;
+            const u32 v = p[b1 * 256u + b];
+            sum += (k >= klo && k < khi) ? v : 0u;
+        }
     }
     acc[q][b] = sum;
     __syncthreads();
