@@ -97,8 +97,10 @@ struct msufsort_hip_ctx {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast<CLS_C_THREADS, CLS_C_ITEMS, FAST_BITS_C, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS, FAST_BITS_C>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast2_lds_bytes<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast<FAST_C_THREADS, FAST_C_ITEMS, FAST_BITS_C, FAST_C_PREFETCH>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast_lds_bytes<FAST_C_THREADS, FAST_C_ITEMS, FAST_BITS_C>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast<CLS_B_THREADS, CLS_B_ITEMS, 12, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12>()));
         attrs_set = true;
@@ -454,9 +456,26 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         if (nC) {
             const u32* ids = nullptr;
             if (use_fast) {
-                k_sort_fast<CLS_C_THREADS, CLS_C_ITEMS, FAST_BITS_C, false><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_fast_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS, FAST_BITS_C>(), st>>>(
+#ifdef FAST_OLD_C
+                k_sort_fast<FAST_C_THREADS, FAST_C_ITEMS, FAST_BITS_C, FAST_C_PREFETCH><<<dim3(std::min<u32>(nC, 256u)), dim3(FAST_C_THREADS), sort_fast_lds_bytes<FAST_C_THREADS, FAST_C_ITEMS, FAST_BITS_C>(), st>>>(
                     bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneC.as<u32>(), (u32)C_FBC);
+#else
+                k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_fast2_lds_bytes<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C>(), st>>>(
+                    bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneC.as<u32>(), (u32)C_FBC);
+#endif
                 DBG("k_sort_fast C");
+#ifdef FAST2_PROF
+                {
+                    unsigned long long h[16];
+                    hipStreamSynchronize(st);
+                    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fast2_prof), sizeof h);
+                    fprintf(stderr, "[fast2 prof] nC=%u cycles/1e6:", nC);
+                    for (int i = 0; i < 12; ++i) fprintf(stderr, " p%d=%.1f", i, h[i] / 1e6);
+                    fprintf(stderr, "\n");
+                    memset(h, 0, sizeof h);
+                    hipMemcpyToSymbol(HIP_SYMBOL(g_fast2_prof), h, sizeof h);
+                }
+#endif
                 ids = c->doneC.as<u32>();
             }
             k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(

@@ -65,6 +65,15 @@ enum {
 #define CLS_B_ITEMS 18       // <= 4608
 #define CLS_C_THREADS 1024
 #define CLS_C_ITEMS 18       // <= 18432
+// k_sort_fast's own shape for class C: half the threads, twice the rows per thread - 8 waves per CU may use 256
+// VGPRs each, which is what it takes to keep the NEXT segment's records in flight while this one is sorted
+#ifndef FAST_C_THREADS
+#define FAST_C_THREADS 1024
+#endif
+#define FAST_C_ITEMS (CLS_C_THREADS * CLS_C_ITEMS / FAST_C_THREADS)
+#ifndef FAST_C_PREFETCH
+#define FAST_C_PREFETCH false
+#endif
 #define CAP_A (CLS_A_THREADS * CLS_A_ITEMS)
 #define CAP_B (CLS_B_THREADS * CLS_B_ITEMS)
 #define CAP_C (CLS_C_THREADS * CLS_C_ITEMS)
@@ -1141,6 +1150,11 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
     constexpr int E = NBIN / THREADS;
     constexpr u32 TRASH_POS = CAP + 32;       // ex slot that absorbs the lanes past the end of the segment
     constexpr u32 TRASH_BIN = NBIN + 1;
+    // sub-bucket g lives at hist[FAST_BIN(g)]: thread t scans the E consecutive sub-buckets t*E .. t*E+E-1, which
+    // this map puts at addresses k*THREADS + t - consecutive lanes touch consecutive words (no bank conflicts in
+    // the scan; a straight layout would put a whole wave on two banks)
+    static_assert((E & (E - 1)) == 0 && (THREADS & (THREADS - 1)) == 0, "power-of-two shapes");
+#define FAST_BIN(g) ((((g) & (u32)(E - 1)) * (u32)THREADS) | ((g) / (u32)E))
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP + 64
     u32* hist = ex + CAP + 64;                                  // NBIN + 16
@@ -1174,6 +1188,19 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
         const u32 kmask = kbits >= 32 ? 0xffffffffu : ((1u << kbits) - 1u);
         const u32 sh = kbits > (u32)BITS ? kbits - BITS : 0u;
         bool ok = kbits <= 26u && len != 0;                      // block-uniform (len 0 = neutral list entry)
+#ifdef FAST_EXP_MEMONLY
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) if (j < rows) { const u32 p = FAST_P(j); if (p < len) sa_out[sa_off + p] = idx[j] + (key[j] & 1); }
+            ok = false;
+            if (!more) break;
+            d = list[seg];
+            const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) { const u32 p = FAST_P(j); nrec[j] = p < d.len ? src[p] : ~0ull; }
+            continue;
+        }
+#endif
 
         if (ok) {
             if (t < 16) misc[t] = 0;
@@ -1190,17 +1217,19 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
                 if (j < rows) {
                     const u32 p = FAST_P(j);
                     const u32 k = key[j] & kmask;
-                    const u32 r = atomicAdd(&hist[p < len ? (k >> sh) : TRASH_BIN], 1u);
+                    const u32 g = k >> sh;
+                    const u32 r = atomicAdd(&hist[p < len ? FAST_BIN(g) : TRASH_BIN], 1u);
                     skew |= (p < len) & (r >= FAST_LIMIT);
                     key[j] = p < len ? ((k << 6) | (r & 63u)) : 0xffffffffu;      // composite (r < 64 is checked below)
                 }
             if (__syncthreads_or(skew)) ok = false;                                 // (2) a sub-bucket is too long: hand back now
         }
         if (ok) {
-            {   // exclusive scan of hist[0..NBIN) in place, E consecutive bins per thread; block max of the counts
+            {   // exclusive scan over the sub-buckets in key order, E consecutive ones per thread; each word becomes
+                // base | count << 16; block max of the counts
                 u32 sum = 0, mx = 0;
 #pragma unroll
-                for (int k = 0; k < E; ++k) { const u32 c = hist[t * E + k]; sum += c; mx = c > mx ? c : mx; }
+                for (int k = 0; k < E; ++k) { const u32 c = hist[k * THREADS + t]; sum += c; mx = c > mx ? c : mx; }
                 u32 wt;
                 u32 e = wave_excl_scan(sum, wt);
 #pragma unroll
@@ -1213,8 +1242,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
                 for (int k = 0; k < W; ++k) if (k < (int)wv) wb += tot[k];
                 e += wb;
 #pragma unroll
-                for (int k = 0; k < E; ++k) { const u32 c = hist[t * E + k]; hist[t * E + k] = e; e += c; }
-                if (t == THREADS - 1) hist[NBIN] = e;
+                for (int k = 0; k < E; ++k) { const u32 c = hist[k * THREADS + t]; hist[k * THREADS + t] = e | (c << 16); e += c; }
             }
             __syncthreads();                                                        // (4)
             ok = misc[1] <= FAST_LIMIT;
@@ -1229,9 +1257,8 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
                     const u32 c = key[j];
                     const bool v = c != 0xffffffffu;
                     const u32 dg = v ? (c >> (6 + sh)) : 0u;
-                    const u32 b0 = hist[dg], b1 = hist[dg + 1];
-                    bc[j] = b0 | ((b1 - b0) << 16);
-                    ex[v ? b0 + (c & 63u) : TRASH_POS] = c;
+                    bc[j] = hist[FAST_BIN(dg)];
+                    ex[v ? (bc[j] & 0xffffu) + (c & 63u) : TRASH_POS] = c;
                 }
             }
             __syncthreads();                                                        // (5)
@@ -1245,7 +1272,11 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
                     const u32 me = key[j], b0 = bc[j] & 0xffffu;
                     u32 lt = 0, eq = 0;
 #pragma unroll
+#ifdef FAST_EXP_PROBES
+                    for (int q = 0; q < FAST_EXP_PROBES; ++q) { const u32 c = ex[b0 + q]; lt += c < me; eq += (c ^ me) < 64u; }
+#else
                     for (int q = 0; q < FAST_PROBE; ++q) { const u32 c = ex[b0 + q]; lt += c < me; eq += (c ^ me) < 64u; }
+#endif
                     const bool v = me != 0xffffffffu;
                     const bool slow = v && ((bc[j] >> 16) > FAST_PROBE || eq > 1);
                     anyslow |= slow;
@@ -1280,15 +1311,21 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
                 fetched = true;
             }
             __syncthreads();                                                        // (6)
+#ifndef FAST_EXP_NOEXCH
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[pos[j]] = idx[j];
             __syncthreads();                                                        // (7)
+#endif
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j)
                 if (j < rows) {
                     const u32 p = FAST_P(j);
                     if (p < len) {
+#ifndef FAST_EXP_NOEXCH
                         sa_out[sa_off + p] = ex[p];
+#else
+                        sa_out[sa_off + p] = idx[j] + (pos[j] & 1);
+#endif
                         if (mode == MODE_ISA) isa[idx[j]] = rank0 + sa_off + (info[j] & 0xffffu) + 1u;
                     }
                 }
@@ -1340,6 +1377,299 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc*
         }
     }
 #undef FAST_P
+#undef FAST_BIN
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sort_fast2: the same sort with the register budget turned into memory/compute overlap.  One workgroup of 1024
+// threads per CU may use 128 VGPRs; k_sort_fast spends them on key, index, base, row and run info of 18 rows and
+// has none left to keep the NEXT segment's records in flight, so every CU alternates between a memory phase and a
+// compute phase of about the same length.  Here
+//   - suffix indices wait in LDS (exi[source position], written and read by the same thread) instead of registers,
+//   - the sub-bucket table shares its LDS with the composite array (it is dead once every row holds its base),
+//   - run information exists only for the few records that need it: they are pushed to a small tie list in LDS,
+// which leaves room for the next segment's 2 x 18 record registers: its loads are issued right after the current
+// records have been unpacked and arrive while this segment is sorted.
+// Segments with more than FAST2_TL tied records go back to k_sort_mid (after their rows have been written once).
+// ------------------------------------------------------------------------------------------------
+#ifdef FAST2_PROF
+__device__ unsigned long long g_fast2_prof[16];
+#define F2P(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); prof_acc[i] += now_ - prof_last; prof_last = now_; } } while (0)
+#else
+#define F2P(i) do { } while (0)
+#endif
+#define FAST2_TL 768u
+#ifndef FAST2_C_ITEMS
+#define FAST2_C_ITEMS 17     // rows per thread of the class-C instance: 17,408 records (a two-byte bucket of 1 GiB of random
+                             // bytes holds 16,384 +- 128); one row fewer than the class limit buys the registers that
+                             // keep the compiler from spilling into the prefetch
+#endif
+template <int THREADS, int ITEMS, int BITS>
+__global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+                                                        u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                        Emit em, u32* __restrict__ counters, u32* __restrict__ fb_list, u32 fb_cnt_idx)
+{
+    constexpr int CAP = THREADS * ITEMS;
+    constexpr int W = THREADS / 64;
+    constexpr int NBIN = 1 << BITS;
+    constexpr int E = NBIN / THREADS;
+    constexpr u32 TRASH_POS = CAP + 32;
+    constexpr u32 TRASH_BIN = NBIN + 1;
+    static_assert(NBIN + 16 <= CAP + 64, "the sub-bucket table must fit under the composite array");
+    static_assert((E & (E - 1)) == 0 && (THREADS & (THREADS - 1)) == 0, "power-of-two shapes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP + 64: sub-bucket table, composites, index exchange
+    u32* hist = ex;
+    u32* exi = ex + CAP + 64;                                   // CAP: suffix index of source position p
+    u32* tl = exi + CAP;                                        // 3 * FAST2_TL: tie list {index, rs | rl << 16 | ro << 24, local offset}
+    u32* tot = tl + 3 * FAST2_TL;                               // 16
+    u32* misc = tot + 16;                                       // 16
+
+    // rows of 64 consecutive records are dealt round-robin to the waves: row j of this thread is position j * THREADS + t
+    u32 t = threadIdx.x;
+#define FAST_P(j) ((u32)(j) * (u32)THREADS + t)
+#define FAST_BIN(g) ((((g) & (u32)(E - 1)) * (u32)THREADS) | ((g) / (u32)E))
+    u32 seg = blockIdx.x;
+    if (seg >= nseg) return;
+    // descriptors are fetched two segments ahead and the record buffer is picked with selects, not with an indexed
+    // load from the argument block: no scalar-memory round trip sits in front of the record loads
+#define FAST_SRC(dd) (reinterpret_cast<const unsigned char*>((((dd).buf & 3u) == 0u ? bufs.p[0] : ((dd).buf & 3u) == 1u ? bufs.p[1] : bufs.p[2]) + (dd).rec_off))
+    Desc d = list[seg];
+    Desc dn = list[seg + gridDim.x < nseg ? seg + gridDim.x : seg];      // unconditional, clamped: stays a scalar load
+    u64 nrec[ITEMS];
+    {
+        // uniform base + 32-bit byte offset per lane (one address register per load, not two); no branches: the
+        // offset is clamped instead
+        const unsigned char* src = FAST_SRC(d);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { const u32 p = FAST_P(j); nrec[j] = *reinterpret_cast<const u64*>(src + (p < d.len ? p * 8u : 0u)); }
+    }
+    const u32 rank0 = counters[C_RANK0];
+#ifdef FAST2_PROF
+    __shared__ unsigned long long prof_acc[16];
+    unsigned long long prof_last = clock64();
+    if (threadIdx.x == 0) for (int i = 0; i < 16; ++i) prof_acc[i] = 0;
+#endif
+    for (;;) {
+        // the thread id is re-materialised per segment so that the address arithmetic hanging off it is redone
+        // here (a handful of adds) instead of being hoisted out of the loop into registers this kernel does not have
+        asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(threadIdx.x));
+        const u32 lane = t & 63u, wv = t >> 6;
+        const u32 len = d.len, sa_off = d.sa_off, cur = seg, kbits = (d.buf >> 8) & 255u;
+        u32 key[ITEMS];                    // key, then composite, then base | size << 16 | rank << 24, then final row
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { key[j] = (u32)(nrec[j] >> 32); exi[FAST_P(j)] = (u32)nrec[j]; }
+        F2P(10);
+        seg += gridDim.x;
+        const bool more = seg < nseg;
+        d = dn;
+        // The next segment's records travel while this one is sorted.  A CU can only keep so many requests in
+        // flight: 18 loads per wave issued back to back stall every wave in the issue queue for microseconds, so
+        // they are issued three rows at a time, one batch behind each phase of the sort (F2_LOAD).
+        const unsigned char* nsrc = FAST_SRC(d);
+        const u32 nlen = more ? d.len : 0u;
+#define F2_LOAD(from, upto) do { _Pragma("unroll") for (int j_ = (from); j_ < (upto) && j_ < ITEMS; ++j_) { const u32 p_ = FAST_P(j_); nrec[j_] = *reinterpret_cast<const u64*>(nsrc + (p_ < nlen ? p_ * 8u : 0u)); } } while (0)
+        constexpr int LB = (ITEMS + 5) / 6;                      // rows per batch, six batches
+        F2_LOAD(0, LB);
+        dn = list[seg + gridDim.x < nseg ? seg + gridDim.x : nseg - 1u];
+        F2P(0);
+        const u32 nrows = (len + 63u) >> 6;
+        const int rows = nrows > wv ? (int)((nrows - wv + W - 1) / W) : 0;
+        const u32 kmask = kbits >= 32 ? 0xffffffffu : ((1u << kbits) - 1u);
+        const u32 sh = kbits > (u32)BITS ? kbits - BITS : 0u;
+        bool ok = kbits <= 26u && len != 0 && len <= (u32)CAP;   // (longer class members go to k_sort_mid)
+        u32 res_t = 0, res_s = 0;
+
+        if (ok) {                                                // ---- phase 1: clear the table
+            if (t < 16) misc[t] = 0;
+            uint4* h4 = reinterpret_cast<uint4*>(hist);
+            const uint4 z4 = {0u, 0u, 0u, 0u};
+            for (u32 i = t; i < ((u32)NBIN + 16u) / 4u; i += THREADS) h4[i] = z4;
+            F2P(11);
+            __syncthreads();                                                        // (1)
+            F2P(1);
+        }
+        F2_LOAD(LB, 2 * LB);
+        if (ok) {                                                // ---- phase 2: arrival ranks
+            bool skew = false;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = FAST_P(j);
+                    const u32 k = key[j] & kmask;
+                    const u32 g = k >> sh;
+                    const u32 r = atomicAdd(&hist[p < len ? FAST_BIN(g) : TRASH_BIN], 1u);
+                    skew |= (p < len) & (r >= FAST_LIMIT);
+                    key[j] = p < len ? ((k << 6) | (r & 63u)) : 0xffffffffu;
+                }
+            if (skew) misc[5] = 1u;
+            __syncthreads();                                                        // (2)
+            if (misc[5]) ok = false;
+            F2P(2);
+        }
+        F2_LOAD(2 * LB, 3 * LB);
+        if (ok) {                                                // ---- phase 3: scan -> base | size << 16
+            u32 sum = 0, mx = 0;
+#pragma unroll
+            for (int k = 0; k < E; ++k) { const u32 c = hist[k * THREADS + t]; sum += c; mx = c > mx ? c : mx; }
+            u32 wt;
+            u32 e = wave_excl_scan(sum, wt);
+#pragma unroll
+            for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(mx, s2, 64); mx = o > mx ? o : mx; }
+            if (lane == 63) tot[wv] = wt;
+            if (lane == 0) atomicMax(&misc[1], mx);
+            __syncthreads();                                                        // (3)
+            u32 wb = 0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) if (k < (int)wv) wb += tot[k];
+            e += wb;
+#pragma unroll
+            for (int k = 0; k < E; ++k) { const u32 c = hist[k * THREADS + t]; hist[k * THREADS + t] = e | (c << 16); e += c; }
+            __syncthreads();                                                        // (4)
+            F2P(3);
+            ok = misc[1] <= FAST_LIMIT;
+        }
+        F2_LOAD(3 * LB, 4 * LB);
+        const bool early_exit = !ok;                             // the rest is requested behind the block below (not
+                                                                 // here: loads pending on one path make the register
+                                                                 // reuse of the other path wait for them)
+        if (ok) {                                                // ---- phase 4: every row fetches its sub-bucket
+            u32 bc[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                bc[j] = 0;
+                if (j < rows) {
+                    const u32 c = key[j];
+                    const u32 dg = c != 0xffffffffu ? (c >> (6 + sh)) : 0u;
+                    bc[j] = hist[FAST_BIN(dg)];
+                }
+            }
+            __syncthreads();                                                        // (5) the table is dead: composites move in
+            F2P(4);
+            F2_LOAD(4 * LB, 5 * LB);
+            // ---- phase 5: composites to their slots
+            // key[] := sub-bucket base | size << 16 | my arrival rank << 24 ; the composite itself goes to LDS and is
+            // read back by its owner (one register per row instead of two while the next segment's records are in flight)
+            if (t < 64) ex[len + t] = 0xffffffffu;               // inert tail for the probes
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 c = key[j];
+                    const bool v = c != 0xffffffffu;
+                    ex[v ? (bc[j] & 0xffffu) + (c & 63u) : TRASH_POS] = c;
+                    key[j] = v ? (bc[j] | ((c & 63u) << 24)) : TRASH_POS;
+                }
+            __syncthreads();                                                        // (6)
+            F2P(5);
+            F2_LOAD(5 * LB, ITEMS);
+            // ---- phase 6: final rows, exchange, output
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                if (j < rows) {
+                    const u32 pk = key[j], b0 = pk & 0xffffu, bsz = (pk >> 16) & 255u;
+                    const u32 me = ex[b0 + (pk >> 24)];
+                    u32 lt = 0, eq = 0;
+#pragma unroll
+                    for (int q = 0; q < FAST_PROBE; ++q) { const u32 c = ex[b0 + q]; lt += c < me; eq += (c ^ me) < 64u; }
+                    const bool v = me != 0xffffffffu;
+                    const bool slow = v && (bsz > FAST_PROBE || eq > 1);
+                    key[j] = v ? b0 + lt : TRASH_POS;            // final row; bit 31: tied (handled through the tie list)
+                    if (__ballot(slow)) {
+                        if (slow) {      // rare: long sub-bucket or equal keys
+                            const u32 b1 = b0 + bsz;
+                            u32 ltk = 0;
+                            lt = 0; eq = 0;
+#pragma nounroll
+                            for (u32 q = b0; q < b1; ++q) { const u32 c = ex[q]; lt += c < me; eq += (c ^ me) < 64u; ltk += (c >> 6) < (me >> 6); }
+                            key[j] = b0 + lt;
+                            if (eq > 1) {
+                                const u32 ro = lt - ltk;
+                                const u32 slot = atomicAdd(&misc[4], 1u);
+                                u32 loc = 0;
+                                if (ro == 0) loc = atomicAdd(&misc[eq <= TINY_MAX ? 2 : 3], eq);
+                                if (slot < FAST2_TL) { tl[3 * slot] = exi[FAST_P(j)]; tl[3 * slot + 1] = (b0 + ltk) | (eq << 16) | (ro << 24); tl[3 * slot + 2] = loc; }
+                                key[j] |= 0x80000000u;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                                        // (7) probing is over: ex becomes the exchange
+            F2P(6);
+            // room for the tied runs: the two returning atomics are issued now and looked at after the exchange
+            if (t == 0 && misc[4] != 0 && misc[4] <= FAST2_TL) {
+                if (misc[2]) res_t = atomicAdd(&counters[em.pool_cnt_idx], misc[2]);
+                if (misc[3]) res_s = atomicAdd(&counters[em.seg_cnt_idx], misc[3]);
+            }
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = FAST_P(j);
+                    if (p < len) {
+                        const u32 id = exi[p];
+                        ex[key[j] & 0xffffu] = id;
+                        if (mode == MODE_ISA && !(key[j] >> 31)) isa[id] = rank0 + sa_off + key[j] + 1u;
+                    }
+                }
+            __syncthreads();                                                        // (8)
+            F2P(7);
+            const u32 nt = misc[4];
+            if (t == 0 && nt != 0 && nt <= FAST2_TL) {
+                u32 bad = 0;
+                if ((u64)res_t + misc[2] > em.pool_cap) { atomicOr(&counters[C_ERR], 32u); bad = 1; }
+                if ((u64)res_s + misc[3] > em.seg_cap) { atomicOr(&counters[C_ERR], 64u); bad = 1; }
+                misc[6] = res_t; misc[7] = res_s; misc[8] = bad;
+            }
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = FAST_P(j);
+                    if (p < len) *reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(sa_out + sa_off) + p * 4u) = ex[p];
+                }
+            if (nt > FAST2_TL) ok = false;                       // too many ties for the list: k_sort_mid redoes the segment
+            else if (nt) {                                       // block-uniform
+                __syncthreads();                                 // rows are out: ex[run start] now carries the run's local offset
+                for (u32 i = t; i < nt; i += THREADS) { const u32 w1 = tl[3 * i + 1]; if ((w1 >> 24) == 0) ex[w1 & 0xffffu] = tl[3 * i + 2]; }
+                __syncthreads();
+                if (!misc[8]) {
+                    const u32 base_t = misc[6], base_s = misc[7];
+                    for (u32 i = t; i < nt; i += THREADS) {
+                        const u32 id = tl[3 * i], w1 = tl[3 * i + 1];
+                        const u32 rs = w1 & 0xffffu, rl = (w1 >> 16) & 255u, ro = w1 >> 24;
+                        if (mode == MODE_ISA) isa[id] = rank0 + sa_off + rs + 1u;
+                        if (rl <= TINY_MAX) {
+                            const u32 o = base_t + ex[rs] + ro;
+                            em.pool_rec[o] = (u64)id;
+                            em.pool_hdr[o] = pack_hdr(sa_off + rs, rl, ro);
+                        } else {
+                            const u32 o = base_s + ex[rs] + ro;
+                            em.seg_rec[o] = (u64)id;
+                            if (ro == 0) { const Desc nd = {o, rl, sa_off + rs, em.seg_buf}; push_desc(em.lists, counters, class_of(rl), nd); }
+                        }
+                    }
+                }
+            }
+        }
+        F2P(8);
+        if (early_exit) F2_LOAD(4 * LB, ITEMS);
+        if (!ok && len != 0 && t == 0) fb_list[atomicAdd(&counters[fb_cnt_idx], 1u)] = cur;   // leave it to k_sort_mid
+        if (!more) break;
+        __syncthreads();            // everyone is done with this segment's LDS before it is reset
+        F2P(9);
+    }
+#ifdef FAST2_PROF
+    if (threadIdx.x == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_fast2_prof[i], prof_acc[i]);
+#endif
+#undef FAST_P
+#undef FAST_BIN
+#undef FAST_SRC
+#undef F2_LOAD
+}
+
+template <int THREADS, int ITEMS, int BITS>
+constexpr size_t sort_fast2_lds_bytes()
+{
+    return ((size_t)THREADS * ITEMS * 2 + 64 + 3 * FAST2_TL + 16 + 16) * 4;
 }
 
 template <int THREADS, int ITEMS, int BITS>
