@@ -122,6 +122,10 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 T)
     return ((q / T) * 8u + x) * T + (q % T);
 }
 
+// 16-byte records pairs.  Vector-memory instructions are what a CU runs out of first in the scatter kernels, so
+// neighbouring records travel together wherever they can: one dwordx4 per lane instead of two dwordx2.
+struct __attribute__((aligned(8))) Rec2 { u64 a, b; };
+
 __device__ __forceinline__ u32 wave_excl_scan(u32 v, u32& total)
 {
     u32 x = v;
@@ -417,8 +421,8 @@ __global__ __launch_bounds__(128) void k_stripes(const u32* __restrict__ sums, u
 __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ text, u32 m, u32 klo, u32 khi, u32 chunk_len,
                                                          u32* __restrict__ cursor0, u64* __restrict__ out)
 {
-    __shared__ u64 stage[P1_TILE];
-    __shared__ u8 sbin[P1_TILE];
+    __shared__ __attribute__((aligned(16))) u64 stage[P1_TILE];
+    __shared__ __attribute__((aligned(16))) u8 sbin[P1_TILE];
     __shared__ u32 hist[256], lstart[256], gbase[256];
     __shared__ u32 s_total;
     const u32 t = threadIdx.x;
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
                                                           u32* __restrict__ cursor, const u32* __restrict__ trivial,
                                                           u32 alt0, u32 alt1, u32 alt2)
 {
-    __shared__ u64 stage[P1_TILE];
+    __shared__ __attribute__((aligned(16))) u64 stage[P1_TILE];
     __shared__ u32 hist[256], lstart[256], gbase[256];
     __shared__ u32 s_seg, s_total;
     const u32 t = threadIdx.x;
@@ -555,13 +559,16 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
     u64* dst = bufs.p[alt];
     u64 rec[P1_ITEMS];
     u32 rank[P1_ITEMS];
+    static_assert(P1_ITEMS % 2 == 0, "records are read in pairs");
 #pragma unroll
-    for (int j = 0; j < P1_ITEMS; ++j) {
-        const u32 p = off + j * P1_THREADS + t;
-        rec[j] = 0; rank[j] = 0xffffffffu;
+    for (int j = 0; j < P1_ITEMS; j += 2) {                  // items j, j+1 = records 2 (j/2 * THREADS + t) and the next one
+        const u32 p = off + 2u * ((u32)(j / 2) * P1_THREADS + t);
+        rec[j] = 0; rec[j + 1] = 0; rank[j] = 0xffffffffu; rank[j + 1] = 0xffffffffu;
         if (p < d.len) {
-            rec[j] = src[p];
+            const Rec2 v = *reinterpret_cast<const Rec2*>(src + p);      // (may read one record past the segment)
+            rec[j] = v.a; rec[j + 1] = v.b;
             rank[j] = atomicAdd(&hist[(u32)(rec[j] >> (32 + shift)) & 255u], 1u);
+            if (p + 1 < d.len) rank[j + 1] = atomicAdd(&hist[(u32)(rec[j + 1] >> (32 + shift)) & 255u], 1u);
         }
     }
     __syncthreads();
@@ -1400,9 +1407,7 @@ __device__ unsigned long long g_fast2_prof[16];
 #endif
 #define FAST2_TL 768u
 #ifndef FAST2_C_ITEMS
-#define FAST2_C_ITEMS 17     // rows per thread of the class-C instance: 17,408 records (a two-byte bucket of 1 GiB of random
-                             // bytes holds 16,384 +- 128); one row fewer than the class limit buys the registers that
-                             // keep the compiler from spilling into the prefetch
+#define FAST2_C_ITEMS CLS_C_ITEMS    // records per thread of the class-C instance (even: they are loaded in pairs)
 #endif
 template <int THREADS, int ITEMS, int BITS>
 __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
@@ -1425,9 +1430,13 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
     u32* tot = tl + 3 * FAST2_TL;                               // 16
     u32* misc = tot + 16;                                       // 16
 
-    // rows of 64 consecutive records are dealt round-robin to the waves: row j of this thread is position j * THREADS + t
+    // Every lane owns PAIRS of neighbouring records: items 2q, 2q+1 of thread t are positions 2 (q THREADS + t) and
+    // the next one, so records arrive as 16-byte loads and indices move through LDS as 8-byte accesses (half the
+    // vector-memory instructions of an 8-byte-per-lane layout; their issue rate is what the CU runs out of first).
+    static_assert(ITEMS % 2 == 0, "items come in pairs");
+    constexpr int NL = ITEMS / 2;
     u32 t = threadIdx.x;
-#define FAST_P(j) ((u32)(j) * (u32)THREADS + t)
+#define FAST_P(j) (((((u32)(j) >> 1) * (u32)THREADS + t) << 1) + ((u32)(j) & 1u))
 #define FAST_BIN(g) ((((g) & (u32)(E - 1)) * (u32)THREADS) | ((g) / (u32)E))
     u32 seg = blockIdx.x;
     if (seg >= nseg) return;
@@ -1442,7 +1451,11 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
         // offset is clamped instead
         const unsigned char* src = FAST_SRC(d);
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { const u32 p = FAST_P(j); nrec[j] = *reinterpret_cast<const u64*>(src + (p < d.len ? p * 8u : 0u)); }
+        for (int q = 0; q < NL; ++q) {
+            const u32 p = FAST_P(2 * q);
+            const Rec2 v = *reinterpret_cast<const Rec2*>(src + (p < d.len ? p * 8u : 0u));    // (may read one record past the segment)
+            nrec[2 * q] = v.a; nrec[2 * q + 1] = v.b;
+        }
     }
     const u32 rank0 = counters[C_RANK0];
 #ifdef FAST2_PROF
@@ -1468,13 +1481,13 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
         // they are issued three rows at a time, one batch behind each phase of the sort (F2_LOAD).
         const unsigned char* nsrc = FAST_SRC(d);
         const u32 nlen = more ? d.len : 0u;
-#define F2_LOAD(from, upto) do { _Pragma("unroll") for (int j_ = (from); j_ < (upto) && j_ < ITEMS; ++j_) { const u32 p_ = FAST_P(j_); nrec[j_] = *reinterpret_cast<const u64*>(nsrc + (p_ < nlen ? p_ * 8u : 0u)); } } while (0)
-        constexpr int LB = (ITEMS + 5) / 6;                      // rows per batch, six batches
+#define F2_LOAD(from, upto) do { _Pragma("unroll") for (int q_ = (from); q_ < (upto) && q_ < NL; ++q_) { const u32 p_ = FAST_P(2 * q_); const Rec2 v_ = *reinterpret_cast<const Rec2*>(nsrc + (p_ < nlen ? p_ * 8u : 0u)); nrec[2 * q_] = v_.a; nrec[2 * q_ + 1] = v_.b; } } while (0)
+        constexpr int LB = (NL + 5) / 6 > 1 ? (NL + 5) / 6 : 2;  // pair loads per batch, up to six batches
         F2_LOAD(0, LB);
         dn = list[seg + gridDim.x < nseg ? seg + gridDim.x : nseg - 1u];
         F2P(0);
-        const u32 nrows = (len + 63u) >> 6;
-        const int rows = nrows > wv ? (int)((nrows - wv + W - 1) / W) : 0;
+        const u32 nrows = (len + 127u) >> 7;                     // a wave covers 128 consecutive positions per pair load
+        const int rows = 2 * (nrows > wv ? (int)((nrows - wv + W - 1) / W) : 0);     // items of this wave that can be inside the segment
         const u32 kmask = kbits >= 32 ? 0xffffffffu : ((1u << kbits) - 1u);
         const u32 sh = kbits > (u32)BITS ? kbits - BITS : 0u;
         bool ok = kbits <= 26u && len != 0 && len <= (u32)CAP;   // (longer class members go to k_sort_mid)
@@ -1561,7 +1574,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
                 }
             __syncthreads();                                                        // (6)
             F2P(5);
-            F2_LOAD(5 * LB, ITEMS);
+            F2_LOAD(5 * LB, NL);
             // ---- phase 6: final rows, exchange, output
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
@@ -1620,12 +1633,20 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
                 if ((u64)res_s + misc[3] > em.seg_cap) { atomicOr(&counters[C_ERR], 64u); bad = 1; }
                 misc[6] = res_t; misc[7] = res_s; misc[8] = bad;
             }
+            {   // rows out, 8 bytes per lane at 8-byte aligned addresses: lane pairs start at an even ROW of the array
+                const u32 shift = sa_off & 1u;
+                u32* outp = sa_out + sa_off;
+                if (shift && t == 0) outp[0] = ex[0];
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-                if (j < rows) {
-                    const u32 p = FAST_P(j);
-                    if (p < len) *reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(sa_out + sa_off) + p * 4u) = ex[p];
-                }
+                for (int q = 0; q < NL; ++q)
+                    if (2 * q < rows) {
+                        const u32 p = FAST_P(2 * q) + shift;
+                        if (p + 1 < len) {
+                            uint2 v; v.x = ex[p]; v.y = ex[p + 1];
+                            *reinterpret_cast<uint2*>(outp + p) = v;
+                        } else if (p < len) outp[p] = ex[p];
+                    }
+            }
             if (nt > FAST2_TL) ok = false;                       // too many ties for the list: k_sort_mid redoes the segment
             else if (nt) {                                       // block-uniform
                 __syncthreads();                                 // rows are out: ex[run start] now carries the run's local offset
@@ -1651,7 +1672,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
             }
         }
         F2P(8);
-        if (early_exit) F2_LOAD(4 * LB, ITEMS);
+        if (early_exit) F2_LOAD(4 * LB, NL);
         if (!ok && len != 0 && t == 0) fb_list[atomicAdd(&counters[fb_cnt_idx], 1u)] = cur;   // leave it to k_sort_mid
         if (!more) break;
         __syncthreads();            // everyone is done with this segment's LDS before it is reset
