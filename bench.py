@@ -150,7 +150,7 @@ def main():
             "k_hist16": (avg("hist16_ms"), n),
             "k_scatter0": (avg("scatter0_ms"), n + 8 * m),
             "k_partition(level 1)": (avg("scatter1_ms"), 16 * m),
-            "k_sort_fast(bucket sort)": (avg("bucket_sort_ms"), 12 * m),
+            "k_sort_fast2(bucket sort)": (avg("bucket_sort_ms"), 12 * m),
         }
         dom = max(kern, key=lambda k: kern[k][0])
         dms, dbytes = kern[dom]
@@ -183,6 +183,9 @@ def main():
             "radix_pass": {"read_bytes": 2 * n, "ms": round(radix_ms, 4),
                            "read_frac_of_hbm_peak": round((2 * n / (radix_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4) if radix_ms > 0 else None},
             "end_to_end": {"compulsory_bytes": 5 * n + 4, "frac_of_hbm_peak": round(((5 * n + 4) / (dt / K) / 1e9) / HBM_PEAK_GBS, 5)},
+            "kernels": {k: {"ms": round(v[0], 4), "algorithmic_GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None,
+                            "frac_of_hbm_peak": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[0] > 0 else None}
+                        for k, v in kern.items()},
             "phases_ms": {k: round(v[0], 4) for k, v in kern.items()} | {"refine": round(avg("refine_ms"), 4), "device_total": round(avg("total_ms"), 4)},
         }
         if not args.no_cpu and world == 1:

@@ -97,12 +97,10 @@ struct msufsort_hip_ctx {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast2_lds_bytes<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast<FAST_C_THREADS, FAST_C_ITEMS, FAST_BITS_C, FAST_C_PREFETCH>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast_lds_bytes<FAST_C_THREADS, FAST_C_ITEMS, FAST_BITS_C>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast<CLS_B_THREADS, CLS_B_ITEMS, 12, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast2_lds_bytes<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast2<CLS_B_THREADS, CLS_B_ITEMS, 12, FAST2_TL_B>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast2_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12, FAST2_TL_B>()));
         attrs_set = true;
         return MSUFSORT_HIP_OK;
     }
@@ -456,13 +454,8 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         if (nC) {
             const u32* ids = nullptr;
             if (use_fast) {
-#ifdef FAST_OLD_C
-                k_sort_fast<FAST_C_THREADS, FAST_C_ITEMS, FAST_BITS_C, FAST_C_PREFETCH><<<dim3(std::min<u32>(nC, 256u)), dim3(FAST_C_THREADS), sort_fast_lds_bytes<FAST_C_THREADS, FAST_C_ITEMS, FAST_BITS_C>(), st>>>(
+                k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_fast2_lds_bytes<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C>(), st>>>(
                     bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneC.as<u32>(), (u32)C_FBC);
-#else
-                k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_fast2_lds_bytes<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C>(), st>>>(
-                    bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneC.as<u32>(), (u32)C_FBC);
-#endif
                 DBG("k_sort_fast C");
 #ifdef FAST2_PROF
                 {
@@ -485,7 +478,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         if (nB) {
             const u32* ids = nullptr;
             if (use_fast) {
-                k_sort_fast<CLS_B_THREADS, CLS_B_ITEMS, 12, true><<<dim3(std::min<u32>(nB, 256u * 4u)), dim3(CLS_B_THREADS), sort_fast_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12>(), st>>>(
+                k_sort_fast2<CLS_B_THREADS, CLS_B_ITEMS, 12, FAST2_TL_B><<<dim3(std::min<u32>(nB, 256u * 4u)), dim3(CLS_B_THREADS), sort_fast2_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12, FAST2_TL_B>(), st>>>(
                     bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneB.as<u32>(), (u32)C_FBB);
                 DBG("k_sort_fast B");
                 ids = c->doneB.as<u32>();

@@ -65,15 +65,6 @@ enum {
 #define CLS_B_ITEMS 18       // <= 4608
 #define CLS_C_THREADS 1024
 #define CLS_C_ITEMS 18       // <= 18432
-// k_sort_fast's own shape for class C: half the threads, twice the rows per thread - 8 waves per CU may use 256
-// VGPRs each, which is what it takes to keep the NEXT segment's records in flight while this one is sorted
-#ifndef FAST_C_THREADS
-#define FAST_C_THREADS 1024
-#endif
-#define FAST_C_ITEMS (CLS_C_THREADS * CLS_C_ITEMS / FAST_C_THREADS)
-#ifndef FAST_C_PREFETCH
-#define FAST_C_PREFETCH false
-#endif
 #define CAP_A (CLS_A_THREADS * CLS_A_ITEMS)
 #define CAP_B (CLS_B_THREADS * CLS_B_ITEMS)
 #define CAP_C (CLS_C_THREADS * CLS_C_ITEMS)
@@ -1138,6 +1129,20 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 //      runs are compacted for the next round.
 // Needs kbits <= 26 (composite in 32 bits) and no sub-bucket above FAST_LIMIT (r < 64); other segments are
 // handed back to k_sort_mid through fb_list.
+//
+// Register budget = memory/compute overlap.  A CU running 1024 threads gives each 128 VGPRs.  Key, index, base,
+// row and run information of 18 records per thread would fill them, leave nothing to keep the NEXT segment's
+// records in flight, and make every CU alternate between a memory phase and a compute phase of about the same
+// length.  So
+//   - suffix indices wait in LDS (exi[source position], written and read by the same thread), not in registers,
+//   - the sub-bucket table shares its LDS with the composite array (it is dead once every row holds its base),
+//   - base, size and arrival rank share one register per record; the composite is read back from LDS by its owner,
+//   - run information exists only for the few records that need it: they are pushed to a small tie list in LDS,
+// which leaves room for the next segment's records: their loads are issued a few at a time behind the barriers of
+// the sort (a CU accepts vector-memory instructions slowly; eighteen back to back stall every wave) and arrive
+// while this segment is sorted.  Records travel as 16-byte pairs, rows leave as aligned 8-byte stores.
+// Segments with more than TL tied records go back to k_sort_mid (after their rows have been written once).
+// Diagnostic build: -DFAST2_PROF accumulates clock64() per phase (printed by the engine after the launch).
 // ------------------------------------------------------------------------------------------------
 #define FAST_LIMIT 48u
 #ifndef FAST_PROBE
@@ -1146,270 +1151,18 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 #ifndef FAST_BITS_C
 #define FAST_BITS_C 14
 #endif
-template <int THREADS, int ITEMS, int BITS, bool PREFETCH>
-__global__ __launch_bounds__(THREADS) void k_sort_fast(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
-                                                       u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
-                                                       Emit em, u32* __restrict__ counters, u32* __restrict__ fb_list, u32 fb_cnt_idx)
-{
-    constexpr int CAP = THREADS * ITEMS;
-    constexpr int W = THREADS / 64;
-    constexpr int NBIN = 1 << BITS;
-    constexpr int E = NBIN / THREADS;
-    constexpr u32 TRASH_POS = CAP + 32;       // ex slot that absorbs the lanes past the end of the segment
-    constexpr u32 TRASH_BIN = NBIN + 1;
-    // sub-bucket g lives at hist[FAST_BIN(g)]: thread t scans the E consecutive sub-buckets t*E .. t*E+E-1, which
-    // this map puts at addresses k*THREADS + t - consecutive lanes touch consecutive words (no bank conflicts in
-    // the scan; a straight layout would put a whole wave on two banks)
-    static_assert((E & (E - 1)) == 0 && (THREADS & (THREADS - 1)) == 0, "power-of-two shapes");
-#define FAST_BIN(g) ((((g) & (u32)(E - 1)) * (u32)THREADS) | ((g) / (u32)E))
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP + 64
-    u32* hist = ex + CAP + 64;                                  // NBIN + 16
-    u32* tot = hist + NBIN + 16;                                // 16
-    u32* misc = tot + 16;                                       // 16
-
-    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
-    // rows of 64 consecutive records are dealt round-robin to the waves (row = j * W + wave): every wave
-    // gets the same number of rows whatever the segment length, and global accesses stay coalesced per row
-#define FAST_P(j) ((((u32)(j) * W + wv) << 6) + lane)
-    u32 seg = blockIdx.x;
-    if (seg >= nseg) return;
-    Desc d = list[seg];
-    u64 nrec[ITEMS];
-    {
-        const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { const u32 p = FAST_P(j); nrec[j] = p < d.len ? src[p] : ~0ull; }
-    }
-    const u32 rank0 = counters[C_RANK0];
-    for (;;) {
-        const u32 len = d.len, sa_off = d.sa_off, cur = seg, kbits = (d.buf >> 8) & 255u;
-        u32 key[ITEMS], idx[ITEMS];       // key[] turns into the composite after the atomics
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { key[j] = (u32)(nrec[j] >> 32); idx[j] = (u32)nrec[j]; }
-        seg += gridDim.x;
-        const bool more = seg < nseg;
-        bool fetched = false;
-        const u32 nrows = (len + 63u) >> 6;
-        const int rows = nrows > wv ? (int)((nrows - wv + W - 1) / W) : 0;      // <= ITEMS because len <= CAP
-        const u32 kmask = kbits >= 32 ? 0xffffffffu : ((1u << kbits) - 1u);
-        const u32 sh = kbits > (u32)BITS ? kbits - BITS : 0u;
-        bool ok = kbits <= 26u && len != 0;                      // block-uniform (len 0 = neutral list entry)
-#ifdef FAST_EXP_MEMONLY
-        if (ok) {
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) if (j < rows) { const u32 p = FAST_P(j); if (p < len) sa_out[sa_off + p] = idx[j] + (key[j] & 1); }
-            ok = false;
-            if (!more) break;
-            d = list[seg];
-            const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) { const u32 p = FAST_P(j); nrec[j] = p < d.len ? src[p] : ~0ull; }
-            continue;
-        }
-#endif
-
-        if (ok) {
-            if (t < 16) misc[t] = 0;
-            {
-                uint4* h4 = reinterpret_cast<uint4*>(hist);
-                const uint4 z4 = {0u, 0u, 0u, 0u};
-                for (u32 i = t; i < ((u32)NBIN + 16u) / 4u; i += THREADS) h4[i] = z4;
-            }
-            if (t < 64) ex[len + t] = 0xffffffffu;               // inert tail for the probes (len + 63 < CAP + 64)
-            __syncthreads();                                                        // (1)
-            bool skew = false;
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-                if (j < rows) {
-                    const u32 p = FAST_P(j);
-                    const u32 k = key[j] & kmask;
-                    const u32 g = k >> sh;
-                    const u32 r = atomicAdd(&hist[p < len ? FAST_BIN(g) : TRASH_BIN], 1u);
-                    skew |= (p < len) & (r >= FAST_LIMIT);
-                    key[j] = p < len ? ((k << 6) | (r & 63u)) : 0xffffffffu;      // composite (r < 64 is checked below)
-                }
-            if (__syncthreads_or(skew)) ok = false;                                 // (2) a sub-bucket is too long: hand back now
-        }
-        if (ok) {
-            {   // exclusive scan over the sub-buckets in key order, E consecutive ones per thread; each word becomes
-                // base | count << 16; block max of the counts
-                u32 sum = 0, mx = 0;
-#pragma unroll
-                for (int k = 0; k < E; ++k) { const u32 c = hist[k * THREADS + t]; sum += c; mx = c > mx ? c : mx; }
-                u32 wt;
-                u32 e = wave_excl_scan(sum, wt);
-#pragma unroll
-                for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(mx, s2, 64); mx = o > mx ? o : mx; }
-                if (lane == 63) tot[wv] = wt;
-                if (lane == 0) atomicMax(&misc[1], mx);
-                __syncthreads();                                                    // (3)
-                u32 wb = 0;
-#pragma unroll
-                for (int k = 0; k < W; ++k) if (k < (int)wv) wb += tot[k];
-                e += wb;
-#pragma unroll
-                for (int k = 0; k < E; ++k) { const u32 c = hist[k * THREADS + t]; hist[k * THREADS + t] = e | (c << 16); e += c; }
-            }
-            __syncthreads();                                                        // (4)
-            ok = misc[1] <= FAST_LIMIT;
-        }
-        if (ok) {
-            // bc[] = sub-bucket base | sub-bucket size << 16 : fetched once, all rows in flight, used twice
-            u32 bc[ITEMS];
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                bc[j] = 0;
-                if (j < rows) {
-                    const u32 c = key[j];
-                    const bool v = c != 0xffffffffu;
-                    const u32 dg = v ? (c >> (6 + sh)) : 0u;
-                    bc[j] = hist[FAST_BIN(dg)];
-                    ex[v ? (bc[j] & 0xffffu) + (c & 63u) : TRASH_POS] = c;
-                }
-            }
-            __syncthreads();                                                        // (5)
-            // pos[] = final row (bit 31: needs the slow path); straight-line probes, no branches
-            u32 pos[ITEMS];
-            bool anyslow = false;
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                pos[j] = TRASH_POS;
-                if (j < rows) {
-                    const u32 me = key[j], b0 = bc[j] & 0xffffu;
-                    u32 lt = 0, eq = 0;
-#pragma unroll
-#ifdef FAST_EXP_PROBES
-                    for (int q = 0; q < FAST_EXP_PROBES; ++q) { const u32 c = ex[b0 + q]; lt += c < me; eq += (c ^ me) < 64u; }
-#else
-                    for (int q = 0; q < FAST_PROBE; ++q) { const u32 c = ex[b0 + q]; lt += c < me; eq += (c ^ me) < 64u; }
-#endif
-                    const bool v = me != 0xffffffffu;
-                    const bool slow = v && ((bc[j] >> 16) > FAST_PROBE || eq > 1);
-                    anyslow |= slow;
-                    if (v) pos[j] = (b0 + lt) | (slow ? 0x80000000u : 0u);
-                }
-            }
-            // info[] = run start (16 bits) | run length << 16 | my offset << 24 ; rare: long sub-bucket or equal keys
-            u32 info[ITEMS];
-            bool tie = false;
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                info[j] = (pos[j] & 0xffffu) | (1u << 16);
-                if (j < rows && __ballot(pos[j] >> 31)) {
-                    if (pos[j] >> 31) {
-                        const u32 me = key[j], b0 = bc[j] & 0xffffu, b1 = b0 + (bc[j] >> 16);
-                        u32 lt = 0, eq = 0, ltk = 0;
-#pragma nounroll
-                        for (u32 q = b0; q < b1; ++q) { const u32 c = ex[q]; lt += c < me; eq += (c ^ me) < 64u; ltk += (c >> 6) < (me >> 6); }
-                        pos[j] = b0 + lt;
-                        info[j] = (b0 + ltk) | (eq << 16) | ((lt - ltk) << 24);
-                        tie |= eq > 1;
-                    }
-                }
-            }
-            (void)anyslow;
-            // composites are dead from here on: prefetch the next segment of this workgroup
-            if (PREFETCH && more) {
-                d = list[seg];
-                const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
-#pragma unroll
-                for (int j = 0; j < ITEMS; ++j) { const u32 p = FAST_P(j); nrec[j] = p < d.len ? src[p] : ~0ull; }
-                fetched = true;
-            }
-            __syncthreads();                                                        // (6)
-#ifndef FAST_EXP_NOEXCH
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[pos[j]] = idx[j];
-            __syncthreads();                                                        // (7)
-#endif
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-                if (j < rows) {
-                    const u32 p = FAST_P(j);
-                    if (p < len) {
-#ifndef FAST_EXP_NOEXCH
-                        sa_out[sa_off + p] = ex[p];
-#else
-                        sa_out[sa_off + p] = idx[j] + (pos[j] & 1);
-#endif
-                        if (mode == MODE_ISA) isa[idx[j]] = rank0 + sa_off + (info[j] & 0xffffu) + 1u;
-                    }
-                }
-            if (__syncthreads_or(tie)) {                                            // (8)
-                // compact still-tied runs: run leader (offset 0) reserves room, members follow
-#pragma unroll
-                for (int j = 0; j < ITEMS; ++j) {
-                    const u32 rl = (info[j] >> 16) & 255u;
-                    if (j < rows && rl > 1 && (info[j] >> 24) == 0)
-                        ex[info[j] & 0xffffu] = atomicAdd(&misc[rl <= TINY_MAX ? 2 : 3], rl);
-                }
-                __syncthreads();
-                if (t == 0) {
-                    u32 bt = 0, bs = 0, bad = 0;
-                    const u32 tt = misc[2], ts = misc[3];
-                    if (tt) { bt = atomicAdd(&counters[em.pool_cnt_idx], tt); if ((u64)bt + tt > em.pool_cap) { atomicOr(&counters[C_ERR], 32u); bad = 1; } }
-                    if (ts) { bs = atomicAdd(&counters[em.seg_cnt_idx], ts); if ((u64)bs + ts > em.seg_cap) { atomicOr(&counters[C_ERR], 64u); bad = 1; } }
-                    misc[6] = bt; misc[7] = bs; misc[8] = bad;
-                }
-                __syncthreads();
-                if (!misc[8]) {
-                    const u32 base_t = misc[6], base_s = misc[7];
-#pragma unroll
-                    for (int j = 0; j < ITEMS; ++j) {
-                        const u32 rs = info[j] & 0xffffu, rl = (info[j] >> 16) & 255u, ro = info[j] >> 24;
-                        if (j < rows && rl > 1) {
-                            if (rl <= TINY_MAX) {
-                                const u32 o = base_t + ex[rs] + ro;
-                                em.pool_rec[o] = (u64)idx[j];
-                                em.pool_hdr[o] = pack_hdr(sa_off + rs, rl, ro);
-                            } else {
-                                const u32 o = base_s + ex[rs] + ro;
-                                em.seg_rec[o] = (u64)idx[j];
-                                if (ro == 0) { const Desc nd = {o, rl, sa_off + rs, em.seg_buf}; push_desc(em.lists, counters, class_of(rl), nd); }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (!ok && len != 0 && t == 0) fb_list[atomicAdd(&counters[fb_cnt_idx], 1u)] = cur;   // leave it to k_sort_mid
-        if (!more) break;
-        __syncthreads();            // everyone is done with misc[]/hist[]/ex[] of this segment before they are reset
-        if (!fetched) {
-            d = list[seg];
-            const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) { const u32 p = FAST_P(j); nrec[j] = p < d.len ? src[p] : ~0ull; }
-        }
-    }
-#undef FAST_P
-#undef FAST_BIN
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_sort_fast2: the same sort with the register budget turned into memory/compute overlap.  One workgroup of 1024
-// threads per CU may use 128 VGPRs; k_sort_fast spends them on key, index, base, row and run info of 18 rows and
-// has none left to keep the NEXT segment's records in flight, so every CU alternates between a memory phase and a
-// compute phase of about the same length.  Here
-//   - suffix indices wait in LDS (exi[source position], written and read by the same thread) instead of registers,
-//   - the sub-bucket table shares its LDS with the composite array (it is dead once every row holds its base),
-//   - run information exists only for the few records that need it: they are pushed to a small tie list in LDS,
-// which leaves room for the next segment's 2 x 18 record registers: its loads are issued right after the current
-// records have been unpacked and arrive while this segment is sorted.
-// Segments with more than FAST2_TL tied records go back to k_sort_mid (after their rows have been written once).
-// ------------------------------------------------------------------------------------------------
 #ifdef FAST2_PROF
 __device__ unsigned long long g_fast2_prof[16];
 #define F2P(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); prof_acc[i] += now_ - prof_last; prof_last = now_; } } while (0)
 #else
 #define F2P(i) do { } while (0)
 #endif
-#define FAST2_TL 768u
+#define FAST2_TL_C 768       // tie-list capacity of the class-C instance
+#define FAST2_TL_B 256       // ... of the class-B instance (four workgroups per CU: 40,320 B of LDS each)
 #ifndef FAST2_C_ITEMS
 #define FAST2_C_ITEMS CLS_C_ITEMS    // records per thread of the class-C instance (even: they are loaded in pairs)
 #endif
-template <int THREADS, int ITEMS, int BITS>
+template <int THREADS, int ITEMS, int BITS, int TL>
 __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                         u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                         Emit em, u32* __restrict__ counters, u32* __restrict__ fb_list, u32 fb_cnt_idx)
@@ -1426,8 +1179,8 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
     u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP + 64: sub-bucket table, composites, index exchange
     u32* hist = ex;
     u32* exi = ex + CAP + 64;                                   // CAP: suffix index of source position p
-    u32* tl = exi + CAP;                                        // 3 * FAST2_TL: tie list {index, rs | rl << 16 | ro << 24, local offset}
-    u32* tot = tl + 3 * FAST2_TL;                               // 16
+    u32* tl = exi + CAP;                                        // 3 * (u32)TL: tie list {index, rs | rl << 16 | ro << 24, local offset}
+    u32* tot = tl + 3 * (u32)TL;                               // 16
     u32* misc = tot + 16;                                       // 16
 
     // Every lane owns PAIRS of neighbouring records: items 2q, 2q+1 of thread t are positions 2 (q THREADS + t) and
@@ -1600,7 +1353,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
                                 const u32 slot = atomicAdd(&misc[4], 1u);
                                 u32 loc = 0;
                                 if (ro == 0) loc = atomicAdd(&misc[eq <= TINY_MAX ? 2 : 3], eq);
-                                if (slot < FAST2_TL) { tl[3 * slot] = exi[FAST_P(j)]; tl[3 * slot + 1] = (b0 + ltk) | (eq << 16) | (ro << 24); tl[3 * slot + 2] = loc; }
+                                if (slot < (u32)TL) { tl[3 * slot] = exi[FAST_P(j)]; tl[3 * slot + 1] = (b0 + ltk) | (eq << 16) | (ro << 24); tl[3 * slot + 2] = loc; }
                                 key[j] |= 0x80000000u;
                             }
                         }
@@ -1610,7 +1363,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
             __syncthreads();                                                        // (7) probing is over: ex becomes the exchange
             F2P(6);
             // room for the tied runs: the two returning atomics are issued now and looked at after the exchange
-            if (t == 0 && misc[4] != 0 && misc[4] <= FAST2_TL) {
+            if (t == 0 && misc[4] != 0 && misc[4] <= (u32)TL) {
                 if (misc[2]) res_t = atomicAdd(&counters[em.pool_cnt_idx], misc[2]);
                 if (misc[3]) res_s = atomicAdd(&counters[em.seg_cnt_idx], misc[3]);
             }
@@ -1627,7 +1380,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
             __syncthreads();                                                        // (8)
             F2P(7);
             const u32 nt = misc[4];
-            if (t == 0 && nt != 0 && nt <= FAST2_TL) {
+            if (t == 0 && nt != 0 && nt <= (u32)TL) {
                 u32 bad = 0;
                 if ((u64)res_t + misc[2] > em.pool_cap) { atomicOr(&counters[C_ERR], 32u); bad = 1; }
                 if ((u64)res_s + misc[3] > em.seg_cap) { atomicOr(&counters[C_ERR], 64u); bad = 1; }
@@ -1647,7 +1400,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
                         } else if (p < len) outp[p] = ex[p];
                     }
             }
-            if (nt > FAST2_TL) ok = false;                       // too many ties for the list: k_sort_mid redoes the segment
+            if (nt > (u32)TL) ok = false;                       // too many ties for the list: k_sort_mid redoes the segment
             else if (nt) {                                       // block-uniform
                 __syncthreads();                                 // rows are out: ex[run start] now carries the run's local offset
                 for (u32 i = t; i < nt; i += THREADS) { const u32 w1 = tl[3 * i + 1]; if ((w1 >> 24) == 0) ex[w1 & 0xffffu] = tl[3 * i + 2]; }
@@ -1687,10 +1440,10 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
 #undef F2_LOAD
 }
 
-template <int THREADS, int ITEMS, int BITS>
+template <int THREADS, int ITEMS, int BITS, int TL>
 constexpr size_t sort_fast2_lds_bytes()
 {
-    return ((size_t)THREADS * ITEMS * 2 + 64 + 3 * FAST2_TL + 16 + 16) * 4;
+    return ((size_t)THREADS * ITEMS * 2 + 64 + 3 * (size_t)TL + 16 + 16) * 4;
 }
 
 template <int THREADS, int ITEMS, int BITS>
