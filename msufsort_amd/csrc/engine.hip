@@ -99,8 +99,8 @@ struct msufsort_hip_ctx {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast2_lds_bytes<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast2<CLS_B_THREADS, CLS_B_ITEMS, 12, FAST2_TL_B>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast2_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12, FAST2_TL_B>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast2<CLS_B_THREADS, CLS_B_ITEMS, FAST_BITS_B, FAST2_TL_B>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast2_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, FAST_BITS_B, FAST2_TL_B>()));
         attrs_set = true;
         return MSUFSORT_HIP_OK;
     }
@@ -320,7 +320,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         if (klo == 0) rank0 = z;
         else { HIP_TRY(hipMemcpyAsync(c->h_bstart, c->bstart.p, 65537 * 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); rank0 = z + c->h_bstart[klo]; }
         sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
-        hipLaunchKernelGGL(k_scatter0, dim3(cdiv(cdiv(m, P1_TILE), 8 * (c->chunk_len / P1_TILE)) * 8 * (c->chunk_len / P1_TILE)), dim3(S0_THREADS), 0, st, d_text, (u32)m, klo, khi, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0]);
+        hipLaunchKernelGGL(k_scatter0, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, (u32)m, klo, khi, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0]);
         HIP_TRY(hipEventRecord(c->ev[2], st));
         DBG("k_scatter0");
         hipLaunchKernelGGL(k_partition, dim3(cdiv(cdiv(m, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
@@ -478,7 +478,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         if (nB) {
             const u32* ids = nullptr;
             if (use_fast) {
-                k_sort_fast2<CLS_B_THREADS, CLS_B_ITEMS, 12, FAST2_TL_B><<<dim3(std::min<u32>(nB, 256u * 4u)), dim3(CLS_B_THREADS), sort_fast2_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, 12, FAST2_TL_B>(), st>>>(
+                k_sort_fast2<CLS_B_THREADS, CLS_B_ITEMS, FAST_BITS_B, FAST2_TL_B><<<dim3(std::min<u32>(nB, 256u * 4u)), dim3(CLS_B_THREADS), sort_fast2_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, FAST_BITS_B, FAST2_TL_B>(), st>>>(
                     bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneB.as<u32>(), (u32)C_FBB);
                 DBG("k_sort_fast B");
                 ids = c->doneB.as<u32>();

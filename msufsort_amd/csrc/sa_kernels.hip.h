@@ -79,7 +79,10 @@ enum {
 #define CUR0_STRIDE 64                       // u32 stride of the 256 first-byte cursors: one 256-B line each,
                                              // so the per-tile claim atomics spread over memory channels
 #define S0_POS 8                             // level-0 scatter: text positions per thread
-#define S0_THREADS (P1_TILE / S0_POS)
+#ifndef S0_THREADS
+#define S0_THREADS 1024
+#endif
+#define S0_TILE (S0_THREADS * S0_POS)        // text positions per workgroup
 
 #define MODE_TEXT 0
 #define MODE_ISA 1
@@ -412,12 +415,12 @@ __global__ __launch_bounds__(128) void k_stripes(const u32* __restrict__ sums, u
 __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ text, u32 m, u32 klo, u32 khi, u32 chunk_len,
                                                          u32* __restrict__ cursor0, u64* __restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) u64 stage[P1_TILE];
-    __shared__ __attribute__((aligned(16))) u8 sbin[P1_TILE];
+    __shared__ __attribute__((aligned(16))) u64 stage[S0_TILE];
+    __shared__ __attribute__((aligned(16))) u8 sbin[S0_TILE];
     __shared__ u32 hist[256], lstart[256], gbase[256];
     __shared__ u32 s_total;
     const u32 t = threadIdx.x;
-    const u64 base0 = (u64)xcd_tile(blockIdx.x, chunk_len / P1_TILE) * P1_TILE;
+    const u64 base0 = (u64)xcd_tile(blockIdx.x, chunk_len / S0_TILE) * S0_TILE;
     if (base0 >= m) return;
     const u64 base = base0 + (u64)t * S0_POS;
     if (t < 256) hist[t] = 0;
@@ -1118,7 +1121,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 // input) - the hot kernel of the whole build.  Persistent workgroups stride over the list.
 //   1. one MSD split on the top BITS of the kbits varying key bits into 2^BITS sub-buckets; the rank r
 //      inside the sub-bucket comes from a returning LDS atomic (arrival order, arbitrary);
-//   2. block-wide exclusive scan of the sub-bucket counts (+ their maximum);
+//   2. block-wide exclusive scan of the sub-bucket counts;
 //   3. every record stores the composite c = (varying key bits << 6) | r at base + r.  Composites are
 //      distinct and globally ordered like (key, r), so a record's FINAL row is base + #{c' < c} over the
 //      next FAST_PROBE slots from its sub-bucket's base - straight-line code, no loop, no predicate: slots
@@ -1146,10 +1149,13 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 // ------------------------------------------------------------------------------------------------
 #define FAST_LIMIT 48u
 #ifndef FAST_PROBE
-#define FAST_PROBE 6
+#define FAST_PROBE 5
 #endif
 #ifndef FAST_BITS_C
-#define FAST_BITS_C 14
+#define FAST_BITS_C 15      // sub-buckets of the class-C instance: 2 per record of a full segment
+#endif
+#ifndef FAST_BITS_B
+#define FAST_BITS_B 13
 #endif
 #ifdef FAST2_PROF
 __device__ unsigned long long g_fast2_prof[16];
@@ -1170,14 +1176,18 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
     constexpr int CAP = THREADS * ITEMS;
     constexpr int W = THREADS / 64;
     constexpr int NBIN = 1 << BITS;
-    constexpr int E = NBIN / THREADS;
+    // Sub-bucket table: one 8-byte entry per FOUR sub-buckets = {their counts, one byte each | base of the first}.
+    // Counts never pass FAST_LIMIT in a segment that is kept, so a byte is enough; the scan then reads an eighth of
+    // the words a count-per-word table would need.
+    constexpr int NW = NBIN / 4;
+    constexpr int EW = NW / THREADS;
     constexpr u32 TRASH_POS = CAP + 32;
-    constexpr u32 TRASH_BIN = NBIN + 1;
-    static_assert(NBIN + 16 <= CAP + 64, "the sub-bucket table must fit under the composite array");
-    static_assert((E & (E - 1)) == 0 && (THREADS & (THREADS - 1)) == 0, "power-of-two shapes");
+    constexpr u32 TRASH_W = NW;
+    static_assert(2 * NW + 16 <= CAP + 64, "the sub-bucket table must fit under the composite array");
+    static_assert((EW & (EW - 1)) == 0 && EW >= 1 && (THREADS & (THREADS - 1)) == 0, "power-of-two shapes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP + 64: sub-bucket table, composites, index exchange
-    u32* hist = ex;
+    uint2* tab = reinterpret_cast<uint2*>(ex);
     u32* exi = ex + CAP + 64;                                   // CAP: suffix index of source position p
     u32* tl = exi + CAP;                                        // 3 * (u32)TL: tie list {index, rs | rl << 16 | ro << 24, local offset}
     u32* tot = tl + 3 * (u32)TL;                               // 16
@@ -1190,7 +1200,10 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
     constexpr int NL = ITEMS / 2;
     u32 t = threadIdx.x;
 #define FAST_P(j) (((((u32)(j) >> 1) * (u32)THREADS + t) << 1) + ((u32)(j) & 1u))
-#define FAST_BIN(g) ((((g) & (u32)(E - 1)) * (u32)THREADS) | ((g) / (u32)E))
+    // table entry w lives at tab[FAST_W(w)]: thread t scans the EW consecutive entries t*EW .. t*EW+EW-1, which this map
+    // puts at k*THREADS + t - consecutive lanes touch consecutive entries (no bank conflicts in the scan)
+#define FAST_W(w) ((((w) & (u32)(EW - 1)) * (u32)THREADS) | ((w) / (u32)EW))
+#define BYTESUM(x) (((x) * 0x01010101u) >> 24)
     u32 seg = blockIdx.x;
     if (seg >= nseg) return;
     // descriptors are fetched two segments ahead and the record buffer is picked with selects, not with an indexed
@@ -1248,9 +1261,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
 
         if (ok) {                                                // ---- phase 1: clear the table
             if (t < 16) misc[t] = 0;
-            uint4* h4 = reinterpret_cast<uint4*>(hist);
+            uint4* h4 = reinterpret_cast<uint4*>(ex);
             const uint4 z4 = {0u, 0u, 0u, 0u};
-            for (u32 i = t; i < ((u32)NBIN + 16u) / 4u; i += THREADS) h4[i] = z4;
+            for (u32 i = t; i < (2u * NW + 16u) / 4u; i += THREADS) h4[i] = z4;
             F2P(11);
             __syncthreads();                                                        // (1)
             F2P(1);
@@ -1263,9 +1276,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
                 if (j < rows) {
                     const u32 p = FAST_P(j);
                     const u32 k = key[j] & kmask;
-                    const u32 g = k >> sh;
-                    const u32 r = atomicAdd(&hist[p < len ? FAST_BIN(g) : TRASH_BIN], 1u);
-                    skew |= (p < len) & (r >= FAST_LIMIT);
+                    const u32 g = k >> sh, by = (g & 3u) * 8u;
+                    const u32 r = (atomicAdd(&tab[p < len ? FAST_W(g >> 2) : TRASH_W].x, 1u << by) >> by) & 255u;
+                    skew |= (p < len) & (r >= FAST_LIMIT);                  // (a byte cannot wrap before somebody sees this)
                     key[j] = p < len ? ((k << 6) | (r & 63u)) : 0xffffffffu;
                 }
             if (skew) misc[5] = 1u;
@@ -1274,26 +1287,22 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
             F2P(2);
         }
         F2_LOAD(2 * LB, 3 * LB);
-        if (ok) {                                                // ---- phase 3: scan -> base | size << 16
-            u32 sum = 0, mx = 0;
+        if (ok) {                                                // ---- phase 3: scan -> base of every table entry
+            u32 sum = 0;
 #pragma unroll
-            for (int k = 0; k < E; ++k) { const u32 c = hist[k * THREADS + t]; sum += c; mx = c > mx ? c : mx; }
+            for (int k = 0; k < EW; ++k) sum += BYTESUM(tab[k * THREADS + t].x);
             u32 wt;
             u32 e = wave_excl_scan(sum, wt);
-#pragma unroll
-            for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(mx, s2, 64); mx = o > mx ? o : mx; }
             if (lane == 63) tot[wv] = wt;
-            if (lane == 0) atomicMax(&misc[1], mx);
             __syncthreads();                                                        // (3)
             u32 wb = 0;
 #pragma unroll
             for (int k = 0; k < W; ++k) if (k < (int)wv) wb += tot[k];
             e += wb;
 #pragma unroll
-            for (int k = 0; k < E; ++k) { const u32 c = hist[k * THREADS + t]; hist[k * THREADS + t] = e | (c << 16); e += c; }
+            for (int k = 0; k < EW; ++k) { tab[k * THREADS + t].y = e; e += BYTESUM(tab[k * THREADS + t].x); }
             __syncthreads();                                                        // (4)
             F2P(3);
-            ok = misc[1] <= FAST_LIMIT;
         }
         F2_LOAD(3 * LB, 4 * LB);
         const bool early_exit = !ok;                             // the rest is requested behind the block below (not
@@ -1306,8 +1315,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
                 bc[j] = 0;
                 if (j < rows) {
                     const u32 c = key[j];
-                    const u32 dg = c != 0xffffffffu ? (c >> (6 + sh)) : 0u;
-                    bc[j] = hist[FAST_BIN(dg)];
+                    const u32 dg = c != 0xffffffffu ? (c >> (6 + sh)) : 0u, by = (dg & 3u) * 8u;
+                    const uint2 e = tab[FAST_W(dg >> 2)];
+                    bc[j] = (e.y + BYTESUM(e.x & ((1u << by) - 1u))) | (((e.x >> by) & 255u) << 16);
                 }
             }
             __syncthreads();                                                        // (5) the table is dead: composites move in
@@ -1435,7 +1445,8 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
     if (threadIdx.x == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_fast2_prof[i], prof_acc[i]);
 #endif
 #undef FAST_P
-#undef FAST_BIN
+#undef FAST_W
+#undef BYTESUM
 #undef FAST_SRC
 #undef F2_LOAD
 }
