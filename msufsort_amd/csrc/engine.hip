@@ -155,11 +155,11 @@ struct msufsort_hip_ctx {
         cap_m = 0; cap_for_m = 0;
     }
 
-    int read_counters()
+    int read_counters(bool tolerate_overflow = false)
     {
         HIP_TRY(hipMemcpyAsync(h_counters, counters.p, C_NCOUNTERS * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (h_counters[C_ERR]) { set_error("device capacity check tripped (flags 0x%x)", h_counters[C_ERR]); return MSUFSORT_HIP_ERR_INTERNAL; }
+        if (h_counters[C_ERR] && !tolerate_overflow) { set_error("device capacity check tripped (flags 0x%x)", h_counters[C_ERR]); return MSUFSORT_HIP_ERR_INTERNAL; }
         return MSUFSORT_HIP_OK;
     }
 };
@@ -290,6 +290,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
     const bool auto_switch = !(opts && opts->text_rounds > 0) && !getenv("MSUFSORT_HIP_TEXT_ROUNDS");
     int text_rounds = (opts && opts->text_rounds > 0) ? opts->text_rounds : 24;
     u64 prev_active = 0;
+    bool exact_sticky = false;
     if (const char* e = getenv("MSUFSORT_HIP_TEXT_ROUNDS")) text_rounds = std::max(1, atoi(e));
     const u64 m = n - z;
     hipStream_t st = c->stream;
@@ -430,6 +431,16 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
             }
         }
         // ---- LDS sorts of everything that fits ----
+        // Persistent workgroups reserve output room in chunks and give up what is left of a chunk that the next
+        // request does not fit into; on inputs where every request is about as large as a chunk (e.g. a file followed
+        // by a copy of itself: every pool window stays completely tied) that waste can exceed the slack of the
+        // buffers.  The sorts only read this round's records, and what they write (rows, ranks, next round's
+        // records) is rebuilt identically by a second run, so an overflowing attempt is simply repeated with exact
+        // reservations (one global atomic per request, no waste: the live records always fit).
+        u32 nA = 0, nB = 0, nC = 0, nP = 0;
+        // once a round has overflowed, the following ones start exact while the tied set stays that large
+        if (exact_sticky && (u64)c->h_counters[cur ? C_POOL1 : C_POOL0] + c->h_counters[cur ? C_SEG1 : C_SEG0] < c->cap_m / 2) exact_sticky = false;
+        for (int attempt = exact_sticky ? 1 : 0; ; ++attempt) {
         Emit em;
         em.pool_rec = c->pool_rec[nxt].as<u64>(); em.pool_hdr = c->pool_hdr[nxt].as<u64>();
         em.seg_rec = bufs.p[nb]; em.seg_buf = DESC_BUF(32, nb);
@@ -438,12 +449,12 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         {   // chunk = what the persistent workgroups reserve per global atomic; slack <= active/16 per kernel
             const u64 act = (u64)c->h_counters[cur ? C_POOL1 : C_POOL0] + c->h_counters[cur ? C_SEG1 : C_SEG0] + (round == 0 ? m : 0);
             const u64 ch = std::min<u64>(4096, std::max<u64>(32, act / (16 * 8192)));
-            em.pool_chunk = (u32)ch; em.seg_chunk = (u32)ch;
+            em.pool_chunk = attempt == 0 ? (u32)ch : 0u; em.seg_chunk = em.pool_chunk;
         }
         em.lists = make_lists(nxt);
         const u32 base = cur ? C_LIST1 : C_LIST0;
-        const u32 nA = c->h_counters[base + 0], nB = c->h_counters[base + 1], nC = c->h_counters[base + 2];
-        const u32 nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
+        nA = c->h_counters[base + 0]; nB = c->h_counters[base + 1]; nC = c->h_counters[base + 2];
+        nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
         // k_sort_fast needs spread-out keys.  The 16-bit histogram already tells: if its largest bucket is far
         // above the mean the input is text-like and every attempt (reading the records, a serialised LDS-atomic
         // phase, rejection) would be wasted work - go straight to the LSD sort.
@@ -495,7 +506,16 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                                    em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32, em.pool_chunk, counters);
         DBG("k_sort_tiny");
         if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
-        TRY(c->read_counters());
+        TRY(c->read_counters(attempt == 0));
+        if (c->h_counters[C_ERR] == 0) break;
+        exact_sticky = true;
+        {   // attempt 0 ran out of room: forget what it reserved for the next round and go again
+            if (verbose) fprintf(stderr, "[msufsort_hip] round %d: reservation slack exhausted (flags 0x%x), repeating with exact reservations\n", round, c->h_counters[C_ERR]);
+            const u32 nP_ = nxt ? C_POOL1 : C_POOL0, nS_ = nxt ? C_SEG1 : C_SEG0, nL_ = nxt ? C_LIST1 : C_LIST0;
+            hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << nP_) | (1u << nS_) | (0x7u << nL_) | (1u << C_ERR));
+        }
+        }
+
         const u32 nb_base = nxt ? C_LIST1 : C_LIST0;
         const u64 actP = c->h_counters[nxt ? C_POOL1 : C_POOL0], actS = c->h_counters[nxt ? C_SEG1 : C_SEG0];
         if (verbose)

@@ -229,3 +229,33 @@ def test_large_random_properties(M):
     inv = torch.empty(n, dtype=torch.uint8, device="cuda")
     ctx.inverse_bwt(bwt, n, sent, inv)
     assert torch.equal(inv, d[:n])
+
+
+@pytest.mark.parametrize("n_unique,copies,extra", [
+    (1 << 25, 2, 0),        # 64 MiB: every suffix of the first half has a twin -> every class-B bucket overflows the tie list
+    ((1 << 26) - 12345, 1, 1 << 20),   # 65 MiB with one repeated MiB: a few ties per bucket (tie list in use, no overflow)
+    (3 << 26, 2, 0),        # 384 MiB: the same with class-C buckets (hand-back to the LSD sort after the rows were written once)
+])
+def test_bucket_sort_tie_paths(M, n_unique, copies, extra):
+    """k_sort_fast2's tie list: sparse ties, and more ties than the list holds (segment handed back to k_sort_mid).
+    Checked with the on-device checker (order by rank + permutation), which is exact."""
+    import torch
+    base = gen.random_bytes(n_unique, 77)
+    parts = [base] * copies
+    if extra:
+        parts.append(base[12345:12345 + extra])
+    t = np.concatenate(parts)
+    n = t.size
+    ctx = M.DeviceContext(0, n)
+    d = _dev(M, t)
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, n, sa)
+    assert ctx.validate_sa(d, n, sa) == 0
+    if copies == 2:
+        # suffix i of the second copy is a proper prefix of suffix i of the first: it sorts immediately before it
+        isa = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        isa[sa.long()] = torch.arange(n + 1, device="cuda")
+        i = torch.randint(0, n_unique, (4096,), device="cuda")
+        assert bool((isa[i + n_unique] < isa[i]).all())
+    del sa, d
+    torch.cuda.empty_cache()
