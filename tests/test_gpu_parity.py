@@ -259,3 +259,36 @@ def test_bucket_sort_tie_paths(M, n_unique, copies, extra):
         assert bool((isa[i + n_unique] < isa[i]).all())
     del sa, d
     torch.cuda.empty_cache()
+
+
+def _fib(n):
+    a, b = np.array([98], np.uint8), np.array([97], np.uint8)
+    while b.size < n:
+        a, b = b, np.concatenate([b, a])
+    return b[:n].copy()
+
+
+@pytest.mark.parametrize("kind", ["copies3", "text_copy", "fibonacci", "skew99", "zero_runs", "ff_runs", "tiled"])
+def test_adversarial_inputs(M, oracle_mod, kind):
+    """Repeats at every scale and degenerate alphabets, bit-exact against the reference (or the oracle restatement)."""
+    n = 1 << 18
+    r = gen.random_bytes(n, 5)
+    if kind == "copies3":
+        t = np.concatenate([r[: n // 3]] * 3)
+    elif kind == "text_copy":
+        x = gen.text_bytes(n // 2, 9); t = np.concatenate([x, x])
+    elif kind == "fibonacci":
+        t = _fib(n)
+    elif kind == "skew99":
+        t = np.where(r < 3, r, 97).astype(np.uint8)
+    elif kind == "zero_runs":
+        t = r.copy(); t[n // 4: n // 2] = 0; t[-(n // 16):] = 0
+    elif kind == "ff_runs":
+        t = r.copy(); t[n // 4: n // 2] = 255; t[-(n // 16):] = 255
+    else:
+        t = np.tile(gen.random_bytes(4099, 6), n // 4099 + 1)[:n].copy()
+    want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+    sa = M.make_suffix_array(t)
+    assert (sa == want).all()
+    bwt, sent = M.forward_burrows_wheeler_transform(t)
+    assert (M.reverse_burrows_wheeler_transform(bwt, sent) == t).all()
