@@ -292,3 +292,33 @@ def test_adversarial_inputs(M, oracle_mod, kind):
     assert (sa == want).all()
     bwt, sent = M.forward_burrows_wheeler_transform(t)
     assert (M.reverse_burrows_wheeler_transform(bwt, sent) == t).all()
+
+
+@pytest.mark.parametrize("kind", ["all_a", "skew", "period3", "random", "two_heavy_pairs"])
+def test_hist16_counter_wrap_paths(M, kind):
+    """k_hist16 keeps 16-bit counters: inputs whose chunks hold a key >= 65,536 times must take the recount path
+    (sub-chunks + overflow list) and still give exact counts; random input takes the optimistic path."""
+    import torch
+    n = (1 << 24) + 12345
+    r = gen.random_bytes(n, 11)
+    if kind == "all_a":
+        t = np.full(n, 65, dtype=np.uint8)
+    elif kind == "skew":
+        t = np.where((r & 3) != 0, 101, r).astype(np.uint8)
+    elif kind == "period3":
+        t = np.frombuffer((b"abc" * (n // 3 + 1))[:n], dtype=np.uint8).copy()
+    elif kind == "two_heavy_pairs":
+        t = r.copy(); t[1 << 20: 3 << 20] = 120; t[5 << 20: 5 * (1 << 20) + 200000: 2] = 7
+    else:
+        t = r
+    d = _dev(M, t)
+    ctx = M.DeviceContext(0, n)
+    h = torch.zeros(65536, dtype=torch.int32, device="cuda")
+    ctx.debug_hist16(d, n, h)
+    tp = np.concatenate([t, np.zeros(1, np.uint8)]).astype(np.uint32)
+    keys = (tp[:-1] << 8) | tp[1:]
+    z = 0
+    while z < n and t[n - 1 - z] == 0:
+        z += 1
+    want = np.bincount(keys[: n - z], minlength=65536)
+    assert (h.cpu().numpy().astype(np.int64) == want).all()
