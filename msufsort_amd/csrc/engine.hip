@@ -74,7 +74,7 @@ struct msufsort_hip_ctx {
     // workspace
     DevBuf rec[3], pool_rec[2], pool_hdr[2];
     DevBuf lists[2][3], large_round[2], lvl[2], seg0;
-    DevBuf seg0_base, stripe_sums, hist_partial, hist, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
+    DevBuf alpha, seg0_base, stripe_sums, hist_partial, hist, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
     DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, aux3, doneB, doneC;
     u32* h_counters = nullptr;   // pinned
     u32* h_bstart = nullptr;     // pinned, 65537
@@ -130,6 +130,7 @@ struct msufsort_hip_ctx {
         TRY(cursor0.ensure(128 * 256 * 4));
         TRY(seg0_base.ensure(256 * 4));
         TRY(stripe_sums.ensure(128 * 256 * 4));
+        TRY(alpha.ensure(256));
         TRY(tile_start.ensure(((size_t)std::max<u32>(large_cap, 256) + 1) * 4));
         TRY(trivial.ensure((size_t)std::max<u32>(large_cap, 256) * 4));
         TRY(hist_partial.ensure((size_t)256 * 65536 * 4));
@@ -149,7 +150,7 @@ struct msufsort_hip_ctx {
         for (auto& b : pool_rec) b.release();
         for (auto& b : pool_hdr) b.release();
         for (int s = 0; s < 2; ++s) { for (int c = 0; c < 3; ++c) lists[s][c].release(); large_round[s].release(); lvl[s].release(); }
-        seg0.release(); seg0_base.release(); stripe_sums.release(); hist_partial.release(); hist.release(); bstart.release(); child_start.release(); child_cnt.release();
+        alpha.release(); seg0.release(); seg0_base.release(); stripe_sums.release(); hist_partial.release(); hist.release(); bstart.release(); child_start.release(); child_cnt.release();
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
         cap_m = 0; cap_for_m = 0;
@@ -249,6 +250,7 @@ void run_scan(msufsort_hip_ctx* c, u32 klo, u32 khi, u64 z)
     hipLaunchKernelGGL(k_scan16, dim3(1), dim3(1024), 0, c->stream, c->hist.as<u32>(), c->bstart.as<u32>(), klo, khi,
                        c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->seg0_base.as<u32>(),
                        c->seg0.as<Desc>(), c->tile_start.as<u32>(), c->counters.as<u32>(), (u32)z);
+    hipLaunchKernelGGL(k_alphabet, dim3(1), dim3(256), 0, c->stream, c->hist.as<u32>(), c->alpha.as<u8>(), c->counters.as<u32>());
     hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks), dim3(1024), 0, c->stream, c->hist_partial.as<u32>(), c->hist_per, klo, khi, c->stripe_sums.as<u32>());
     hipLaunchKernelGGL(k_stripes, dim3(256), dim3(128), 0, c->stream, c->stripe_sums.as<u32>(), c->nchunks,
                        c->seg0_base.as<u32>(), c->cursor0.as<u32>());
@@ -334,6 +336,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
     u32 sb = 1, nb = 2;          // record buffer holding the current segments / receiving next round's
     u32 mode = MODE_TEXT;
     u64 depth = 5;               // text bytes consumed after round 0: bucket bytes 0,1 + key bytes 2,3,4
+    u32 abits = 8;               // bits per symbol of the dense alphabet code (8 = plain 4-byte windows); known after round 0
     auto make_lists = [&](int slot) {
         Lists L;
         for (int k = 0; k < 3; ++k) { L.cls[k] = c->lists[slot][k].as<Desc>(); L.cap[k] = c->list_cap[k]; }
@@ -373,9 +376,9 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         TRY(c->read_counters());
         const u64 actP = c->h_counters[C_POOL0];
         if (actP) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actP, 256), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, (u32)C_POOL0,
-                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode);
+                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), abits);
         hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(m, 256), 65536u)), dim3(256), 0, st, bufs.p[sb], counters, (u32)C_SEG0,
-                           d_text, c->isa.as<u32>(), (u32)n, depth, mode);
+                           d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), abits);
         depth *= 2; tm.doubling_rounds++; tm.rounds++;
         HIP_TRY(hipEventRecord(c->ev[1], st)); HIP_TRY(hipEventRecord(c->ev[2], st)); HIP_TRY(hipEventRecord(c->ev[3], st)); HIP_TRY(hipEventRecord(c->ev[4], st));
     }
@@ -524,6 +527,11 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                     c->h_counters[nb_base], c->h_counters[nb_base + 1], c->h_counters[nb_base + 2], c->h_counters[nb_base + 3]);
         if (round == 0) tm.unresolved_after_round0 = (int64_t)(actP + actS);
         if (actP + actS == 0) break;
+        if (round == 0 && !resume) {     // key packing for the gather rounds (k_alphabet ran with the histogram)
+            const u32 b = c->h_counters[C_ABITS];
+            abits = (b >= 2 && b < 7 && !getenv("MSUFSORT_HIP_NO_PACK")) ? b : 8u;
+            if (verbose) fprintf(stderr, "[msufsort_hip] alphabet code: %u bits per symbol -> %u symbols per key\n", b, abits < 7 ? std::min<u32>(32u / abits, 16u) : 4u);
+        }
         if (round > 200) { set_error("no convergence after %d rounds", round); return MSUFSORT_HIP_ERR_INTERNAL; }
 
         // ---- prepare next round ----
@@ -590,11 +598,11 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         }
         // refill keys of all still-tied suffixes
         if (actP) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
-                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode);
+                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), abits);
         if (actS) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actS, 1024), 65536u)), dim3(256), 0, st, bufs.p[sb], counters, curS,
-                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode);
+                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), abits);
         DBG("k_refill");
-        if (mode == MODE_TEXT) depth += 4; else { depth *= 2; tm.doubling_rounds++; }
+        if (mode == MODE_TEXT) depth += (abits < 7u ? std::min<u32>(32u / abits, 16u) : 4u); else { depth *= 2; tm.doubling_rounds++; }
         tm.rounds++;
     }
     if (d_grp_rows && !resume)

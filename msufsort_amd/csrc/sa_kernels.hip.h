@@ -54,6 +54,7 @@ enum {
     C_FBB = 22, C_FBC = 23,           // segments k_sort_fast handed back (class B / C)
     C_HMAX = 24,                      // largest 16-bit bucket of this shard (skew forecast)
     C_HNZ = 25,                       // number of non-empty 16-bit buckets (alphabet-size estimate)
+    C_ABITS = 26,                     // bits per symbol of the dense alphabet code (k_alphabet)
     C_NCOUNTERS = 32
 };
 
@@ -733,13 +734,45 @@ __global__ __launch_bounds__(P1_THREADS) void k_carry_copy(RecBufs bufs, const D
 }
 
 // ------------------------------------------------------------------------------------------------
-// Key refill for the next round (get_value, cpp:129-143): key = big-endian 4-byte window of the text at
-// depth `d`, zero beyond the end; in prefix-doubling rounds key = rank of suffix index + h (0 past n).
+// Dense alphabet code.  Texts over small alphabets (DNA, plain ASCII) waste most of a 4-byte key window: with an
+// order-preserving code of `bits` bits per symbol one 32-bit key holds 32 / bits symbols instead of 4, so every
+// key-gather round resolves that many more characters per random text access.  code(0) = 0 (the zero padding past
+// the end of the text must stay the smallest symbol), code(b) = 1 + number of smaller non-zero byte values that
+// occur in the text.  The byte values that occur are the first bytes of the non-empty 16-bit buckets.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_alphabet(const u32* __restrict__ hist /* 65536, big-endian key */, u8* __restrict__ code /* 256 */,
+                                                  u32* __restrict__ counters)
+{
+    __shared__ u32 s_in[256], s_out[256];
+    const u32 b = threadIdx.x;
+    u32 any = 0;
+    for (u32 k = 0; k < 256u; ++k) any |= hist[b * 256u + k];
+    s_in[b] = (b != 0 && any != 0) ? 1u : 0u;
+    __syncthreads();
+    const u32 total = scan256_first_wave(s_in, s_out);
+    __syncthreads();
+    code[b] = b == 0 ? (u8)0 : (u8)(1u + s_out[b]);      // (codes of absent bytes are never looked up)
+    if (b == 0) {
+        const u32 ncodes = total + 1u;                   // + the reserved zero
+        u32 bits = 1;
+        while ((1u << bits) < ncodes) ++bits;
+        counters[C_ABITS] = bits < 2u ? 2u : bits;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Key refill for the next round (get_value, cpp:129-143): key = big-endian window of the text at depth `d`,
+// zero beyond the end - 4 bytes, or (abits < 7) 32 / abits symbols in the dense alphabet code, first symbol in
+// the top bits; in prefix-doubling rounds key = rank of suffix index + h (0 past n).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32* __restrict__ counters, u32 cnt_idx,
                                                 const u8* __restrict__ text, const u32* __restrict__ isa,
-                                                u32 n, u64 depth, u32 mode)
+                                                u32 n, u64 depth, u32 mode, const u8* __restrict__ code, u32 abits)
 {
+    __shared__ u8 s_code[256];
+    const bool packed = mode == MODE_TEXT && abits < 7u;
+    if (packed) { s_code[threadIdx.x] = code[threadIdx.x]; __syncthreads(); }
+    const u32 cpk = packed ? (32u / abits > 16u ? 16u : 32u / abits) : 4u;     // symbols per key
     const u32 count = counters[cnt_idx];
     constexpr int U = 4;                       // independent gathers in flight per lane (latency bound otherwise)
     for (u64 base = (u64)blockIdx.x * 256u * U + threadIdx.x; base < count; base += (u64)gridDim.x * 256u * U) {
@@ -747,16 +780,34 @@ __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32
         bool v[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) { const u64 i = base + (u64)k * 256u; v[k] = i < count; idx[k] = v[k] ? (u32)rec[i] : 0u; }
+        if (!packed) {
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const u64 pos = (u64)idx[k] + depth;
-            key[k] = 0;
-            if (v[k] && pos < n) {
-                if (mode == MODE_TEXT) {
-                    u32 w;
-                    __builtin_memcpy(&w, text + pos, 4);      // text is padded with >= 64 zero bytes
-                    key[k] = __builtin_bswap32(w);
-                } else key[k] = isa[pos];
+            for (int k = 0; k < U; ++k) {
+                const u64 pos = (u64)idx[k] + depth;
+                key[k] = 0;
+                if (v[k] && pos < n) {
+                    if (mode == MODE_TEXT) {
+                        u32 w;
+                        __builtin_memcpy(&w, text + pos, 4);      // text is padded with >= 64 zero bytes
+                        key[k] = __builtin_bswap32(w);
+                    } else key[k] = isa[pos];
+                }
+            }
+        } else {
+            u32 w[U][4];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const u64 pos = (u64)idx[k] + depth;
+                w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0;
+                if (v[k] && pos < n) __builtin_memcpy(w[k], text + pos, 16);      // (pad: >= 64 zero bytes behind the text)
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                u32 acc = 0, sh = 32;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if ((u32)i < cpk) { sh -= abits; acc |= (u32)s_code[(w[k][i >> 2] >> (8 * (i & 3))) & 255u] << sh; }
+                key[k] = acc;
             }
         }
 #pragma unroll

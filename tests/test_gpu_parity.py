@@ -120,6 +120,16 @@ def test_lcp_plcp_path(M, oracle_mod, monkeypatch):
     assert (M.make_lcp_array(t, sa) == oracle_mod.lcp(t, sa)).all()
 
 
+def _symbols_per_key(t):
+    """Symbols one gather round consumes: 4 bytes, or 32 / bits symbols of the dense alphabet code (k_alphabet)."""
+    ncodes = len(set(np.unique(t).tolist()) - {0}) + 1
+    bits = 1
+    while (1 << bits) < ncodes:
+        bits += 1
+    bits = max(bits, 2)
+    return min(32 // bits, 16) if bits < 7 else 4
+
+
 def _dev(M, t):
     import torch
     n = t.size
@@ -204,7 +214,7 @@ def test_logical_shards_deep_ties_finish(M, oracle_mod, shards):
             assert (l2, h2) == (lo, hi)
             depth = max(depth, dp if unres else 0)
         want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
-        assert depth == 9                                   # 5 bytes from round 0 + one 4-byte key round
+        assert depth == 5 + _symbols_per_key(t)              # 5 bytes from round 0 + one key-gather round
         g_host = grp.cpu().numpy()
         assert (g_host <= np.arange(n + 1)).all() and (g_host >= 0).all()
         ctxs[-1].finish_sa(d, n, full, grp, depth)
