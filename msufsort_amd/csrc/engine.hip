@@ -112,9 +112,9 @@ struct msufsort_hip_ctx {
         for (auto& b : rec) TRY(b.ensure(cap * 8));
         for (auto& b : pool_rec) TRY(b.ensure(cap * 8));
         for (auto& b : pool_hdr) TRY(b.ensure(cap * 8));
-        list_cap[0] = (u32)(cap / (TINY_MAX + 1) + (2u << 20));
-        list_cap[1] = (u32)(cap / (CAP_A + 1) + (2u << 20));
-        list_cap[2] = (u32)(cap / (CAP_B + 1) + (2u << 20));
+        list_cap[0] = (u32)(2 * (cap / (TINY_MAX + 1)) + (4u << 20));   // x 2: what the descriptor chunks may give up; + open chunk tails
+        list_cap[1] = (u32)(2 * (cap / (CAP_A + 1)) + (4u << 20));
+        list_cap[2] = (u32)(2 * (cap / (CAP_B + 1)) + (4u << 20));
         large_cap = (u32)(cap / (CAP_C + 1) + 16);
         for (int s = 0; s < 2; ++s) {
             for (int c = 0; c < 3; ++c) TRY(lists[s][c].ensure((size_t)list_cap[c] * sizeof(Desc)));
@@ -166,6 +166,15 @@ struct msufsort_hip_ctx {
 };
 
 namespace {
+
+__global__ void k_dbg_check_descs(const Desc* list, u32 n, u32 cap, u32 ms, u32* out)
+{
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const Desc d = list[i];
+        const bool bad = (u64)d.rec_off + d.len > cap || (d.buf & 3u) > 2u || (u64)d.sa_off + d.len > ms;
+        if (bad) { const u32 k = atomicAdd(&out[0], 1u); if (k < 6) { out[1 + 5 * k] = i; out[2 + 5 * k] = d.rec_off; out[3 + 5 * k] = d.len; out[4 + 5 * k] = d.sa_off; out[5 + 5 * k] = d.buf; } }
+    }
+}
 
 __global__ void k_zero_idx(u32* counters, u32 mask)
 {
@@ -488,6 +497,21 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
             k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
                 bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, ids, (u32)C_FBC);
             DBG("k_sort_mid C");
+        }
+        if (g_sync_debug) {
+            for (int k = 0; k < 3; ++k) {
+                const u32 cnt = c->h_counters[base + k];
+                if (!cnt) continue;
+                (void)c->aux0.ensure(256);
+                (void)hipMemsetAsync(c->aux0.p, 0, 256, st);
+                hipLaunchKernelGGL(k_dbg_check_descs, dim3(1024), dim3(256), 0, st, c->lists[cur][k].as<Desc>(), cnt, cap32, (u32)c->h_counters[C_MS], c->aux0.as<u32>());
+                u32 h[40];
+                (void)hipMemcpyAsync(h, c->aux0.p, 160, hipMemcpyDeviceToHost, st);
+                (void)hipStreamSynchronize(st);
+                fprintf(stderr, "[dbg] class %d: %u descriptors, %u bad", k, cnt, h[0]);
+                for (u32 q = 0; q < std::min<u32>(h[0], 6); ++q) fprintf(stderr, " (#%u off %u len %u sa %u buf 0x%x)", h[1 + 5 * q], h[2 + 5 * q], h[3 + 5 * q], h[4 + 5 * q], h[5 + 5 * q]);
+                fprintf(stderr, "\n");
+            }
         }
         if (nB) {
             const u32* ids = nullptr;

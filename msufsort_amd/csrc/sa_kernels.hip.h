@@ -1061,6 +1061,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     if (!__syncthreads_or(any_eq)) return;
 
     // ---- compact still-tied runs into next round's structures ----
+    u32 hc[3] = {0, 0, 0};           // run heads of this wave per size class
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
         if (j < rows) {
@@ -1069,7 +1070,17 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
             const u64 bt = __ballot(tied && rl[j] <= TINY_MAX);
             const u64 bs = __ballot(tied && rl[j] > TINY_MAX);
             if (lane == 0) { bm_tiny[p >> 6] = bt; bm_seg[p >> 6] = bs; }
+            if (bs) {        // run heads per size class = descriptors this segment will push (exact, so none are wasted)
+                const bool head = tied && rl[j] > TINY_MAX && p == rs[j];
+                const u32 cls = class_of(rl[j]);
+#pragma unroll
+                for (u32 k = 0; k < 3; ++k) hc[k] += (u32)__popcll(__ballot(head && cls == k));
+            }
         }
+    if (lane == 0) {
+#pragma unroll
+        for (u32 k = 0; k < 3; ++k) if (hc[k]) atomicAdd(&misc[4 + k], hc[k]);
+    }
     __syncthreads();
     if (t < 64) {
         u32 ct = 0, cs = 0;
@@ -1101,31 +1112,38 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                     pf[0] = ach[0]; pf[1] = ach[1];
                     const u32 sz = tt > em.pool_chunk ? tt : em.pool_chunk;
                     const u32 b = atomicAdd(&counters[em.pool_cnt_idx], sz);
-                    if ((u64)b + sz > em.pool_cap) { atomicOr(&counters[C_ERR], 32u); bad = 1; }
-                    ach[0] = b; ach[1] = b + sz;
+                    // (a chunk past the end of the buffer is never adopted: the workgroup lives on and would
+                    // hand its "room" to later segments)
+                    if ((u64)b + sz > em.pool_cap) { atomicOr(&counters[C_ERR], 32u); bad = 1; ach[0] = 0; ach[1] = 0; }
+                    else { ach[0] = b; ach[1] = b + sz; }
                 }
-                bt = ach[0]; ach[0] += tt;
+                if (!bad) { bt = ach[0]; ach[0] += tt; }
             }
             if (ts) {
                 if (ach[2] + ts > ach[3]) {
                     pf[2] = ach[2]; pf[3] = ach[3];
                     const u32 sz = ts > em.seg_chunk ? ts : em.seg_chunk;
                     const u32 b = atomicAdd(&counters[em.seg_cnt_idx], sz);
-                    if ((u64)b + sz > em.seg_cap) { atomicOr(&counters[C_ERR], 64u); bad = 1; }
-                    ach[2] = b; ach[3] = b + sz;
+                    if ((u64)b + sz > em.seg_cap) { atomicOr(&counters[C_ERR], 64u); bad = 1; ach[2] = 0; ach[3] = 0; }
+                    else { ach[2] = b; ach[3] = b + sz; }
                 }
-                bs = ach[2]; ach[2] += ts;
-                // descriptor room for every run head this segment can produce (classes up to my own)
-                constexpr u32 MAXH = CAP / (TINY_MAX + 1) + 1;
-                constexpr u32 NCLS = CAP <= CAP_A ? 1 : (CAP <= CAP_B ? 2 : 3);
+                if (!bad) { bs = ach[2]; ach[2] += ts; }
+                // descriptor room: exactly the run heads counted above, taken from a chunk per class; a request that
+                // does not fit gives up less than it asks for, so the lists never need more than twice the descriptors
+                // that can exist
 #pragma unroll
-                for (u32 k = 0; k < NCLS; ++k) {
-                    if (ach[5 + 2 * k] - ach[4 + 2 * k] < MAXH) {
+                for (u32 k = 0; k < 3; ++k) {
+                    const u32 need = misc[4 + k];
+                    if (need && ach[4 + 2 * k] + need > ach[5 + 2 * k]) {
                         pf[4 + 2 * k] = ach[4 + 2 * k]; pf[5 + 2 * k] = ach[5 + 2 * k];
-                        const u32 sz = MAXH + 32u;
+                        // chunk per DESTINATION class: a neutral descriptor left over in a chunk costs its consumer a
+                        // whole (empty) iteration, which is cheap for the 64-thread class-A sort and expensive for the
+                        // 1024-thread class-C sort; exact mode (chunk 0): no slack at all
+                        const u32 dch = em.seg_chunk ? (k == 0 ? 64u : (k == 1 ? 16u : 4u)) : 0u;
+                        const u32 sz = need > dch ? need : dch;
                         const u32 b = atomicAdd(&counters[em.lists.cnt_idx + k], sz);
-                        if ((u64)b + sz > em.lists.cap[k]) { atomicOr(&counters[C_ERR], 1u); bad = 1; }
-                        ach[4 + 2 * k] = b; ach[5 + 2 * k] = b + sz;
+                        if ((u64)b + sz > em.lists.cap[k]) { atomicOr(&counters[C_ERR], 1u); bad = 1; ach[4 + 2 * k] = 0; ach[5 + 2 * k] = 0; }
+                        else { ach[4 + 2 * k] = b; ach[5 + 2 * k] = b + sz; }
                     }
                 }
             }
