@@ -291,21 +291,38 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const u64* __restrict__ packe
                                                    u32* __restrict__ queue /* [0] static head, [1] dynamic count */,
                                                    u32* __restrict__ nxt, u32* __restrict__ dist, u8* __restrict__ segbuf)
 {
-    u32 id = atomicAdd(&queue[0], 1u) + 1u;
+    // chain ids 1 .. K-1 are dealt to the workgroups in contiguous shares and pulled from an LDS counter: one global
+    // counter for all 4 M pulls of a 1 GiB input saturates (~90 returning atomics per us) and was what the walk waited
+    // for; chain lengths are i.i.d., so a share of a few thousand chains is balanced to a few per cent
+    __shared__ u32 s_next, s_end;
+    if (threadIdx.x == 0) {
+        const u32 per = (K - 1u + gridDim.x - 1u) / gridDim.x;
+        const u64 b = 1ull + (u64)blockIdx.x * per;
+        s_next = b < K ? (u32)b : K;
+        s_end = b + per < K ? (u32)(b + per) : K;
+    }
+    __syncthreads();
+#define IBWT_PULL() ([&]() { const u32 i_ = atomicAdd(&s_next, 1u); return i_ < s_end ? i_ : K; }())
+    u32 id = IBWT_PULL();
     u32 cur = 0, len = 0, my = id;
+    u64 acc = 0;                       // the last (len & 7) bytes met: bytes leave as aligned 8-byte stores (one memory
+                                       // transaction per 8 hops and lane instead of one per hop)
     if (id < K) cur = (u32)packed[ibwt_start(id, sent, kreg)];
     while (id < K) {
         const u64 e = packed[cur];
-        segbuf[(u64)my * IBWT_CW + len] = (u8)(e >> 32);
+        acc |= (u64)(u8)(e >> 32) << (8u * (len & 7u));
         ++len;
+        if ((len & 7u) == 0) { *reinterpret_cast<u64*>(segbuf + (u64)my * IBWT_CW + len - 8u) = acc; acc = 0; }
         if (ibwt_marked(cur, sent)) {
+            if (len & 7u) *reinterpret_cast<u64*>(segbuf + (u64)my * IBWT_CW + (len & ~7u)) = acc;     // (tail bytes beyond len are never read)
+            acc = 0;
             nxt[my] = ibwt_id(cur, sent, kreg);
             dist[my] = len;
-            id = atomicAdd(&queue[0], 1u) + 1u;
+            id = IBWT_PULL();
             my = id; len = 0;
             if (id < K) cur = (u32)packed[ibwt_start(id, sent, kreg)];
         } else {
-            if (len == IBWT_CW) {
+            if (len == IBWT_CW) {      // (a multiple of 8: acc has just been stored)
                 const u32 fresh = K + atomicAdd(&queue[1], 1u);
                 if (fresh >= kt_cap) { queue[2] = 1u; return; }          // cannot happen (capacity covers every cut)
                 nxt[my] = fresh; dist[my] = len;
@@ -314,6 +331,7 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const u64* __restrict__ packe
             cur = (u32)e;
         }
     }
+#undef IBWT_PULL
 }
 
 // out[pos .. pos + len) = segment buffer; one wave per segment, 64 contiguous bytes per store instruction
