@@ -345,7 +345,8 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
     u32 sb = 1, nb = 2;          // record buffer holding the current segments / receiving next round's
     u32 mode = MODE_TEXT;
     u64 depth = 5;               // text bytes consumed after round 0: bucket bytes 0,1 + key bytes 2,3,4
-    u32 abits = 8;               // bits per symbol of the dense alphabet code (8 = plain 4-byte windows); known after round 0
+    u32 asigma = 256, cpk = 4, zlow = 0;   // dense alphabet code of the gather rounds (k_alphabet; known after round 0):
+                                            // number of codes, symbols per key, left shift; cpk == 4: plain 4-byte windows
     auto make_lists = [&](int slot) {
         Lists L;
         for (int k = 0; k < 3; ++k) { L.cls[k] = c->lists[slot][k].as<Desc>(); L.cap[k] = c->list_cap[k]; }
@@ -385,9 +386,9 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         TRY(c->read_counters());
         const u64 actP = c->h_counters[C_POOL0];
         if (actP) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actP, 256), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, (u32)C_POOL0,
-                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), abits);
+                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), asigma, cpk, zlow);
         hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(m, 256), 65536u)), dim3(256), 0, st, bufs.p[sb], counters, (u32)C_SEG0,
-                           d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), abits);
+                           d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), asigma, cpk, zlow);
         depth *= 2; tm.doubling_rounds++; tm.rounds++;
         HIP_TRY(hipEventRecord(c->ev[1], st)); HIP_TRY(hipEventRecord(c->ev[2], st)); HIP_TRY(hipEventRecord(c->ev[3], st)); HIP_TRY(hipEventRecord(c->ev[4], st));
     }
@@ -552,11 +553,15 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         if (round == 0) tm.unresolved_after_round0 = (int64_t)(actP + actS);
         if (actP + actS == 0) break;
         if (round == 0 && !resume) {     // key packing for the gather rounds (k_alphabet ran with the histogram)
-            const u32 b = c->h_counters[C_ABITS];
-            abits = (b >= 2 && b < 7 && !getenv("MSUFSORT_HIP_NO_PACK")) ? b : 8u;
-            if (verbose) fprintf(stderr, "[msufsort_hip] alphabet code: %u bits per symbol -> %u symbols per key\n", b, abits < 7 ? std::min<u32>(32u / abits, 16u) : 4u);
+            const u32 b = c->h_counters[C_ABITS], sg = c->h_counters[C_ASIGMA];
+            if (b >= 2 && b < 7 && sg >= 2 && !getenv("MSUFSORT_HIP_NO_PACK")) {
+                u64 p = 1; u32 k = 0;
+                while (k < 16 && p * sg <= (1ull << 32)) { p *= sg; ++k; }       // sigma^k <= 2^32
+                u32 bl = 0; while (bl < 32 && ((p - 1) >> bl) != 0) ++bl;         // bits of the largest key
+                asigma = sg; cpk = k; zlow = 32 - bl;
+            }
+            if (verbose) fprintf(stderr, "[msufsort_hip] alphabet: %u codes (%u bits) -> %u symbols per key\n", sg, b, cpk);
         }
-        if (round > 200) { set_error("no convergence after %d rounds", round); return MSUFSORT_HIP_ERR_INTERNAL; }
 
         // ---- prepare next round ----
         cur = nxt;
@@ -622,11 +627,11 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         }
         // refill keys of all still-tied suffixes
         if (actP) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
-                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), abits);
+                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), asigma, cpk, zlow);
         if (actS) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actS, 1024), 65536u)), dim3(256), 0, st, bufs.p[sb], counters, curS,
-                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), abits);
+                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), asigma, cpk, zlow);
         DBG("k_refill");
-        if (mode == MODE_TEXT) depth += (abits < 7u ? std::min<u32>(32u / abits, 16u) : 4u); else { depth *= 2; tm.doubling_rounds++; }
+        if (mode == MODE_TEXT) depth += cpk; else { depth *= 2; tm.doubling_rounds++; }
         tm.rounds++;
     }
     if (d_grp_rows && !resume)

@@ -55,6 +55,7 @@ enum {
     C_HMAX = 24,                      // largest 16-bit bucket of this shard (skew forecast)
     C_HNZ = 25,                       // number of non-empty 16-bit buckets (alphabet-size estimate)
     C_ABITS = 26,                     // bits per symbol of the dense alphabet code (k_alphabet)
+    C_ASIGMA = 27,                    // number of codes (symbols that occur + the reserved zero)
     C_NCOUNTERS = 32
 };
 
@@ -757,22 +758,24 @@ __global__ __launch_bounds__(256) void k_alphabet(const u32* __restrict__ hist /
         u32 bits = 1;
         while ((1u << bits) < ncodes) ++bits;
         counters[C_ABITS] = bits < 2u ? 2u : bits;
+        counters[C_ASIGMA] = ncodes < 2u ? 2u : ncodes;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Key refill for the next round (get_value, cpp:129-143): key = big-endian window of the text at depth `d`,
-// zero beyond the end - 4 bytes, or (abits < 7) 32 / abits symbols in the dense alphabet code, first symbol in
-// the top bits; in prefix-doubling rounds key = rank of suffix index + h (0 past n).
+// zero beyond the end - 4 bytes, or (small alphabets) up to 16 symbols of the dense alphabet code read as one number
+// in base sigma; in prefix-doubling rounds key = rank of suffix index + h (0 past n).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32* __restrict__ counters, u32 cnt_idx,
                                                 const u8* __restrict__ text, const u32* __restrict__ isa,
-                                                u32 n, u64 depth, u32 mode, const u8* __restrict__ code, u32 abits)
+                                                u32 n, u64 depth, u32 mode, const u8* __restrict__ code, u32 sigma, u32 cpk, u32 zlow)
 {
+    // packed: key = (sum code(c_i) sigma^(cpk-1-i)) << zlow - the symbols read as ONE number in base sigma (denser than
+    // bit fields: 13 DNA symbols per key instead of 10), left-aligned so that the top bits stay evenly used
     __shared__ u8 s_code[256];
-    const bool packed = mode == MODE_TEXT && abits < 7u;
+    const bool packed = mode == MODE_TEXT && cpk != 4u;
     if (packed) { s_code[threadIdx.x] = code[threadIdx.x]; __syncthreads(); }
-    const u32 cpk = packed ? (32u / abits > 16u ? 16u : 32u / abits) : 4u;     // symbols per key
     const u32 count = counters[cnt_idx];
     constexpr int U = 4;                       // independent gathers in flight per lane (latency bound otherwise)
     for (u64 base = (u64)blockIdx.x * 256u * U + threadIdx.x; base < count; base += (u64)gridDim.x * 256u * U) {
@@ -803,11 +806,11 @@ __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32
             }
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                u32 acc = 0, sh = 32;
+                u32 acc = 0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if ((u32)i < cpk) { sh -= abits; acc |= (u32)s_code[(w[k][i >> 2] >> (8 * (i & 3))) & 255u] << sh; }
-                key[k] = acc;
+                    if ((u32)i < cpk) acc = acc * sigma + (u32)s_code[(w[k][i >> 2] >> (8 * (i & 3))) & 255u];
+                key[k] = acc << zlow;
             }
         }
 #pragma unroll

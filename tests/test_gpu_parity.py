@@ -121,13 +121,20 @@ def test_lcp_plcp_path(M, oracle_mod, monkeypatch):
 
 
 def _symbols_per_key(t):
-    """Symbols one gather round consumes: 4 bytes, or 32 / bits symbols of the dense alphabet code (k_alphabet)."""
-    ncodes = len(set(np.unique(t).tolist()) - {0}) + 1
+    """Symbols one gather round consumes: 4 bytes, or (alphabets below 7 bits) as many symbols of the dense alphabet
+    code as fit one 32-bit number in base sigma (k_alphabet, k_refill)."""
+    sigma = len(set(np.unique(t).tolist()) - {0}) + 1
     bits = 1
-    while (1 << bits) < ncodes:
+    while (1 << bits) < sigma:
         bits += 1
-    bits = max(bits, 2)
-    return min(32 // bits, 16) if bits < 7 else 4
+    if max(bits, 2) >= 7:
+        return 4
+    sigma = max(sigma, 2)
+    k, p = 0, 1
+    while k < 16 and p * sigma <= (1 << 32):
+        p *= sigma
+        k += 1
+    return k
 
 
 def _dev(M, t):
