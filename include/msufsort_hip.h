@@ -127,6 +127,16 @@ int msufsort_hip_finish_sa_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n
 int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
                                   int32_t n_shards, int64_t* bounds);
 
+/* 64-bit output (callers with 64-bit index types).  Same rows as the int32 entry points, widened on
+ * the device.  This round builds with 32-bit indices internally: n > 2^31 - 2 returns MSUFSORT_HIP_ERR_TOO_LARGE
+ * (BASELINE config 5, 8 GiB over 8 GPUs, needs 33-bit indices and a distributed doubling phase - not built). */
+int msufsort_hip_make_sa_i64(const uint8_t* text, int64_t n, int64_t* sa_out /* n+1 */,
+                             const msufsort_hip_opts* opts);
+int msufsort_hip_make_sa_i64_ctx(msufsort_hip_ctx* ctx, const uint8_t* text, int64_t n, int64_t* sa_out,
+                                 const msufsort_hip_opts* opts);
+int msufsort_hip_make_sa_i64_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
+                                 int64_t* d_sa_out /* n+1 */, const msufsort_hip_opts* opts);
+
 /* Host-only helper used by the two calls above (no device work): balanced key-range cuts from the
  * exclusive prefix bstart[65537] of the 16-bit histogram; cuts/rows have n_shards+1 entries. */
 int msufsort_hip_plan_cuts(const uint32_t* bstart, int64_t n, int64_t z, int32_t n_shards,

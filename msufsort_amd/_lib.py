@@ -38,6 +38,7 @@ SYMBOLS = [
     "msufsort_hip_inverse_bwt_dev", "msufsort_hip_lcp_i32", "msufsort_hip_lcp_i32_dev",
     "msufsort_hip_validate_sa_dev", "msufsort_hip_debug_hist16_dev",
     "msufsort_hip_make_sa_i32_ctx", "msufsort_hip_forward_bwt_ctx", "msufsort_hip_inverse_bwt_ctx", "msufsort_hip_lcp_i32_ctx",
+    "msufsort_hip_make_sa_i64", "msufsort_hip_make_sa_i64_ctx", "msufsort_hip_make_sa_i64_dev",
 ]
 
 _lib = None
@@ -93,6 +94,9 @@ def lib():
     L.msufsort_hip_validate_sa_dev.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
     L.msufsort_hip_debug_hist16_dev.argtypes = [vp, vp, i64, vp]
     L.msufsort_hip_make_sa_i32_ctx.argtypes = [vp, vp, i64, vp, C.POINTER(Opts)]
+    L.msufsort_hip_make_sa_i64.argtypes = [vp, i64, vp, C.POINTER(Opts)]
+    L.msufsort_hip_make_sa_i64_ctx.argtypes = [vp, vp, i64, vp, C.POINTER(Opts)]
+    L.msufsort_hip_make_sa_i64_dev.argtypes = [vp, vp, i64, vp, C.POINTER(Opts)]
     L.msufsort_hip_forward_bwt_ctx.argtypes = [vp, vp, i64, C.POINTER(i64), C.POINTER(Opts)]
     L.msufsort_hip_inverse_bwt_ctx.argtypes = [vp, vp, i64, i64, C.POINTER(Opts)]
     L.msufsort_hip_lcp_i32_ctx.argtypes = [vp, vp, i64, vp, vp]

@@ -54,6 +54,15 @@ def make_suffix_array(data, threads: int = 1, *, device: int = 0, verbose: int =
     return sa
 
 
+def make_suffix_array_i64(data, threads: int = 1, *, device: int = 0) -> np.ndarray:
+    """The same rows as int64 (msufsort_hip_make_sa_i64; inputs above 2^31 - 2 bytes are rejected in this round)."""
+    t = _u8(data)
+    sa = np.empty(t.size + 1, dtype=np.int64)
+    o = _opts(device)
+    _lib.check(_lib.lib().msufsort_hip_make_sa_i64(t.ctypes.data, t.size, sa.ctypes.data, C.byref(o)), "make_suffix_array_i64")
+    return sa
+
+
 def forward_burrows_wheeler_transform(data, threads: int = 1, *, device: int = 0):
     """maniscalco::forward_burrows_wheeler_transform (h:449-462): returns (bwt bytes, sentinel row)."""
     t = _u8(data).copy()

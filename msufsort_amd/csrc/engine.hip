@@ -869,6 +869,52 @@ int msufsort_hip_make_sa_i32(const uint8_t* text, int64_t n, int32_t* sa_out, co
     return msufsort_hip_make_sa_i32_ctx(t.c, text, n, sa_out, opts);
 }
 
+// ---- 64-bit output: the int32 rows, widened on the device ----
+namespace {
+__global__ __launch_bounds__(256) void k_widen(const int32_t* __restrict__ in, u64 rows, int64_t* __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < rows; i += (u64)gridDim.x * 256u) out[i] = (int64_t)in[i];
+}
+}
+
+int msufsort_hip_make_sa_i64_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int64_t* d_sa_out, const msufsort_hip_opts* opts)
+{
+    if (!c || !d_sa_out || n < 0 || (n > 0 && !d_text)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n(n));
+    HIP_TRY(hipSetDevice(c->device));
+    TRY(c->sa_own.ensure(((size_t)n + 1) * 4));
+    TRY(msufsort_hip_make_sa_i32_dev(c, d_text, n, c->sa_own.as<int32_t>(), opts));
+    hipLaunchKernelGGL(k_widen, dim3(std::min<u32>(cdiv((u64)n + 1, 256), 1u << 20)), dim3(256), 0, c->stream, c->sa_own.as<int32_t>(), (u64)n + 1, d_sa_out);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_make_sa_i64_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64_t n, int64_t* sa_out, const msufsort_hip_opts* opts)
+{
+    if (!c || !sa_out || (n > 0 && !text)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n(n));
+    if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
+    HIP_TRY(hipSetDevice(c->device));
+    TRY(c->text_own.ensure((size_t)n + MSUFSORT_HIP_TEXT_PAD));
+    TRY(c->aux2.ensure(((size_t)n + 1) * 8));
+    HIP_TRY(hipMemcpyAsync(c->text_own.p, text, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    TRY(msufsort_hip_make_sa_i64_dev(c, c->text_own.as<u8>(), n, c->aux2.as<int64_t>(), opts));
+    HIP_TRY(hipMemcpyAsync(sa_out, c->aux2.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_make_sa_i64(const uint8_t* text, int64_t n, int64_t* sa_out, const msufsort_hip_opts* opts)
+{
+    if (!sa_out || (n > 0 && !text)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n(n));
+    if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
+    TmpCtx t;
+    TRY(msufsort_hip_ctx_create(&t.c, opts ? opts->device : 0, 0));
+    return msufsort_hip_make_sa_i64_ctx(t.c, text, n, sa_out, opts);
+}
+
 // Host-only: split the 16-bit key space into n_shards count-balanced contiguous ranges.
 // bstart[65537] = exclusive prefix of the 16-bit histogram over the m = n - z radix-sorted suffixes.
 // cuts[n_shards+1] = first key of every shard; rows[n_shards+1] = first SA row of every shard

@@ -46,6 +46,14 @@ def test_literal_golden(M, oracle_mod, golden):
         _check_golden(M, oracle_mod, d, literal=True)
 
 
+def test_int64_output(M):
+    """msufsort_hip_make_sa_i64: the int32 rows, widened; n = 0 defined."""
+    t = gen.text_bytes(300001, 5)
+    a, b = M.make_suffix_array(t), M.make_suffix_array_i64(t)
+    assert b.dtype == np.int64 and (a.astype(np.int64) == b).all()
+    assert M.make_suffix_array_i64(np.zeros(0, np.uint8)).tolist() == [0]
+
+
 def test_empty_input(M):
     assert M.make_suffix_array(b"").tolist() == [0]
     b, s = M.forward_burrows_wheeler_transform(b"")
