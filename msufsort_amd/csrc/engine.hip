@@ -465,6 +465,13 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
             em.pool_chunk = attempt == 0 ? (u32)ch : 0u; em.seg_chunk = em.pool_chunk;
         }
         em.lists = make_lists(nxt);
+        // The chunk above is sized for the 8192-workgroup launches (class A, tiny pool).  The class-B / class-C sorts
+        // run 1024 / 256 workgroups whose segments emit thousands of records each: with the small chunk nearly every
+        // segment goes to the two global counters (one returning atomic per segment, ~90 per us chip-wide), so they
+        // take proportionally larger chunks (same total of open chunk tails).
+        Emit emB = em, emC = em;
+        emB.pool_chunk = emB.seg_chunk = (u32)std::min<u64>(65536, (u64)em.seg_chunk * 8);
+        emC.pool_chunk = emC.seg_chunk = (u32)std::min<u64>(262144, (u64)em.seg_chunk * 32);
         const u32 base = cur ? C_LIST1 : C_LIST0;
         nA = c->h_counters[base + 0]; nB = c->h_counters[base + 1]; nC = c->h_counters[base + 2];
         nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
@@ -496,7 +503,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 ids = c->doneC.as<u32>();
             }
             k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
-                bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, ids, (u32)C_FBC);
+                bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, emC, counters, ids, (u32)C_FBC);
             DBG("k_sort_mid C");
         }
         if (g_sync_debug) {
@@ -522,8 +529,8 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 DBG("k_sort_fast B");
                 ids = c->doneB.as<u32>();
             }
-            k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(std::min<u32>(nB, 768u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
-                bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, ids, (u32)C_FBB);
+            k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
+                bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, emB, counters, ids, (u32)C_FBB);
             DBG("k_sort_mid B");
         }
         if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(

@@ -866,7 +866,11 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 
     const u32 len = d.len;
     if (len == 0) return;                           // neutral list entry (unused chunk tail)
-    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    // (the thread id is re-materialised per segment: the address arithmetic hanging off it is then redone here instead
+    // of being hoisted out of the caller's segment loop into registers that cost a whole wave of occupancy)
+    u32 t;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(threadIdx.x));
+    const u32 lane = t & 63u, wv = t >> 6;
     // every wave takes the same number of consecutive 64-record rows (wave-major order keeps the LSD passes stable);
     // with a fixed ITEMS rows per wave a short segment would be sorted by one wave while the others idle
     const u32 rpw = ((len + 63u) / 64u + W - 1) / W;            // rows per wave, <= ITEMS because len <= CAP
@@ -1536,8 +1540,9 @@ constexpr size_t sort_fast_lds_bytes()
 }
 
 // persistent launch: workgroups stride over the list and skip what k_sort_fast already finished
+// (the class-B instance asks for 4 waves per SIMD = 128 VGPRs: one more resident workgroup per CU)
 template <int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+__global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                       u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                       Emit em, u32* __restrict__ counters, const u32* __restrict__ ids, u32 ids_cnt_idx)
 {
