@@ -31,10 +31,15 @@ struct Desc {            // one segment = run of records that are equal on every
     u32 rec_off;         // first record (in record buffer `buf`)
     u32 len;
     u32 sa_off;          // first (shard-local) suffix-array row of the segment
-    u32 buf;             // bits 0-1: record buffer index 0..2; bits 8-15: kbits = number of low key bits that
+    u32 buf;             // bits 0-1: record buffer index 0..2; bit 2: DESC_STALE; bits 8-15: kbits = number of low key bits that
                          // can still differ inside the segment (32 for fresh keys, 24 after the level-1 split, ...)
 };
 #define DESC_BUF(kbits, buf) (((u32)(kbits) << 8) | (u32)(buf))
+// Prefix-doubling rounds keep ISA[i] = 1 + first row of i's group.  A segment that was emitted by the previous round's
+// sort already has that rank in all its members, so after sorting it only the members that do NOT stay in its first
+// run need a (random 4-byte) ISA write.  Segments created by a partition level in the current round carry DESC_STALE:
+// their members still hold the parent's rank and are all rewritten.
+#define DESC_STALE 4u
 
 struct RecBufs { u64* p[3]; };
 
@@ -632,14 +637,16 @@ __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __re
             if ((u64)base + wtot > pool_cap) { if (lane_id() == 0) atomicOr(&counters[C_ERR], 2u); }
             else if (want) {
                 const u32 b = base + woff;
-                for (u32 k = 0; k < cnt; ++k) { pool_rec[b + k] = src[k]; pool_hdr[b + k] = pack_hdr(sa, cnt, k); }
+                const u64 st = (sa != par.sa_off || (par.buf & DESC_STALE)) ? (1ull << 48) : 0ull;      // header bit 48 = DESC_STALE of a pool run
+                for (u32 k = 0; k < cnt; ++k) { pool_rec[b + k] = src[k]; pool_hdr[b + k] = pack_hdr(sa, cnt, k) | st; }
             }
         }
     }
     // descriptors: one counter atomic per wave and class instead of one per child
     const u32 cls = cnt > TINY_MAX ? class_of(cnt) : 4u;
     const u64 lt_mask = lane_id() ? (~0ull >> (64 - lane_id())) : 0ull;
-    const Desc d = {start, cnt, sa, DESC_BUF(child_kbits, buf)};
+    const u32 stale = (cnt && (sa != par.sa_off || (par.buf & DESC_STALE))) ? DESC_STALE : 0u;
+    const Desc d = {start, cnt, sa, DESC_BUF(child_kbits, buf | stale)};
 #pragma unroll
     for (u32 k = 0; k < 4; ++k) {
         const u64 m = __ballot(cls == k);
@@ -1026,7 +1033,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                 const u32 e = above ? (u32)((w << 6) + __ffsll((long long)above) - 1) : pre_seg[w];
                 rs[j] = s; rl[j] = e - s + 1;
                 sa_out[d.sa_off + p] = idx[j];
-                if (mode == MODE_ISA) isa[idx[j]] = rank0 + d.sa_off + s + 1u;
+                if (mode == MODE_ISA && (s != 0 || (d.buf & DESC_STALE))) isa[idx[j]] = rank0 + d.sa_off + s + 1u;
             }
         }
     } else {
@@ -1060,7 +1067,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
             if (j < 2 && p < len) {
                 idx[j] = ex[p]; rs[j] = ex[128 + p]; rl[j] = ex[256 + p];
                 sa_out[d.sa_off + p] = idx[j];
-                if (mode == MODE_ISA) isa[idx[j]] = rank0 + d.sa_off + rs[j] + 1u;
+                if (mode == MODE_ISA && (rs[j] != 0 || (d.buf & DESC_STALE))) isa[idx[j]] = rank0 + d.sa_off + rs[j] + 1u;
                 any_eq |= rl[j] > 1;
             }
         }
@@ -1311,6 +1318,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
         asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(threadIdx.x));
         const u32 lane = t & 63u, wv = t >> 6;
         const u32 len = d.len, sa_off = d.sa_off, cur = seg, kbits = (d.buf >> 8) & 255u;
+        const bool stale = (d.buf & DESC_STALE) != 0;
         u32 key[ITEMS];                    // key, then composite, then base | size << 16 | rank << 24, then final row
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) { key[j] = (u32)(nrec[j] >> 32); exi[FAST_P(j)] = (u32)nrec[j]; }
@@ -1460,7 +1468,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
                     if (p < len) {
                         const u32 id = exi[p];
                         ex[key[j] & 0xffffu] = id;
-                        if (mode == MODE_ISA && !(key[j] >> 31)) isa[id] = rank0 + sa_off + key[j] + 1u;
+                        if (mode == MODE_ISA && !(key[j] >> 31) && (key[j] != 0 || stale)) isa[id] = rank0 + sa_off + key[j] + 1u;
                     }
                 }
             __syncthreads();                                                        // (8)
@@ -1496,7 +1504,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
                     for (u32 i = t; i < nt; i += THREADS) {
                         const u32 id = tl[3 * i], w1 = tl[3 * i + 1];
                         const u32 rs = w1 & 0xffffu, rl = (w1 >> 16) & 255u, ro = w1 >> 24;
-                        if (mode == MODE_ISA) isa[id] = rank0 + sa_off + rs + 1u;
+                        if (mode == MODE_ISA && (rs != 0 || stale)) isa[id] = rank0 + sa_off + rs + 1u;
                         if (rl <= TINY_MAX) {
                             const u32 o = base_t + ex[rs] + ro;
                             em.pool_rec[o] = (u64)id;
@@ -1552,9 +1560,16 @@ __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(
     if (threadIdx.x < 24) ach[threadIdx.x] = 0;
     __syncthreads();
     const u32 total = ids ? counters[ids_cnt_idx] : nseg;
-    for (u32 i = blockIdx.x; i < total; i += gridDim.x) {
-        sort_mid_segment<THREADS, ITEMS>(bufs, list[ids ? ids[i] : i], sa_out, isa, mode, em, counters);
-        __syncthreads();
+    if (blockIdx.x < total) {
+        // the next descriptor is fetched while the current segment is sorted (one memory round trip less per segment)
+        Desc d = list[ids ? ids[blockIdx.x] : blockIdx.x];
+        for (u32 i = blockIdx.x; i < total; i += gridDim.x) {
+            const u32 ni = i + gridDim.x < total ? i + gridDim.x : i;
+            const Desc dn = list[ids ? ids[ni] : ni];
+            sort_mid_segment<THREADS, ITEMS>(bufs, d, sa_out, isa, mode, em, counters);
+            __syncthreads();
+            d = dn;
+        }
     }
     // give back what is left of my chunks as neutral entries
     for (u32 i = ach[0] + threadIdx.x; i < ach[1]; i += THREADS) { em.pool_rec[i] = 0; em.pool_hdr[i] = 0; }
@@ -1612,7 +1627,7 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
                     }
                     const u32 row = sa_start + n_lt[k] + n_eqb[k];
                     sa_out[row] = (u32)rec[k];
-                    if (mode == MODE_ISA) isa[(u32)rec[k]] = rank0 + sa_start + n_lt[k] + 1u;
+                    if (mode == MODE_ISA && (n_lt[k] != 0 || ((hdr[k] >> 48) & 1ull))) isa[(u32)rec[k]] = rank0 + sa_start + n_lt[k] + 1u;
                     if (n_eq[k] > 1 && n_eqb[k] == 0) lrun[e] = atomicAdd(&s_total, n_eq[k]);
                 }
             }
