@@ -837,8 +837,7 @@ template <int THREADS, int ITEMS>
 constexpr size_t sort_mid_lds_bytes()
 {
     constexpr int CAP = THREADS * ITEMS;
-    constexpr int NBIN = 1 << (CAP >= 16384 ? 12 : (CAP >= 4096 ? 10 : 7));
-    constexpr int WC = ((THREADS / 64) * 256 > NBIN ? (THREADS / 64) * 256 : NBIN) + 8;
+    constexpr int WC = (THREADS / 64) * 256 + 8;               // per-wave digit counters
     return (size_t)(THREADS * ITEMS) * 4 + (size_t)WC * 4 + 256 * 4 * 2 +
            (size_t)(THREADS * ITEMS / 64) * (8 * 3 + 4 * 2) + 8 * 4 + 24 * 4;
 }
@@ -856,9 +855,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     constexpr int W = THREADS / 64;
     constexpr int NW = CAP / 64;                    // bitmap words
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int MSD_BITS = CAP >= 16384 ? 12 : (CAP >= 4096 ? 10 : 7);
-    constexpr int NBIN = 1 << MSD_BITS;                         // sub-buckets of the MSD fast path
-    constexpr int WCNT = (W * 256 > NBIN ? W * 256 : NBIN) + 8; // LSD per-wave digit counters / MSD histogram
+    constexpr int WCNT = W * 256 + 8;                           // LSD per-wave digit counters
     u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP
     u32* wcnt = ex + CAP;                                       // WCNT
     u32* tot = wcnt + WCNT;                                     // 256
