@@ -838,8 +838,7 @@ constexpr size_t sort_mid_lds_bytes()
 {
     constexpr int CAP = THREADS * ITEMS;
     constexpr int WC = (THREADS / 64) * 256 + 8;               // per-wave digit counters
-    return (size_t)(THREADS * ITEMS) * 4 + (size_t)WC * 4 + 256 * 4 * 2 +
-           (size_t)(THREADS * ITEMS / 64) * (8 * 3 + 4 * 2) + 8 * 4 + 24 * 4;
+    return (size_t)CAP * 4 + (size_t)WC * 4 + 256 * 4 * 2 + (size_t)(CAP / 64) * (8 * 3 + 4 * 2) + 8 * 4 + 24 * 4;
 }
 
 template <int THREADS, int ITEMS>
