@@ -402,7 +402,17 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         {
             Desc* src_list; u32 nl, ntiles; int lp;       // lp = index of the lvl list used as destination
             u32 shift;
-            if (round == 0) { src_list = c->lvl[0].as<Desc>(); nl = c->h_counters[C_LVL0]; ntiles = c->h_counters[C_LVLT0]; lp = 1; shift = 16; }
+            if (round == 0) {
+                src_list = c->lvl[0].as<Desc>(); nl = c->h_counters[C_LVL0]; ntiles = c->h_counters[C_LVLT0]; lp = 1;
+                // Two-byte buckets just above the class-C limit (1.2 .. 2 GiB of random bytes) should not be cut into
+                // 256 crumbs of ~100 records each (17 M class-A segments through the slow LSD sort): the level splits
+                // on an 8-bit window that starts only `b` bits below the consumed key byte - the rest of the window
+                // is constant inside a segment - so children come out around 3/4 of the class-C capacity and go
+                // through k_sort_fast2.  Skewed inputs (largest bucket >> class C) keep the full byte.
+                u32 b = 1;
+                while (b < 8 && ((u64)c->h_counters[C_HMAX] >> b) > (u64)CAP_C * 3 / 4) ++b;
+                shift = 24 - b;
+            }
             else { src_list = c->large_round[cur].as<Desc>(); nl = c->h_counters[(cur ? C_LIST1 : C_LIST0) + 3]; ntiles = c->h_counters[cur ? C_LTILES1 : C_LTILES0]; lp = 0; shift = 24; }
             while (nl > 0) {
                 const bool last = (shift == 0);
@@ -440,7 +450,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                     }
                     break;
                 }
-                shift -= 8;
+                shift = shift >= 8 ? shift - 8 : 0;
             }
         }
         // ---- LDS sorts of everything that fits ----
