@@ -249,7 +249,7 @@ int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
     const u32 hchunks = nchunks * per;
     c->nchunks = nchunks; c->chunk_len = (u32)chunk_len; c->hist_per = per;
     hipLaunchKernelGGL(k_hist16, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, (u32)m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>());
-    hipLaunchKernelGGL(k_reduce16, dim3(64), dim3(1024), 0, c->stream, c->hist_partial.as<u32>(), hchunks, c->hist.as<u32>());
+    hipLaunchKernelGGL(k_reduce16, dim3(256), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), hchunks, c->hist.as<u32>());
     HIP_TRY(hipGetLastError());
     return MSUFSORT_HIP_OK;
 }
@@ -260,7 +260,8 @@ void run_scan(msufsort_hip_ctx* c, u32 klo, u32 khi, u64 z)
                        c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->seg0_base.as<u32>(),
                        c->seg0.as<Desc>(), c->tile_start.as<u32>(), c->counters.as<u32>(), (u32)z);
     hipLaunchKernelGGL(k_alphabet, dim3(1), dim3(256), 0, c->stream, c->hist.as<u32>(), c->alpha.as<u8>(), c->counters.as<u32>());
-    hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks), dim3(1024), 0, c->stream, c->hist_partial.as<u32>(), c->hist_per, klo, khi, c->stripe_sums.as<u32>());
+    (void)hipMemsetAsync(c->stripe_sums.p, 0, (size_t)c->nchunks * 256 * 4, c->stream);
+    hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks * 4), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), c->hist_per, klo, khi, c->stripe_sums.as<u32>());
     hipLaunchKernelGGL(k_stripes, dim3(256), dim3(128), 0, c->stream, c->stripe_sums.as<u32>(), c->nchunks,
                        c->seg0_base.as<u32>(), c->cursor0.as<u32>());
 }

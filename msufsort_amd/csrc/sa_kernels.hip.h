@@ -299,12 +299,18 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u3
 }
 
 // sums the per-chunk partials (indexed by the memory-order key) and stores them under the big-endian key
-__global__ __launch_bounds__(1024) void k_reduce16(const u32* __restrict__ partial, u32 nchunks, u32* __restrict__ hist)
+__global__ __launch_bounds__(256) void k_reduce16(const u32* __restrict__ partial, u32 nchunks, u32* __restrict__ hist)
 {
-    const u32 kle = blockIdx.x * 1024u + threadIdx.x;          // T[i] | T[i+1] << 8
-    u32 s = 0;
-    for (u32 c = 0; c < nchunks; ++c) s += partial[(u64)c * 65536u + kle];
-    hist[((kle & 255u) << 8) | (kle >> 8)] = s;
+    // 256 workgroups (one per CU) x 256 keys; four independent partial sums keep four loads in flight per lane
+    const u32 kle = blockIdx.x * 256u + threadIdx.x;           // T[i] | T[i+1] << 8
+    u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    u32 c = 0;
+    for (; c + 4 <= nchunks; c += 4) {
+        s0 += partial[(u64)c * 65536u + kle]; s1 += partial[(u64)(c + 1) * 65536u + kle];
+        s2 += partial[(u64)(c + 2) * 65536u + kle]; s3 += partial[(u64)(c + 3) * 65536u + kle];
+    }
+    for (; c < nchunks; ++c) s0 += partial[(u64)c * 65536u + kle];
+    hist[((kle & 255u) << 8) | (kle >> 8)] = s0 + s1 + s2 + s3;
 }
 
 // Exclusive scan of the 65,536 counts (bucket offsets, cpp:1603-1630) + set-up of the two scatter
@@ -382,13 +388,12 @@ __global__ __launch_bounds__(1024) void k_scan16(const u32* __restrict__ hist, u
 // suffixes with first byte b in earlier stripes (from the per-chunk histograms k_hist16 left behind).  With one
 // cursor set per stripe the 256 output streams become 256 x nchunks, which spreads the scatter's writes
 // (and its claim atomics) over all HBM channels.
-__global__ __launch_bounds__(1024) void k_stripe_sums(const u32* __restrict__ partial, u32 per, u32 klo, u32 khi, u32* __restrict__ sums)
+__global__ __launch_bounds__(256) void k_stripe_sums(const u32* __restrict__ partial, u32 per, u32 klo, u32 khi, u32* __restrict__ sums /* zeroed */)
 {
     // sums[stripe][b] = in-range suffixes of this stripe (= `per` histogram chunks) whose first byte is b.
     // partial[] is indexed in memory byte order (first byte in the low 8 bits), so row b1 of a chunk is
-    // contiguous over b: coalesced reads.
-    __shared__ u32 acc[4][256];
-    const u32 c = blockIdx.x, b = threadIdx.x & 255u, q = threadIdx.x >> 8;
+    // contiguous over b: coalesced reads.  Four workgroups per stripe, one quarter of the second bytes each.
+    const u32 c = blockIdx.x >> 2, q = blockIdx.x & 3u, b = threadIdx.x;
     u32 sum = 0;
     for (u32 h = 0; h < per; ++h) {
         const u32* p = partial + (u64)(c * per + h) * 65536u;
@@ -400,9 +405,7 @@ __global__ __launch_bounds__(1024) void k_stripe_sums(const u32* __restrict__ pa
             sum += (k >= klo && k < khi) ? v : 0u;
         }
     }
-    acc[q][b] = sum;
-    __syncthreads();
-    if (q == 0) sums[c * 256u + b] = acc[0][b] + acc[1][b] + acc[2][b] + acc[3][b];
+    if (sum) atomicAdd(&sums[c * 256u + b], sum);
 }
 
 __global__ __launch_bounds__(128) void k_stripes(const u32* __restrict__ sums, u32 nchunks,

@@ -32,7 +32,7 @@ int main(int argc, char** argv)
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
-    k_reduce16<<<64, 1024>>>(p1, nc * per, h1);
+    k_reduce16<<<256, 256>>>(p1, nc * per, h1);
     CK(hipDeviceSynchronize());
     std::vector<u32> a(65536, 0), b(65536);
     for (u64 i = 0; i < n; ++i) a[(h[i] << 8) | h[i + 1]]++;
