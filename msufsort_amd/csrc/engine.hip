@@ -91,6 +91,7 @@ struct msufsort_hip_ctx {
     {
         if (attrs_set) return MSUFSORT_HIP_OK;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan16), hipFuncAttributeMaxDynamicSharedMemorySize, SCAN16_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS>),
@@ -256,9 +257,11 @@ int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
 
 void run_scan(msufsort_hip_ctx* c, u32 klo, u32 khi, u64 z)
 {
-    hipLaunchKernelGGL(k_scan16, dim3(1), dim3(1024), 0, c->stream, c->hist.as<u32>(), c->bstart.as<u32>(), klo, khi,
+    hipLaunchKernelGGL(k_scan16, dim3(1), dim3(1024), SCAN16_LDS_BYTES, c->stream, c->hist.as<u32>(), c->bstart.as<u32>(), klo, khi,
                        c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->seg0_base.as<u32>(),
                        c->seg0.as<Desc>(), c->tile_start.as<u32>(), c->counters.as<u32>(), (u32)z);
+    hipLaunchKernelGGL(k_scan16_post, dim3(64), dim3(1024), 0, c->stream, c->hist.as<u32>(), c->bstart.as<u32>(), klo, khi,
+                       c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->counters.as<u32>());
     hipLaunchKernelGGL(k_alphabet, dim3(1), dim3(256), 0, c->stream, c->hist.as<u32>(), c->alpha.as<u8>(), c->counters.as<u32>());
     (void)hipMemsetAsync(c->stripe_sums.p, 0, (size_t)c->nchunks * 256 * 4, c->stream);
     hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks * 4), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), c->hist_per, klo, khi, c->stripe_sums.as<u32>());

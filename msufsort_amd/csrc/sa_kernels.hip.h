@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) void k_reduce16(const u32* __restrict__ partia
     hist[((kle & 255u) << 8) | (kle >> 8)] = s0 + s1 + s2 + s3;
 }
 
+#define SCAN16_LDS_BYTES ((32768u + 1024u + 32u) * 4u)
 // Exclusive scan of the 65,536 counts (bucket offsets, cpp:1603-1630) + set-up of the two scatter
 // levels for the key range [klo, khi) of this shard.  One workgroup of 1024 threads.
 __global__ __launch_bounds__(1024) void k_scan16(const u32* __restrict__ hist, u32* __restrict__ bstart /*65537*/,
@@ -324,39 +325,57 @@ __global__ __launch_bounds__(1024) void k_scan16(const u32* __restrict__ hist, u
 {
     __shared__ u32 wsum[16];
     __shared__ u32 s_in[256], s_out[256];
+    __shared__ u32 s_half;
+    extern __shared__ u32 tbuf[];                       // SCAN16_LDS_BYTES: 32768 words, one pad word per 32
     const u32 t = threadIdx.x;
-    u32 loc = 0;
-    for (u32 k = 0; k < 64; ++k) loc += hist[t * 64 + k];
-    u32 wtot;
-    u32 ex = wave_excl_scan(loc, wtot);
-    if (lane_id() == 63) wsum[t >> 6] = wtot;
-    __syncthreads();
-    if (t < 64) {
-        u32 v = (t < 16) ? wsum[t] : 0, tot;
-        u32 e = wave_excl_scan(v, tot);
-        if (t < 16) wsum[t] = e;
-        if (t == 0) bstart[65536] = tot;
+    // A thread scans 32 CONSECUTIVE bins per half of the key space.  Reading them straight from global memory makes
+    // every load instruction touch 64 cache lines; instead each half goes through LDS: coalesced global accesses on
+    // one side, conflict-free rows (index i lives at i + i / 32) on the other.
+#define SC_PAD(i) ((i) + ((i) >> 5))
+    u32 v[2][32];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+#pragma unroll 8
+        for (u32 k = 0; k < 32; ++k) tbuf[SC_PAD(k * 1024u + t)] = hist[h * 32768u + k * 1024u + t];
+        __syncthreads();
+#pragma unroll
+        for (u32 k = 0; k < 32; ++k) v[h][k] = tbuf[t * 33u + k];
     }
-    __syncthreads();
-    u32 run = wsum[t >> 6] + ex;
-    for (u32 k = 0; k < 64; ++k) { bstart[t * 64 + k] = run; run += hist[t * 64 + k]; }
+    u32 ex[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        u32 loc = 0;
+#pragma unroll
+        for (u32 k = 0; k < 32; ++k) loc += v[h][k];
+        u32 wtot;
+        u32 e = wave_excl_scan(loc, wtot);
+        __syncthreads();
+        if (lane_id() == 63) wsum[t >> 6] = wtot;
+        __syncthreads();
+        if (t < 64) {
+            u32 w = (t < 16) ? wsum[t] : 0, tot;
+            u32 we = wave_excl_scan(w, tot);
+            if (t < 16) wsum[t] = we;
+            if (t == 0) { if (h == 0) s_half = tot; else bstart[65536] = s_half + tot; }
+        }
+        __syncthreads();
+        ex[h] = wsum[t >> 6] + e + (h ? s_half : 0u);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        u32 run = ex[h];
+#pragma unroll
+        for (u32 k = 0; k < 32; ++k) { tbuf[t * 33u + k] = run; run += v[h][k]; }
+        __syncthreads();
+#pragma unroll 8
+        for (u32 k = 0; k < 32; ++k) bstart[h * 32768u + k * 1024u + t] = tbuf[SC_PAD(k * 1024u + t)];
+    }
+#undef SC_PAD
+    __threadfence_block();
     __syncthreads();
     const u32 base = bstart[klo];
-    u32 hmax = 0, hnz = 0;
-    for (u32 key = t; key < 65536u; key += 1024u) {
-        const bool in = key >= klo && key < khi;
-        const u32 s = in ? bstart[key] - base : 0u;
-        child_start[key] = s;
-        cursor1[key] = s;
-        const u32 c = in ? hist[key] : 0u;
-        child_cnt[key] = c;
-        hmax = c > hmax ? c : hmax;
-        if (c) ++hnz;
-    }
-    if (hnz) atomicAdd(&counters[C_HNZ], hnz);
-#pragma unroll
-    for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(hmax, s2, 64); hmax = o > hmax ? o : hmax; }
-    if (lane_id() == 0) atomicMax(&counters[C_HMAX], hmax);
     if (t < 256) {
         u32 lo = t << 8, hi = (t + 1) << 8;
         if (lo < klo) lo = klo;
@@ -376,6 +395,32 @@ __global__ __launch_bounds__(1024) void k_scan16(const u32* __restrict__ hist, u
     }
     __syncthreads();
     if (t < 256) tile_start0[t] = s_out[t];
+}
+
+// per-key outputs of the scan for the level-1 partition (child offsets, cursors, counts) + the two statistics the host
+// reads (largest bucket, number of non-empty buckets): 64 workgroups instead of the tail of a single one
+__global__ __launch_bounds__(1024) void k_scan16_post(const u32* __restrict__ hist, const u32* __restrict__ bstart, u32 klo, u32 khi,
+                                                      u32* __restrict__ child_start, u32* __restrict__ child_cnt,
+                                                      u32* __restrict__ cursor1, u32* __restrict__ counters)
+{
+    const u32 key = blockIdx.x * 1024u + threadIdx.x;
+    const u32 base = bstart[klo];
+    const bool in = key >= klo && key < khi;
+    const u32 s = in ? bstart[key] - base : 0u;
+    child_start[key] = s;
+    cursor1[key] = s;
+    const u32 c = in ? hist[key] : 0u;
+    child_cnt[key] = c;
+    u32 hmax = c;
+    const u32 hnz = (u32)__popcll(__ballot(c != 0));
+#pragma unroll
+    for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(hmax, s2, 64); hmax = o > hmax ? o : hmax; }
+    __shared__ u32 s_nz, s_mx;                // (one pair of global atomics per workgroup: ~90 per us is all one address takes)
+    if (threadIdx.x == 0) { s_nz = 0; s_mx = 0; }
+    __syncthreads();
+    if (lane_id() == 0) { if (hnz) atomicAdd(&s_nz, hnz); if (hmax) atomicMax(&s_mx, hmax); }
+    __syncthreads();
+    if (threadIdx.x == 0) { if (s_nz) atomicAdd(&counters[C_HNZ], s_nz); if (s_mx) atomicMax(&counters[C_HMAX], s_mx); }
 }
 
 // ------------------------------------------------------------------------------------------------
