@@ -157,6 +157,11 @@ class DeviceContext:
         o = _opts(self.device, verbose, text_rounds)
         _lib.check(self._L.msufsort_hip_make_sa_i32_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa), C.byref(o)), "make_sa_dev")
 
+    def make_sa_i64(self, d_text, n: int, d_sa64, *, verbose=0, text_rounds=0):
+        """d_text: >= n+64 bytes in HBM; d_sa64: n+1 int64 in HBM (the int32 rows, widened on the device)."""
+        o = _opts(self.device, verbose, text_rounds)
+        _lib.check(self._L.msufsort_hip_make_sa_i64_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa64), C.byref(o)), "make_sa_i64_dev")
+
     def shard_bounds(self, d_text, n: int, n_shards: int):
         b = (C.c_int64 * (n_shards + 1))()
         _lib.check(self._L.msufsort_hip_shard_bounds_dev(self._h, self._ptr(d_text), n, n_shards, b), "shard_bounds")

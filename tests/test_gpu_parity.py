@@ -52,6 +52,12 @@ def test_int64_output(M):
     a, b = M.make_suffix_array(t), M.make_suffix_array_i64(t)
     assert b.dtype == np.int64 and (a.astype(np.int64) == b).all()
     assert M.make_suffix_array_i64(np.zeros(0, np.uint8)).tolist() == [0]
+    import torch
+    ctx = M.DeviceContext(0)
+    d = _dev(M, t)
+    s64 = torch.empty(t.size + 1, dtype=torch.int64, device="cuda")
+    ctx.make_sa_i64(d, t.size, s64)
+    assert (s64.cpu().numpy() == b).all()
 
 
 def test_empty_input(M):
