@@ -306,6 +306,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
     int text_rounds = (opts && opts->text_rounds > 0) ? opts->text_rounds : 24;
     u64 prev_active = 0;
     bool exact_sticky = false;
+    bool fast_gave_up = false;       // k_sort_fast2 was tried on packed keys in a later round and mostly refused
     if (const char* e = getenv("MSUFSORT_HIP_TEXT_ROUNDS")) text_rounds = std::max(1, atoi(e));
     const u64 m = n - z;
     hipStream_t st = c->stream;
@@ -494,7 +495,14 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         // phase, rejection) would be wasted work - go straight to the LSD sort.
         const u64 ms_shard = c->h_counters[C_MS];
         const bool spread = (u64)c->h_counters[C_HMAX] * (u64)(khi - klo) <= 8ull * std::max<u64>(ms_shard, 1);   // max <= 8 x mean
-        const bool use_fast = getenv("MSUFSORT_HIP_NO_FAST") == nullptr && (spread || getenv("MSUFSORT_HIP_FORCE_FAST"));
+        // Later rounds of a small-alphabet input sort dense base-sigma keys: if the symbols are about evenly used
+        // (largest two-byte bucket <= 2 x the mean of the non-empty ones: random DNA, base64, hex dumps) the children of
+        // the partition levels are as spread out as random bytes.  The attempt is dropped for the rest of the build as
+        // soon as a round hands more than a quarter of its segments back (tandem repeats, text).
+        const bool dense_uniform = round >= 1 && cpk != 4u &&
+                                   (u64)c->h_counters[C_HMAX] * (u64)std::max<u32>(c->h_counters[C_HNZ], 1u) <= 2ull * std::max<u64>(ms_shard, 1);
+        const bool use_fast = getenv("MSUFSORT_HIP_NO_FAST") == nullptr &&
+                              (spread || (dense_uniform && !fast_gave_up) || getenv("MSUFSORT_HIP_FORCE_FAST"));
         if (use_fast && (nB || nC)) hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << C_FBB) | (1u << C_FBC));
         if (nC) {
             const u32* ids = nullptr;
@@ -556,7 +564,10 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         DBG("k_sort_tiny");
         if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
         TRY(c->read_counters(attempt == 0));
-        if (c->h_counters[C_ERR] == 0) break;
+        if (c->h_counters[C_ERR] == 0) {
+            if (use_fast && round >= 1 && (u64)(c->h_counters[C_FBB] + c->h_counters[C_FBC]) * 4 > (u64)nB + nC) fast_gave_up = true;
+            break;
+        }
         exact_sticky = true;
         {   // attempt 0 ran out of room: forget what it reserved for the next round and go again
             if (verbose) fprintf(stderr, "[msufsort_hip] round %d: reservation slack exhausted (flags 0x%x), repeating with exact reservations\n", round, c->h_counters[C_ERR]);
