@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void k_lcp(const u8* __restrict__ text, u64 n,
                                              u32 cap, u32* __restrict__ flag)
 {
     for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u) {
+        if (*reinterpret_cast<volatile u32*>(flag)) return;       // somebody met a pair beyond the cap: the host switches to PLCP, stop here
         u32 v = 0;
         if (i + 1 < n) {
             u64 a = sa[i + 1], b = sa[i + 2];
