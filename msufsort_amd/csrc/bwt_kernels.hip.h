@@ -112,25 +112,27 @@ __global__ __launch_bounds__(256) void k_lcp_from_plcp(const u32* __restrict__ s
 // byte, which is O(n * LCP) and takes minutes on periodic inputs; the order test used here is the exact linear one:
 // with rank = inverse permutation (rank of the empty suffix = 0),
 //     suffix a < suffix b  <=>  T[a] < T[b]  or  (T[a] == T[b] and rank[a+1] < rank[b+1]).
-__global__ __launch_bounds__(256) void k_validate_perm(u64 n, const u32* __restrict__ sa, u32* __restrict__ seen /* ceil(n/32) zeroed */,
-                                                       u32* __restrict__ rank /* n+1 */, unsigned long long* __restrict__ errors)
+__global__ __launch_bounds__(256) void k_validate_perm(u64 n, const u32* __restrict__ sa, u32* __restrict__ rank /* n+1 */,
+                                                       unsigned long long* __restrict__ errors)
 {
     for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r <= n; r += (u64)gridDim.x * 256u) {
         const u32 v = sa[r];
         if (r == 0) { if (v != (u32)n) atomicAdd(errors, 1ull); rank[n] = 0; continue; }
         if (v >= n) { atomicAdd(errors, 1ull); continue; }
-        const u32 old = atomicOr(&seen[v >> 5], 1u << (v & 31));
-        if (old & (1u << (v & 31))) atomicAdd(errors, 1ull);
-        rank[v] = (u32)r;
+        rank[v] = (u32)r;                       // duplicates: one row wins, k_validate_order sees the others
     }
 }
 
 __global__ __launch_bounds__(256) void k_validate_order(const u8* __restrict__ text, u64 n, const u32* __restrict__ sa,
                                                         const u32* __restrict__ rank, unsigned long long* __restrict__ errors)
 {
-    for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x + 2; r <= n; r += (u64)gridDim.x * 256u) {
-        const u32 a = sa[r - 1], b = sa[r];
-        if (a >= n || b >= n) continue;                    // already counted by k_validate_perm
+    for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x + 1; r <= n; r += (u64)gridDim.x * 256u) {
+        const u32 b = sa[r];
+        if (b >= n) continue;                               // already counted by k_validate_perm
+        if (rank[b] != (u32)r) { atomicAdd(errors, 1ull); continue; }      // permutation: every value names its own row
+        if (r < 2) continue;
+        const u32 a = sa[r - 1];
+        if (a >= n) continue;
         const u32 ca = text[a], cb = text[b];
         const bool ok = ca < cb || (ca == cb && rank[a + 1] < rank[b + 1]);
         if (!ok) atomicAdd(errors, 1ull);
