@@ -337,7 +337,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         if (klo == 0) rank0 = z;
         else { HIP_TRY(hipMemcpyAsync(c->h_bstart, c->bstart.p, 65537 * 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); rank0 = z + c->h_bstart[klo]; }
         sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
-        hipLaunchKernelGGL(k_scatter0, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, (u32)m, klo, khi, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0]);
+        hipLaunchKernelGGL(k_scatter0, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, (u32)m, klo, khi, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0], c->alpha.as<u8>(), counters, getenv("MSUFSORT_HIP_NO_PACK") ? 0u : 1u);
         HIP_TRY(hipEventRecord(c->ev[2], st));
         DBG("k_scatter0");
         hipLaunchKernelGGL(k_partition, dim3(cdiv(cdiv(m, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
@@ -420,7 +420,10 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
             }
             else { src_list = c->large_round[cur].as<Desc>(); nl = c->h_counters[(cur ? C_LIST1 : C_LIST0) + 3]; ntiles = c->h_counters[cur ? C_LTILES1 : C_LTILES0]; lp = 0; shift = 24; }
             while (nl > 0) {
-                const bool last = (shift == 0);
+                // (tiny alphabets: k_scatter0 left only the top two key bytes non-zero, a level at or below bit 16 ends round 0's splitting)
+                const bool tiny0 = round == 0 && !getenv("MSUFSORT_HIP_NO_PACK") &&
+                                   (u64)c->h_counters[C_ASIGMA] * c->h_counters[C_ASIGMA] * c->h_counters[C_ASIGMA] <= 256 && c->h_counters[C_ASIGMA] >= 2;
+                const bool last = (shift == 0) || (tiny0 && shift <= 16);
                 const u32 cnt_idx = lp ? C_LVL1 : C_LVL0, til_idx = lp ? C_LVLT1 : C_LVLT0;
                 hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << cnt_idx) | (1u << til_idx));
                 hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, src_list, nl, c->tile_start.as<u32>());

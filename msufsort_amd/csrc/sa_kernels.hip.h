@@ -468,8 +468,15 @@ __global__ __launch_bounds__(128) void k_stripes(const u32* __restrict__ sums, u
 }
 
 __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ text, u32 m, u32 klo, u32 khi, u32 chunk_len,
-                                                         u32* __restrict__ cursor0, u64* __restrict__ out)
+                                                         u32* __restrict__ cursor0, u64* __restrict__ out,
+                                                         const u8* __restrict__ code, const u32* __restrict__ counters, u32 allow_pack)
 {
+    // Tiny alphabets (sigma^3 <= 256, e.g. DNA): the three key bytes behind the second byte hold 4 values each, so
+    // three partition levels would each split 4 ways.  Their three symbols are written as ONE dense base-sigma digit
+    // in the top key byte below the bucket byte instead (the rest of the key is 0): same depth, one level.
+    __shared__ u8 s_code[256];
+    const u32 sigma = counters[C_ASIGMA];
+    const bool tiny = allow_pack != 0u && sigma * sigma * sigma <= 256u;      // kernel-uniform
     __shared__ __attribute__((aligned(16))) u64 stage[S0_TILE];
     __shared__ __attribute__((aligned(16))) u8 sbin[S0_TILE];
     __shared__ u32 hist[256], lstart[256], gbase[256];
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
     const u64 base0 = (u64)xcd_tile(blockIdx.x, chunk_len / S0_TILE) * S0_TILE;
     if (base0 >= m) return;
     const u64 base = base0 + (u64)t * S0_POS;
-    if (t < 256) hist[t] = 0;
+    if (t < 256) { hist[t] = 0; if (tiny) s_code[t] = code[t]; }
     __syncthreads();
     u32 w[S0_POS / 4 + 2];
 #pragma unroll
@@ -510,9 +517,16 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
         if (validmask & (1u << j)) {
             const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
             u32 key = 0;
+            if (!tiny) {
 #pragma unroll
-            for (int q = 1; q <= 4; ++q)
-                key = (key << 8) | ((w[(j + q) >> 2] >> (8 * ((j + q) & 3))) & 255u);
+                for (int q = 1; q <= 4; ++q)
+                    key = (key << 8) | ((w[(j + q) >> 2] >> (8 * ((j + q) & 3))) & 255u);
+            } else {
+                u32 dg = 0;
+#pragma unroll
+                for (int q = 2; q <= 4; ++q) dg = dg * sigma + (u32)s_code[(w[(j + q) >> 2] >> (8 * ((j + q) & 3))) & 255u];
+                key = (((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u) << 24) | (dg << 16);
+            }
             const u32 slot = lstart[b0] + rank[j];
             stage[slot] = ((u64)key << 32) | (u64)(u32)(base + j);
             sbin[slot] = (u8)b0;
