@@ -589,11 +589,13 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         if (actP + actS == 0) break;
         if (round == 0 && !resume) {     // key packing for the gather rounds (k_alphabet ran with the histogram)
             const u32 b = c->h_counters[C_ABITS], sg = c->h_counters[C_ASIGMA];
-            if (b >= 2 && b < 7 && sg >= 2 && !getenv("MSUFSORT_HIP_NO_PACK")) {
+            if (b >= 2 && sg >= 2 && !getenv("MSUFSORT_HIP_NO_PACK")) {
                 u64 p = 1; u32 k = 0;
                 while (k < 16 && p * sg <= (1ull << 32)) { p *= sg; ++k; }       // sigma^k <= 2^32
-                u32 bl = 0; while (bl < 32 && ((p - 1) >> bl) != 0) ++bl;         // bits of the largest key
-                asigma = sg; cpk = k; zlow = 32 - bl;
+                if (k >= 5) {                                                     // (sigma <= 84: at least one symbol more than a 4-byte window)
+                    u32 bl = 0; while (bl < 32 && ((p - 1) >> bl) != 0) ++bl;     // bits of the largest key
+                    asigma = sg; cpk = k; zlow = 32 - bl;
+                }
             }
             if (verbose) fprintf(stderr, "[msufsort_hip] alphabet: %u codes (%u bits) -> %u symbols per key\n", sg, b, cpk);
         }

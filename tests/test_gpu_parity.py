@@ -135,20 +135,14 @@ def test_lcp_plcp_path(M, oracle_mod, monkeypatch):
 
 
 def _symbols_per_key(t):
-    """Symbols one gather round consumes: 4 bytes, or (alphabets below 7 bits) as many symbols of the dense alphabet
-    code as fit one 32-bit number in base sigma (k_alphabet, k_refill)."""
-    sigma = len(set(np.unique(t).tolist()) - {0}) + 1
-    bits = 1
-    while (1 << bits) < sigma:
-        bits += 1
-    if max(bits, 2) >= 7:
-        return 4
-    sigma = max(sigma, 2)
+    """Symbols one gather round consumes: as many symbols of the dense alphabet code as fit one 32-bit number in base
+    sigma (k_alphabet, k_refill) when that is more than the 4 bytes of a plain window (sigma <= 84)."""
+    sigma = max(len(set(np.unique(t).tolist()) - {0}) + 1, 2)
     k, p = 0, 1
     while k < 16 and p * sigma <= (1 << 32):
         p *= sigma
         k += 1
-    return k
+    return k if k >= 5 else 4
 
 
 def _dev(M, t):
