@@ -420,10 +420,13 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
             }
             else { src_list = c->large_round[cur].as<Desc>(); nl = c->h_counters[(cur ? C_LIST1 : C_LIST0) + 3]; ntiles = c->h_counters[cur ? C_LTILES1 : C_LTILES0]; lp = 0; shift = 24; }
             while (nl > 0) {
-                // (tiny alphabets: k_scatter0 left only the top two key bytes non-zero, a level at or below bit 16 ends round 0's splitting)
-                const bool tiny0 = round == 0 && !getenv("MSUFSORT_HIP_NO_PACK") &&
-                                   (u64)c->h_counters[C_ASIGMA] * c->h_counters[C_ASIGMA] * c->h_counters[C_ASIGMA] <= 256 && c->h_counters[C_ASIGMA] >= 2;
-                const bool last = (shift == 0) || (tiny0 && shift <= 16);
+                // (small alphabets: k_scatter0 left only the top bl0 of the 24 key bits non-zero; a level that reaches below
+                // them ends round 0's splitting)
+                const u32 sg0 = c->h_counters[C_ASIGMA];
+                const bool packed0 = round == 0 && !getenv("MSUFSORT_HIP_NO_PACK") && sg0 >= 2 && sg0 <= 84;
+                u32 bl0 = 0;
+                if (packed0) while (bl0 < 32 && (((u64)sg0 * sg0 * sg0 - 1) >> bl0) != 0) ++bl0;
+                const bool last = (shift == 0) || (packed0 && shift <= 24 - bl0);
                 const u32 cnt_idx = lp ? C_LVL1 : C_LVL0, til_idx = lp ? C_LVLT1 : C_LVLT0;
                 hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << cnt_idx) | (1u << til_idx));
                 hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, src_list, nl, c->tile_start.as<u32>());
@@ -502,7 +505,10 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         // (largest two-byte bucket <= 2 x the mean of the non-empty ones: random DNA, base64, hex dumps) the children of
         // the partition levels are as spread out as random bytes.  The attempt is dropped for the rest of the build as
         // soon as a round hands more than a quarter of its segments back (tandem repeats, text).
-        const bool dense_uniform = round >= 1 && cpk != 4u &&
+        // (round 0's dense digits give class-B children of a few hundred records: the 2^13-entry table of k_sort_fast2 costs
+        // more than it saves there - measured on 16..80-symbol random texts - so the dense keys only count from round 1 on)
+        // ... and only for alphabets of up to 16 codes (>= 8 symbols per key): measured, a 17-code hex text loses 11 ms to it
+        const bool dense_uniform = round >= 1 && cpk >= 8u &&
                                    (u64)c->h_counters[C_HMAX] * (u64)std::max<u32>(c->h_counters[C_HNZ], 1u) <= 2ull * std::max<u64>(ms_shard, 1);
         const bool use_fast = getenv("MSUFSORT_HIP_NO_FAST") == nullptr &&
                               (spread || (dense_uniform && !fast_gave_up) || getenv("MSUFSORT_HIP_FORCE_FAST"));
@@ -568,7 +574,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
         TRY(c->read_counters(attempt == 0));
         if (c->h_counters[C_ERR] == 0) {
-            if (use_fast && round >= 1 && (u64)(c->h_counters[C_FBB] + c->h_counters[C_FBC]) * 4 > (u64)nB + nC) fast_gave_up = true;
+            if (use_fast && !spread && (u64)(c->h_counters[C_FBB] + c->h_counters[C_FBC]) * 4 > (u64)nB + nC) fast_gave_up = true;
             break;
         }
         exact_sticky = true;

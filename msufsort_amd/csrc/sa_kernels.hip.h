@@ -471,12 +471,15 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
                                                          u32* __restrict__ cursor0, u64* __restrict__ out,
                                                          const u8* __restrict__ code, const u32* __restrict__ counters, u32 allow_pack)
 {
-    // Tiny alphabets (sigma^3 <= 256, e.g. DNA): the three key bytes behind the second byte hold 4 values each, so
-    // three partition levels would each split 4 ways.  Their three symbols are written as ONE dense base-sigma digit
-    // in the top key byte below the bucket byte instead (the rest of the key is 0): same depth, one level.
+    // Small alphabets (up to 84 codes, k_alphabet): the three key symbols behind the second byte are written as ONE
+    // dense base-sigma number, left-aligned in the 24 key bits below the bucket byte.  Same depth (5 characters), but
+    // the partition levels below the two-byte buckets split on evenly used bits: one level instead of three for DNA
+    // (sigma^3 = 125 values), two for a 28-letter text, and children that k_sort_fast2 accepts when the symbols are
+    // evenly used.
     __shared__ u8 s_code[256];
     const u32 sigma = counters[C_ASIGMA];
-    const bool tiny = allow_pack != 0u && sigma * sigma * sigma <= 256u;      // kernel-uniform
+    const bool tiny = allow_pack != 0u && sigma >= 2u && sigma <= 84u;        // kernel-uniform
+    const u32 dshift = tiny ? 24u - (32u - (u32)__clz((int)(sigma * sigma * sigma - 1u))) : 0u;
     __shared__ __attribute__((aligned(16))) u64 stage[S0_TILE];
     __shared__ __attribute__((aligned(16))) u8 sbin[S0_TILE];
     __shared__ u32 hist[256], lstart[256], gbase[256];
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
                 u32 dg = 0;
 #pragma unroll
                 for (int q = 2; q <= 4; ++q) dg = dg * sigma + (u32)s_code[(w[(j + q) >> 2] >> (8 * ((j + q) & 3))) & 255u];
-                key = (((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u) << 24) | (dg << 16);
+                key = (((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u) << 24) | (dg << dshift);
             }
             const u32 slot = lstart[b0] + rank[j];
             stage[slot] = ((u64)key << 32) | (u64)(u32)(base + j);
