@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmsufsort_hip.so")
+# MSUFSORT_HIP_LIB selects an alternative build of the same C-ABI (profiling / experiment builds); the product library
+# in msufsort_amd/lib/ is never overwritten by tooling.
+LIB_PATH = os.environ.get("MSUFSORT_HIP_LIB") or os.path.join(_HERE, "lib", "libmsufsort_hip.so")
 
 TEXT_PAD = 64
 

@@ -86,6 +86,7 @@ struct msufsort_hip_ctx {
     u64 cap_for_m = 0;           // largest m the workspace was sized for
     msufsort_hip_timings tm{};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int sync_debug = 0;          // MSUFSORT_HIP_SYNC_DEBUG, read once when the context is created
 
     int set_attrs()
     {
@@ -183,6 +184,9 @@ __global__ void k_zero_idx(u32* counters, u32 mask)
     if (t < C_NCOUNTERS && ((mask >> t) & 1u)) counters[t] = 0;
 }
 
+// counters[dst] = counters[src]
+__global__ void k_copy_idx(u32* counters, u32 dst, u32 src) { if (threadIdx.x == 0) counters[dst] = counters[src]; }
+
 __global__ void k_last_nonzero(const u8* __restrict__ text, u64 n, unsigned long long* out)
 {
     unsigned long long best = 0;
@@ -224,14 +228,13 @@ int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out)
 // MSUFSORT_HIP_SYNC_DEBUG=1: synchronise and check after every phase so a faulting kernel is named
 #define DBG(label)                                                                                   \
     do {                                                                                             \
-        if (g_sync_debug) {                                                                          \
+        if (c->sync_debug) {                                                                         \
             hipError_t e_ = hipStreamSynchronize(c->stream);                                         \
             if (e_ == hipSuccess) e_ = hipGetLastError();                                            \
             if (e_ != hipSuccess) { set_error("after %s: %s", label, hipGetErrorString(e_)); return MSUFSORT_HIP_ERR_HIP; } \
-            if (g_sync_debug > 1) fprintf(stderr, "[dbg] %s ok\n", label);                           \
+            if (c->sync_debug > 1) fprintf(stderr, "[dbg] %s ok\n", label);                          \
         }                                                                                            \
     } while (0)
-int g_sync_debug = 0;
 
 struct ShardPlan {
     u32 klo = 0, khi = 65536;
@@ -248,6 +251,7 @@ int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
     chunk_len = (chunk_len + 32767) / 32768 * 32768;
     const u32 per = chunk_len >= 131072 ? 2 : 1;
     const u32 hchunks = nchunks * per;
+    TRY(c->set_attrs());          // (k_hist16 takes 136 KiB of dynamic LDS; shard planning reaches this before any build)
     c->nchunks = nchunks; c->chunk_len = (u32)chunk_len; c->hist_per = per;
     hipLaunchKernelGGL(k_hist16, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, (u32)m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>());
     hipLaunchKernelGGL(k_reduce16, dim3(256), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), hchunks, c->hist.as<u32>());
@@ -300,13 +304,14 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
              u32* d_grp_rows = nullptr, u64 resume_depth = 0, u64 slice_rows = 0)
 {
     const int verbose = opts ? opts->verbose : 0;
-    if (const char* e = getenv("MSUFSORT_HIP_SYNC_DEBUG")) g_sync_debug = atoi(e);
     const bool sharded = opts && opts->n_shards > 1;
     const bool auto_switch = !(opts && opts->text_rounds > 0) && !getenv("MSUFSORT_HIP_TEXT_ROUNDS");
     int text_rounds = (opts && opts->text_rounds > 0) ? opts->text_rounds : 24;
     u64 prev_active = 0;
     bool exact_sticky = false;
     bool fast_gave_up = false;       // k_sort_fast2 was tried on packed keys in a later round and mostly refused
+    const bool force_retry = getenv("MSUFSORT_HIP_FORCE_RETRY") != nullptr;   // test hook: every round's first sort attempt is
+                                                                             // thrown away and repeated with exact reservations
     if (const char* e = getenv("MSUFSORT_HIP_TEXT_ROUNDS")) text_rounds = std::max(1, atoi(e));
     const u64 m = n - z;
     hipStream_t st = c->stream;
@@ -457,6 +462,8 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                                            c->large_round[nxt].as<Desc>(), c->large_cap, (u32)((nxt ? C_LIST1 : C_LIST0) + 3), (u32)(nxt ? C_LTILES1 : C_LTILES0), counters);
                         hipLaunchKernelGGL(k_carry_copy, dim3(ntiles), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.as<u32>(), c->trivial.as<u32>(),
                                            sa_local, c->isa.as<u32>(), mode, bufs.p[nb], counters);
+                        // what the carry reserved must survive a repeated sort attempt (see the retry below)
+                        hipLaunchKernelGGL(k_copy_idx, dim3(1), dim3(64), 0, st, counters, (u32)C_CARRY, (u32)(nxt ? C_SEG1 : C_SEG0));
                         DBG("k_carry");
                     }
                     break;
@@ -537,7 +544,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, emC, counters, ids, (u32)C_FBC);
             DBG("k_sort_mid C");
         }
-        if (g_sync_debug) {
+        if (c->sync_debug) {
             for (int k = 0; k < 3; ++k) {
                 const u32 cnt = c->h_counters[base + k];
                 if (!cnt) continue;
@@ -573,15 +580,19 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         DBG("k_sort_tiny");
         if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
         TRY(c->read_counters(attempt == 0));
+        if (attempt == 0 && force_retry) c->h_counters[C_ERR] |= 0x8000u;      // test hook: MSUFSORT_HIP_FORCE_RETRY=1
         if (c->h_counters[C_ERR] == 0) {
             if (use_fast && !spread && (u64)(c->h_counters[C_FBB] + c->h_counters[C_FBC]) * 4 > (u64)nB + nC) fast_gave_up = true;
             break;
         }
-        exact_sticky = true;
+        if (c->h_counters[C_ERR] & ~0x8000u) exact_sticky = true;    // (the test hook repeats EVERY round's first attempt)
         {   // attempt 0 ran out of room: forget what it reserved for the next round and go again
             if (verbose) fprintf(stderr, "[msufsort_hip] round %d: reservation slack exhausted (flags 0x%x), repeating with exact reservations\n", round, c->h_counters[C_ERR]);
             const u32 nP_ = nxt ? C_POOL1 : C_POOL0, nS_ = nxt ? C_SEG1 : C_SEG0, nL_ = nxt ? C_LIST1 : C_LIST0;
-            hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << nP_) | (1u << nS_) | (0x7u << nL_) | (1u << C_ERR));
+            // (carried large segments already sit at the start of next round's segment array, their descriptors in
+            // its large list: the segment counter goes back to the end of the carry, not to 0, and the large list stays)
+            hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << nP_) | (0x7u << nL_) | (1u << C_ERR));
+            hipLaunchKernelGGL(k_copy_idx, dim3(1), dim3(64), 0, st, counters, nS_, (u32)C_CARRY);
         }
         }
 
@@ -612,7 +623,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         const u32 curP = cur ? C_POOL1 : C_POOL0, curS = cur ? C_SEG1 : C_SEG0, curL = cur ? C_LIST1 : C_LIST0;
         const u32 oP = cur ? C_POOL0 : C_POOL1, oS = cur ? C_SEG0 : C_SEG1, oL = cur ? C_LIST0 : C_LIST1, oT = cur ? C_LTILES0 : C_LTILES1;
         hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters,
-                           (1u << oP) | (1u << oS) | (0xfu << oL) | (1u << oT));
+                           (1u << oP) | (1u << oS) | (0xfu << oL) | (1u << oT) | (1u << C_CARRY));
         // Switch from key gathers to prefix doubling after text_rounds rounds, or (default policy) as soon as the
         // tied set stops shrinking: a round that keeps > 70 % of the previous round's ties means long repeats,
         // where every further 4-byte round is wasted and doubling (log2 LCP rounds) wins despite the ISA build.
@@ -645,7 +656,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
             }
             // switch to prefix doubling: build the inverse suffix array
             TRY(c->isa.ensure((size_t)(n + 1) * 4));
-            if (g_sync_debug) {
+            if (c->sync_debug) {
                 TRY(c->aux0.ensure(256));
                 HIP_TRY(hipMemsetAsync(c->aux0.p, 0, 256, st));
                 hipLaunchKernelGGL(k_dbg_scan_sa, dim3(4096), dim3(256), 0, st, sa_local, (u32)c->h_counters[C_MS], (u32)n, c->aux0.as<u32>());
@@ -748,6 +759,7 @@ int msufsort_hip_ctx_create(msufsort_hip_ctx** out, int32_t device, int64_t max_
     HIP_TRY(hipSetDevice(device));
     auto* c = new msufsort_hip_ctx();
     c->device = device;
+    if (const char* dbg = getenv("MSUFSORT_HIP_SYNC_DEBUG")) c->sync_debug = atoi(dbg);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return MSUFSORT_HIP_ERR_HIP; }
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);

@@ -61,6 +61,8 @@ enum {
     C_HNZ = 25,                       // number of non-empty 16-bit buckets (alphabet-size estimate)
     C_ABITS = 26,                     // bits per symbol of the dense alphabet code (k_alphabet)
     C_ASIGMA = 27,                    // number of codes (symbols that occur + the reserved zero)
+    C_CARRY = 28,                     // records k_carry_alloc placed in NEXT round's segment array during this round (a repeated
+                                      // sort attempt restarts that array behind them, not at 0)
     C_NCOUNTERS = 32
 };
 

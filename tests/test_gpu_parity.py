@@ -347,3 +347,23 @@ def test_hist16_counter_wrap_paths(M, kind):
         z += 1
     want = np.bincount(keys[: n - z], minlength=65536)
     assert (h.cpu().numpy().astype(np.int64) == want).all()
+
+
+@pytest.mark.parametrize("kind", ["a_runs", "text_copy", "tiled", "dna_tandem"])
+def test_forced_retry_keeps_carried_segments(M, oracle_mod, monkeypatch, kind):
+    """A round whose first sort attempt is thrown away (reservation overflow) must not lose the large all-equal
+    segments that k_carry_alloc / k_carry_copy already moved to next round's segment array: the test hook repeats
+    every round's first attempt, the inputs hold tie groups far above the class-C capacity (18,432)."""
+    r = gen.random_bytes(1 << 18, 3)
+    if kind == "a_runs":
+        t = np.concatenate([np.full(70000, 97, np.uint8), gen.text_bytes(150000, 2), np.full(50000, 97, np.uint8), r[:1000]])
+    elif kind == "text_copy":
+        x = gen.text_bytes(1 << 17, 9); t = np.concatenate([x, x])
+    elif kind == "tiled":
+        t = np.tile(gen.random_bytes(4099, 6), 64)
+    else:
+        t = gen.dna_tandem_bytes(300000, 4)
+    want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+    monkeypatch.setenv("MSUFSORT_HIP_FORCE_RETRY", "1")
+    assert (M.make_suffix_array(t) == want).all()
+    assert (M.make_suffix_array(t, text_rounds=2) == want).all()

@@ -10,4 +10,4 @@ python bench.py --steps 5 --warmup 2 --size 268435456 --no-cpu 2>&1 | grep -v am
 bash tools/gpu_pmc_traffic.sh > $O/pmc_traffic.txt 2>&1; cat $O/pmc_traffic.txt
 timeout 600 python tools/gpu_configs.py text 1073741823 ref > $O/cfg3_cfg4_text.log 2>&1; grep -E "SA:|BWT|LCP|RESULT|reference" $O/cfg3_cfg4_text.log
 timeout 300 python tools/gpu_configs.py dna 1073741823 > $O/dna_1GiB.log 2>&1; grep -E "SA:|RESULT" $O/dna_1GiB.log
-( timeout 100 tools/exp/bin/exp_hist 1073741823 0; timeout 100 tools/exp/bin/exp_hist 1073741823 2; timeout 100 tools/exp/bin/exp_write ) > $O/microbench.txt 2>&1
+( timeout 100 tools/microbench/bin/exp_hist 1073741823 0; timeout 100 tools/microbench/bin/exp_hist 1073741823 2; timeout 100 tools/microbench/bin/exp_write ) > $O/microbench.txt 2>&1
