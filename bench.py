@@ -99,6 +99,7 @@ def main():
     # (every build and every exchange is complete before the closing barrier of the timed region)
     sa_bufs = [d_sa, torch.empty(n + 1, dtype=torch.int32, device=dev)] if world > 1 else [d_sa]
     pending = {"works": [], "buf": None, "last": d_sa, "k": 0}
+    shard_state = mdist.ShardState() if world > 1 else None
 
     def step():
         if world == 1:
@@ -106,7 +107,7 @@ def main():
             return
         out = sa_bufs[pending["k"] & 1]
         pending["k"] += 1
-        works = mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp_full=d_grp, overlap=True)
+        works = mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp_full=d_grp, overlap=True, state=shard_state)
         mdist.wait_all(pending["works"], pending["buf"])        # the previous exchange overlapped with this build
         pending["works"], pending["buf"], pending["last"] = works, out, out
 
@@ -188,6 +189,8 @@ def main():
                         for k, v in kern.items()},
             "phases_ms": {k: round(v[0], 4) for k, v in kern.items()} | {"refine": round(avg("refine_ms"), 4), "device_total": round(avg("total_ms"), 4)},
         }
+        if world > 1 and shard_state.stats:
+            out["doubling"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in shard_state.stats.items()}
         if not args.no_cpu and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.seed)

@@ -34,7 +34,7 @@ typedef enum msufsort_hip_status {
     MSUFSORT_HIP_OK = 0,
     MSUFSORT_HIP_ERR_NO_DEVICE = -1,     /* no gfx950 device visible: the product path has no CPU fallback */
     MSUFSORT_HIP_ERR_BAD_ARG = -2,
-    MSUFSORT_HIP_ERR_TOO_LARGE = -3,     /* n > 2^31 - 2 for the int32 entry points */
+    MSUFSORT_HIP_ERR_TOO_LARGE = -3,     /* n > 2^31 - 2 for the int32 entry points, n > 2^40 - 2 for the int64 ones */
     MSUFSORT_HIP_ERR_HIP = -4,           /* a HIP runtime call failed; see msufsort_hip_last_error */
     MSUFSORT_HIP_ERR_NOMEM = -5,
     MSUFSORT_HIP_ERR_INTERNAL = -6,      /* internal capacity/consistency check tripped */
@@ -46,12 +46,15 @@ typedef struct msufsort_hip_ctx msufsort_hip_ctx;
 /* Tunables; zero-initialise and override what you need. */
 typedef struct msufsort_hip_opts {
     int32_t device;            /* HIP device ordinal (default 0) */
-    int32_t shard;             /* this call builds shard `shard` of `n_shards` (16-bit-key range split); */
-    int32_t n_shards;          /*   0 or 1 = whole array */
+    int32_t shard;             /* msufsort_hip_make_sa_shard*_dev: this call builds shard `shard` of `n_shards` (16-bit-key range
+                                  split).  msufsort_hip_make_sa_i32_dev: shard = -1 builds ALL n_shards logical shards one after
+                                  the other on the context's GPU (bounded workspace; distributed prefix doubling) */
+    int32_t n_shards;          /*   0 or 1 = whole array; msufsort_hip_make_sa_i64_dev: at least this many logical shards */
     int32_t text_rounds;       /* key-gather rounds before switching to prefix doubling; 0 = adaptive (switch when the
                                   tied set stops shrinking past the depth the alphabet needs, at the latest after 24) */
     int32_t verbose;           /* 1: per-round statistics on stderr */
-    int32_t reserved[11];
+    int32_t force_wide;        /* int64 entry points: use the wide (40-bit index) engine also below 2^31 - 1 bytes (parity tests) */
+    int32_t reserved[10];
 } msufsort_hip_opts;
 
 /* Per-phase device time of the last build on this context (hipEvent, milliseconds), plus
@@ -63,13 +66,13 @@ typedef struct msufsort_hip_timings {
     double scatter1_ms;        /* second-byte scatter: reads 8*m, writes 8*m */
     double bucket_sort_ms;     /* round-0 LDS sorts of the 16-bit buckets */
     double refine_ms;          /* all later rounds (key gathers / prefix doubling) */
-    double other_ms;
+    double other_ms;           /* single-process sharded builds: wall time of the distributed doubling phase */
     int64_t n;
     int64_t m;                 /* suffixes sorted by the radix path (n minus trailing 0x00 run) */
     int32_t rounds;            /* rounds after round 0 */
     int32_t doubling_rounds;
     int64_t unresolved_after_round0;
-    int64_t reserved[8];
+    int64_t reserved[8];       /* [0] depth at which a sharded build stopped its key rounds, [1] logical shards of the last build */
 } msufsort_hip_timings;
 
 int msufsort_hip_device_count(void);
@@ -81,6 +84,7 @@ int msufsort_hip_ctx_create(msufsort_hip_ctx** out, int32_t device, int64_t max_
 void msufsort_hip_ctx_destroy(msufsort_hip_ctx* ctx);
 void* msufsort_hip_ctx_stream(msufsort_hip_ctx* ctx);  /* hipStream_t, for hipEvent timing */
 int msufsort_hip_ctx_sync(msufsort_hip_ctx* ctx);
+int msufsort_hip_ctx_trim(msufsort_hip_ctx* ctx);      /* frees the workspace (it is rebuilt on demand) */
 int msufsort_hip_last_timings(msufsort_hip_ctx* ctx, msufsort_hip_timings* out);
 
 /* ---- suffix array: replaces msufsort::make_suffix_array (reference msufsort.cpp:1730-1767,
@@ -110,26 +114,48 @@ int msufsort_hip_make_sa_shard_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64
                                    int64_t* slice_lo, int64_t* slice_hi,
                                    const msufsort_hip_opts* opts);
 /* Same, for inputs whose ties may run deeper than the key-gather rounds allow (long repeats): also fills
- * d_grp_slice_out[row - lo] = first row of the tie group of that row (the row itself when it is final).
- * Returns 0 when the slice is completely sorted, 1 (MSUFSORT_HIP_UNRESOLVED_GROUPS) when groups remain;
- * *depth_out = number of bytes the members of every remaining group share.  After the all-gatherv of the SA
- * and group slices, every rank calls msufsort_hip_finish_sa_dev on the complete arrays if ANY rank returned 1. */
+ * d_grp_slice_out[row - lo] = first row of the tie group of that row, RELATIVE to the slice (the row itself when it is
+ * final).  Returns 0 when the slice is completely sorted, 1 (MSUFSORT_HIP_UNRESOLVED_GROUPS) when groups remain;
+ * *depth_out = number of bytes the members of every remaining group share.  If ANY rank returned 1 the ranks continue
+ * with the distributed prefix doubling below.  The _i64 variant runs the wide engine (40-bit indices, int64 rows):
+ * any n up to 2^40 - 2 (BASELINE config 5: 8 GiB over 8 GPUs). */
 #define MSUFSORT_HIP_UNRESOLVED_GROUPS 1
 int msufsort_hip_make_sa_shard_groups_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
-                                          int32_t* d_slice_out, int32_t* d_grp_slice_out, int64_t slice_capacity,
+                                          int32_t* d_slice_out, uint32_t* d_grp_slice_out, int64_t slice_capacity,
                                           int64_t* slice_lo, int64_t* slice_hi, int64_t* depth_out,
                                           const msufsort_hip_opts* opts);
-/* Finishes a gathered sharded build by prefix doubling (replaces the reference's tandem-repeat path,
- * msufsort.cpp:316-484): d_sa_full / d_grp_full hold all n+1 rows; the result is the final suffix array. */
-int msufsort_hip_finish_sa_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n, int32_t* d_sa_full,
-                               int32_t* d_grp_full, int64_t depth, const msufsort_hip_opts* opts);
+int msufsort_hip_make_sa_shard_groups_i64_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
+                                              int64_t* d_slice_out, uint32_t* d_grp_slice_out, int64_t slice_capacity,
+                                              int64_t* slice_lo, int64_t* slice_hi, int64_t* depth_out,
+                                              const msufsort_hip_opts* opts);
+/* Distributed prefix doubling (replaces the reference's tandem-repeat path, msufsort.cpp:316-484; the shards stay the
+ * independent sort problems of msufsort.cpp:1652-1683).  State per shard: its slice rows + group heads; the rank array
+ * isa[i] = global row of the head of suffix i's group (n + 1 entries of index_bytes = 4 or 8) is replicated and read-only
+ * during a step.  One step at offset h (h starts at *depth_out and doubles):
+ *   every rank:  msufsort_hip_double_sort_dev      sorts its tied groups by isa[i + h]; rewrites slice rows + group heads
+ *                msufsort_hip_emit_updates_dev     rows [r0, r1) of the slice whose group head changed -> updates
+ *                                                  (index_bytes 4: one uint64 = new_row << 32 | suffix; 8: {suffix, new_row})
+ *   exchange:    all-gatherv of the updates (RCCL), then on every rank
+ *                msufsort_hip_apply_updates_dev    isa[suffix] = new_row, for the updates of ALL ranks
+ * until no rank has tied rows left.  msufsort_hip_isa_from_slice_dev initialises a replica from one (gathered) slice. */
+int msufsort_hip_isa_from_slice_dev(msufsort_hip_ctx* ctx, const void* d_sa_slice, const uint32_t* d_grp_slice,
+                                    int64_t lo, int64_t hi, void* d_isa, int32_t index_bytes);
+int msufsort_hip_double_sort_dev(msufsort_hip_ctx* ctx, int64_t n, void* d_sa_slice, uint32_t* d_grp_slice,
+                                 uint32_t* d_grp_prev_slice, int64_t lo, int64_t hi, const void* d_isa, int64_t h,
+                                 int32_t index_bytes, const msufsort_hip_opts* opts, int64_t* tied_before);
+int msufsort_hip_emit_updates_dev(msufsort_hip_ctx* ctx, const void* d_sa_slice, const uint32_t* d_grp_slice,
+                                  const uint32_t* d_grp_prev_slice, int64_t lo, int64_t hi, int64_t r0, int64_t r1,
+                                  void* d_updates, int64_t capacity, int32_t index_bytes, int64_t* count, int64_t* tied_rows);
+int msufsort_hip_apply_updates_dev(msufsort_hip_ctx* ctx, const void* d_updates, int64_t count, void* d_isa,
+                                   int32_t index_bytes);
 /* Slice bounds only (all shards), without sorting: bounds[n_shards + 1], in SA rows. */
 int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
                                   int32_t n_shards, int64_t* bounds);
 
-/* 64-bit output (callers with 64-bit index types).  Same rows as the int32 entry points, widened on
- * the device.  This round builds with 32-bit indices internally: n > 2^31 - 2 returns MSUFSORT_HIP_ERR_TOO_LARGE
- * (BASELINE config 5, 8 GiB over 8 GPUs, needs 33-bit indices and a distributed doubling phase - not built). */
+/* 64-bit output (callers with 64-bit index types; the reference's suffix_index is int32 with two
+ * flag bits, msufsort.h:47,84-93, i.e. n < 2^30).  n <= 2^31 - 2: the int32 rows, widened on the device.  Larger inputs, up to
+ * 2^40 - 2 bytes: the wide engine - 8-byte records (24-bit key, 40-bit index), as many logical shards as the workspace
+ * needs taking turns on the context's GPU, int64 rows written in place, distributed prefix doubling for deep ties. */
 int msufsort_hip_make_sa_i64(const uint8_t* text, int64_t n, int64_t* sa_out /* n+1 */,
                              const msufsort_hip_opts* opts);
 int msufsort_hip_make_sa_i64_ctx(msufsort_hip_ctx* ctx, const uint8_t* text, int64_t n, int64_t* sa_out,
@@ -139,7 +165,7 @@ int msufsort_hip_make_sa_i64_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t
 
 /* Host-only helper used by the two calls above (no device work): balanced key-range cuts from the
  * exclusive prefix bstart[65537] of the 16-bit histogram; cuts/rows have n_shards+1 entries. */
-int msufsort_hip_plan_cuts(const uint32_t* bstart, int64_t n, int64_t z, int32_t n_shards,
+int msufsort_hip_plan_cuts(const uint64_t* bstart, int64_t n, int64_t z, int32_t n_shards,
                            uint32_t* cuts, int64_t* rows);
 
 /* ---- forward BWT: replaces msufsort::forward_burrows_wheeler_transform (cpp:1771-1817) ---- */
@@ -151,6 +177,8 @@ int msufsort_hip_forward_bwt_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t
 /* BWT from an SA that is already in HBM (gather T[SA[r]-1]). */
 int msufsort_hip_bwt_from_sa_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int64_t n,
                                  const int32_t* d_sa, uint8_t* d_bwt_out, int64_t* sentinel_row);
+int msufsort_hip_bwt_from_sa_i64_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int64_t n,
+                                     const int64_t* d_sa, uint8_t* d_bwt_out, int64_t* sentinel_row);
 
 /* ---- inverse BWT: replaces msufsort::reverse_burrows_wheeler_transform (cpp:1821-2096) ---- */
 int msufsort_hip_inverse_bwt(uint8_t* inout, int64_t n, int64_t sentinel_row,
@@ -168,6 +196,8 @@ int msufsort_hip_lcp_i32_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int64
 /* ---- validation on device: checker of reference main.cpp:236-270 (+ permutation check) ---- */
 int msufsort_hip_validate_sa_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int64_t n,
                                  const int32_t* d_sa, int64_t* error_count);
+int msufsort_hip_validate_sa_i64_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int64_t n,
+                                     const int64_t* d_sa, int64_t* error_count);
 
 /* ---- stage probes used by the parity tests (not part of the reference surface) ---- */
 int msufsort_hip_debug_hist16_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,

@@ -18,7 +18,7 @@ TEXT_PAD = 64
 
 class Opts(C.Structure):
     _fields_ = [("device", C.c_int32), ("shard", C.c_int32), ("n_shards", C.c_int32),
-                ("text_rounds", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32 * 11)]
+                ("text_rounds", C.c_int32), ("verbose", C.c_int32), ("force_wide", C.c_int32), ("reserved", C.c_int32 * 10)]
 
 
 class Timings(C.Structure):
@@ -35,7 +35,9 @@ SYMBOLS = [
     "msufsort_hip_ctx_create", "msufsort_hip_ctx_destroy", "msufsort_hip_ctx_stream", "msufsort_hip_ctx_sync",
     "msufsort_hip_last_timings", "msufsort_hip_make_sa_i32", "msufsort_hip_make_sa_i32_dev",
     "msufsort_hip_make_sa_shard_dev", "msufsort_hip_shard_bounds_dev", "msufsort_hip_plan_cuts",
-    "msufsort_hip_make_sa_shard_groups_dev", "msufsort_hip_finish_sa_dev", "msufsort_hip_forward_bwt",
+    "msufsort_hip_make_sa_shard_groups_dev", "msufsort_hip_make_sa_shard_groups_i64_dev", "msufsort_hip_isa_from_slice_dev",
+    "msufsort_hip_double_sort_dev", "msufsort_hip_emit_updates_dev", "msufsort_hip_apply_updates_dev", "msufsort_hip_ctx_trim",
+    "msufsort_hip_validate_sa_i64_dev", "msufsort_hip_bwt_from_sa_i64_dev", "msufsort_hip_forward_bwt",
     "msufsort_hip_forward_bwt_dev", "msufsort_hip_bwt_from_sa_dev", "msufsort_hip_inverse_bwt",
     "msufsort_hip_inverse_bwt_dev", "msufsort_hip_lcp_i32", "msufsort_hip_lcp_i32_dev",
     "msufsort_hip_validate_sa_dev", "msufsort_hip_debug_hist16_dev",
@@ -83,7 +85,14 @@ def lib():
     L.msufsort_hip_make_sa_i32_dev.argtypes = [vp, vp, i64, vp, C.POINTER(Opts)]
     L.msufsort_hip_make_sa_shard_dev.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(Opts)]
     L.msufsort_hip_make_sa_shard_groups_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(Opts)]
-    L.msufsort_hip_finish_sa_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.POINTER(Opts)]
+    L.msufsort_hip_make_sa_shard_groups_i64_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(Opts)]
+    L.msufsort_hip_isa_from_slice_dev.argtypes = [vp, vp, vp, i64, i64, vp, i32]
+    L.msufsort_hip_double_sort_dev.argtypes = [vp, i64, vp, vp, vp, i64, i64, vp, i64, i32, C.POINTER(Opts), C.POINTER(i64)]
+    L.msufsort_hip_emit_updates_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, vp, i64, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.msufsort_hip_apply_updates_dev.argtypes = [vp, vp, i64, vp, i32]
+    L.msufsort_hip_ctx_trim.argtypes = [vp]
+    L.msufsort_hip_validate_sa_i64_dev.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
+    L.msufsort_hip_bwt_from_sa_i64_dev.argtypes = [vp, vp, i64, vp, vp, C.POINTER(i64)]
     L.msufsort_hip_shard_bounds_dev.argtypes = [vp, vp, i64, i32, C.POINTER(i64)]
     L.msufsort_hip_plan_cuts.argtypes = [vp, i64, i64, i32, vp, vp]
     L.msufsort_hip_forward_bwt.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(Opts)]

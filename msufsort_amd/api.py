@@ -35,9 +35,9 @@ def _u8(data) -> np.ndarray:
     return a
 
 
-def _opts(device=0, verbose=0, text_rounds=0, shard=0, n_shards=1) -> Opts:
+def _opts(device=0, verbose=0, text_rounds=0, shard=0, n_shards=1, force_wide=0) -> Opts:
     o = Opts()
-    o.device, o.verbose, o.text_rounds, o.shard, o.n_shards = device, verbose, text_rounds, shard, n_shards
+    o.device, o.verbose, o.text_rounds, o.shard, o.n_shards, o.force_wide = device, verbose, text_rounds, shard, n_shards, int(force_wide)
     return o
 
 
@@ -54,11 +54,13 @@ def make_suffix_array(data, threads: int = 1, *, device: int = 0, verbose: int =
     return sa
 
 
-def make_suffix_array_i64(data, threads: int = 1, *, device: int = 0) -> np.ndarray:
-    """The same rows as int64 (msufsort_hip_make_sa_i64; inputs above 2^31 - 2 bytes are rejected in this round)."""
+def make_suffix_array_i64(data, threads: int = 1, *, device: int = 0, force_wide: bool = False, n_shards: int = 1,
+                          text_rounds: int = 0, verbose: int = 0) -> np.ndarray:
+    """The same rows as int64 (msufsort_hip_make_sa_i64).  Inputs above 2^31 - 2 bytes - and any input with
+    force_wide - run the wide engine (40-bit indices, logical shards, distributed prefix doubling)."""
     t = _u8(data)
     sa = np.empty(t.size + 1, dtype=np.int64)
-    o = _opts(device)
+    o = _opts(device, verbose, text_rounds, 0, n_shards, force_wide)
     _lib.check(_lib.lib().msufsort_hip_make_sa_i64(t.ctypes.data, t.size, sa.ctypes.data, C.byref(o)), "make_suffix_array_i64")
     return sa
 
@@ -152,15 +154,20 @@ class DeviceContext:
             return int(x.data_ptr())
         return int(x)
 
-    def make_sa(self, d_text, n: int, d_sa, *, verbose=0, text_rounds=0):
-        """d_text: >= n+64 bytes in HBM; d_sa: n+1 int32 in HBM."""
-        o = _opts(self.device, verbose, text_rounds)
+    def make_sa(self, d_text, n: int, d_sa, *, verbose=0, text_rounds=0, logical_shards=0):
+        """d_text: >= n+64 bytes in HBM; d_sa: n+1 int32 in HBM.  logical_shards > 1: the shards of a multi-GPU build,
+        one after the other on this GPU (same code path as the distributed build, bounded workspace)."""
+        o = _opts(self.device, verbose, text_rounds, -1 if logical_shards > 1 else 0, max(logical_shards, 1))
         _lib.check(self._L.msufsort_hip_make_sa_i32_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa), C.byref(o)), "make_sa_dev")
 
-    def make_sa_i64(self, d_text, n: int, d_sa64, *, verbose=0, text_rounds=0):
-        """d_text: >= n+64 bytes in HBM; d_sa64: n+1 int64 in HBM (the int32 rows, widened on the device)."""
-        o = _opts(self.device, verbose, text_rounds)
+    def make_sa_i64(self, d_text, n: int, d_sa64, *, verbose=0, text_rounds=0, force_wide=False, n_shards=1):
+        """d_text: >= n+64 bytes in HBM; d_sa64: n+1 int64 in HBM.  n > 2^31 - 2 (or force_wide): the wide engine with at
+        least n_shards logical shards."""
+        o = _opts(self.device, verbose, text_rounds, 0, n_shards, force_wide)
         _lib.check(self._L.msufsort_hip_make_sa_i64_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa64), C.byref(o)), "make_sa_i64_dev")
+
+    def trim(self):
+        _lib.check(self._L.msufsort_hip_ctx_trim(self._h), "ctx_trim")
 
     def shard_bounds(self, d_text, n: int, n_shards: int):
         b = (C.c_int64 * (n_shards + 1))()
@@ -174,23 +181,44 @@ class DeviceContext:
                                                           C.byref(lo), C.byref(hi), C.byref(o)), "make_sa_shard")
         return int(lo.value), int(hi.value)
 
-    def make_sa_shard_groups(self, d_text, n: int, d_slice, d_grp_slice, capacity: int, shard: int, n_shards: int, *, verbose=0, text_rounds=0):
-        """Like make_sa_shard, plus the tie-group heads of the slice rows.  Returns (lo, hi, unresolved, depth)."""
+    def make_sa_shard_groups(self, d_text, n: int, d_slice, d_grp_slice, capacity: int, shard: int, n_shards: int, *, verbose=0, text_rounds=0,
+                             index_bytes=4):
+        """Like make_sa_shard, plus the tie-group heads of the slice rows (uint32, relative to the slice).  index_bytes = 8:
+        the wide engine (int64 rows).  Returns (lo, hi, unresolved, depth)."""
         o = _opts(self.device, verbose, text_rounds, shard, n_shards)
         lo, hi, depth = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        r = self._L.msufsort_hip_make_sa_shard_groups_dev(self._h, self._ptr(d_text), n, self._ptr(d_slice), self._ptr(d_grp_slice), capacity,
-                                                          C.byref(lo), C.byref(hi), C.byref(depth), C.byref(o))
+        f = self._L.msufsort_hip_make_sa_shard_groups_i64_dev if index_bytes == 8 else self._L.msufsort_hip_make_sa_shard_groups_dev
+        r = f(self._h, self._ptr(d_text), n, self._ptr(d_slice), self._ptr(d_grp_slice), capacity, C.byref(lo), C.byref(hi), C.byref(depth), C.byref(o))
         if r not in (0, 1):
             _lib.check(r, "make_sa_shard_groups")
         return int(lo.value), int(hi.value), r == 1, int(depth.value)
 
-    def finish_sa(self, d_text, n: int, d_sa_full, d_grp_full, depth: int, *, verbose=0):
-        o = _opts(self.device, verbose)
-        _lib.check(self._L.msufsort_hip_finish_sa_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa_full), self._ptr(d_grp_full), depth, C.byref(o)), "finish_sa")
+    # ---- distributed prefix doubling (include/msufsort_hip.h) ----
+    def isa_from_slice(self, d_sa_slice, d_grp_slice, lo: int, hi: int, d_isa, index_bytes=4):
+        _lib.check(self._L.msufsort_hip_isa_from_slice_dev(self._h, self._ptr(d_sa_slice), self._ptr(d_grp_slice), lo, hi, self._ptr(d_isa), index_bytes), "isa_from_slice")
 
-    def bwt_from_sa(self, d_text, n: int, d_sa, d_bwt) -> int:
+    def double_sort(self, n: int, d_sa_slice, d_grp_slice, d_grp_prev_slice, lo: int, hi: int, d_isa, h: int, index_bytes=4, verbose=0) -> int:
+        """One doubling step's sort work for this slice; returns how many groups were tied when it began (0: slice final)."""
+        o = _opts(self.device, verbose)
+        t = C.c_int64(0)
+        _lib.check(self._L.msufsort_hip_double_sort_dev(self._h, n, self._ptr(d_sa_slice), self._ptr(d_grp_slice), self._ptr(d_grp_prev_slice), lo, hi,
+                                                        self._ptr(d_isa), h, index_bytes, C.byref(o), C.byref(t)), "double_sort")
+        return int(t.value)
+
+    def emit_updates(self, d_sa_slice, d_grp_slice, d_grp_prev_slice, lo: int, hi: int, r0: int, r1: int, d_updates, capacity: int, index_bytes=4):
+        """Rank updates of slice rows [r0, r1) -> d_updates; returns (count, tied_rows)."""
+        cnt, tied = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._L.msufsort_hip_emit_updates_dev(self._h, self._ptr(d_sa_slice), self._ptr(d_grp_slice), self._ptr(d_grp_prev_slice), lo, hi, r0, r1,
+                                                         self._ptr(d_updates), capacity, index_bytes, C.byref(cnt), C.byref(tied)), "emit_updates")
+        return int(cnt.value), int(tied.value)
+
+    def apply_updates(self, d_updates, count: int, d_isa, index_bytes=4):
+        _lib.check(self._L.msufsort_hip_apply_updates_dev(self._h, self._ptr(d_updates), count, self._ptr(d_isa), index_bytes), "apply_updates")
+
+    def bwt_from_sa(self, d_text, n: int, d_sa, d_bwt, index_bytes=4) -> int:
         s = C.c_int64(0)
-        _lib.check(self._L.msufsort_hip_bwt_from_sa_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa), self._ptr(d_bwt), C.byref(s)), "bwt_from_sa")
+        f = self._L.msufsort_hip_bwt_from_sa_i64_dev if index_bytes == 8 else self._L.msufsort_hip_bwt_from_sa_dev
+        _lib.check(f(self._h, self._ptr(d_text), n, self._ptr(d_sa), self._ptr(d_bwt), C.byref(s)), "bwt_from_sa")
         return int(s.value)
 
     def forward_bwt(self, d_text, n: int, d_bwt) -> int:
@@ -206,9 +234,10 @@ class DeviceContext:
     def lcp(self, d_text, n: int, d_sa, d_lcp):
         _lib.check(self._L.msufsort_hip_lcp_i32_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa), self._ptr(d_lcp)), "lcp_dev")
 
-    def validate_sa(self, d_text, n: int, d_sa) -> int:
+    def validate_sa(self, d_text, n: int, d_sa, index_bytes=4) -> int:
         e = C.c_int64(0)
-        _lib.check(self._L.msufsort_hip_validate_sa_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa), C.byref(e)), "validate")
+        f = self._L.msufsort_hip_validate_sa_i64_dev if index_bytes == 8 else self._L.msufsort_hip_validate_sa_dev
+        _lib.check(f(self._h, self._ptr(d_text), n, self._ptr(d_sa), C.byref(e)), "validate")
         return int(e.value)
 
     def debug_hist16(self, d_text, n: int, d_hist):

@@ -4,19 +4,21 @@
 #include "sa_kernels.hip.h"
 
 // row r with SA[r] == 0 (the sentinel row, cpp:1283-1286)
-__global__ __launch_bounds__(256) void k_find_sentinel(const u32* __restrict__ sa, u64 rows, u32* __restrict__ counters)
+template <bool W>
+__global__ __launch_bounds__(256) void k_find_sentinel(const typename Wd<W>::sa_t* __restrict__ sa, u64 rows, unsigned long long* __restrict__ sent)
 {
     for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r < rows; r += (u64)gridDim.x * 256u)
-        if (sa[r] == 0) counters[C_SENT] = (u32)r;
+        if (sa[r] == 0) *sent = r;
 }
 
 // BWT bytes with the sentinel row removed (cpp:1811-1815)
-__global__ __launch_bounds__(256) void k_bwt_gather(const u8* __restrict__ text, const u32* __restrict__ sa, u64 rows,
-                                                    const u32* __restrict__ counters, u8* __restrict__ out)
+template <bool W>
+__global__ __launch_bounds__(256) void k_bwt_gather(const u8* __restrict__ text, const typename Wd<W>::sa_t* __restrict__ sa, u64 rows,
+                                                    const unsigned long long* __restrict__ sentp, u8* __restrict__ out)
 {
-    const u32 sent = counters[C_SENT];
+    const u64 sent = *sentp;
     for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r < rows; r += (u64)gridDim.x * 256u) {
-        const u32 v = sa[r];
+        const u64 v = sa[r];
         if (v != 0) out[r - (r > sent)] = text[v - 1];
     }
 }
@@ -112,26 +114,30 @@ __global__ __launch_bounds__(256) void k_lcp_from_plcp(const u32* __restrict__ s
 // byte, which is O(n * LCP) and takes minutes on periodic inputs; the order test used here is the exact linear one:
 // with rank = inverse permutation (rank of the empty suffix = 0),
 //     suffix a < suffix b  <=>  T[a] < T[b]  or  (T[a] == T[b] and rank[a+1] < rank[b+1]).
-__global__ __launch_bounds__(256) void k_validate_perm(u64 n, const u32* __restrict__ sa, u32* __restrict__ rank /* n+1 */,
+template <bool W>
+__global__ __launch_bounds__(256) void k_validate_perm(u64 n, const typename Wd<W>::sa_t* __restrict__ sa, typename Wd<W>::sa_t* __restrict__ rank /* n+1 */,
                                                        unsigned long long* __restrict__ errors)
 {
+    typedef typename Wd<W>::sa_t sa_t;
     for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r <= n; r += (u64)gridDim.x * 256u) {
-        const u32 v = sa[r];
-        if (r == 0) { if (v != (u32)n) atomicAdd(errors, 1ull); rank[n] = 0; continue; }
+        const sa_t v = sa[r];
+        if (r == 0) { if (v != (sa_t)n) atomicAdd(errors, 1ull); rank[n] = 0; continue; }
         if (v >= n) { atomicAdd(errors, 1ull); continue; }
-        rank[v] = (u32)r;                       // duplicates: one row wins, k_validate_order sees the others
+        rank[v] = (sa_t)r;                      // duplicates: one row wins, k_validate_order sees the others
     }
 }
 
-__global__ __launch_bounds__(256) void k_validate_order(const u8* __restrict__ text, u64 n, const u32* __restrict__ sa,
-                                                        const u32* __restrict__ rank, unsigned long long* __restrict__ errors)
+template <bool W>
+__global__ __launch_bounds__(256) void k_validate_order(const u8* __restrict__ text, u64 n, const typename Wd<W>::sa_t* __restrict__ sa,
+                                                        const typename Wd<W>::sa_t* __restrict__ rank, unsigned long long* __restrict__ errors)
 {
+    typedef typename Wd<W>::sa_t sa_t;
     for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x + 1; r <= n; r += (u64)gridDim.x * 256u) {
-        const u32 b = sa[r];
+        const sa_t b = sa[r];
         if (b >= n) continue;                               // already counted by k_validate_perm
-        if (rank[b] != (u32)r) { atomicAdd(errors, 1ull); continue; }      // permutation: every value names its own row
+        if (rank[b] != (sa_t)r) { atomicAdd(errors, 1ull); continue; }      // permutation: every value names its own row
         if (r < 2) continue;
-        const u32 a = sa[r - 1];
+        const sa_t a = sa[r - 1];
         if (a >= n) continue;
         const u32 ca = text[a], cb = text[b];
         const bool ok = ca < cb || (ca == cb && rank[a + 1] < rank[b + 1]);

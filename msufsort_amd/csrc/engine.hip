@@ -17,8 +17,6 @@
 #include <string>
 #include <vector>
 
-extern "C" int msufsort_hip_plan_cuts(const uint32_t* bstart, int64_t n, int64_t z, int32_t n_shards, uint32_t* cuts, int64_t* rows);
-
 namespace {
 
 thread_local std::string g_last_error;
@@ -74,10 +72,13 @@ struct msufsort_hip_ctx {
     // workspace
     DevBuf rec[3], pool_rec[2], pool_hdr[2];
     DevBuf lists[2][3], large_round[2], lvl[2], seg0;
-    DevBuf alpha, seg0_base, stripe_sums, hist_partial, hist, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
+    DevBuf alpha, seg0_base, stripe_sums, hist_partial, hist, hist_clip, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
     DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, aux3, doneB, doneC;
+    DevBuf grp_full, grp_prev, upd, upd_cnt;      // single-process sharded builds: tie-group heads (all rows), their copy at the
+                                                  // start of a doubling step, rank updates of one row window
     u32* h_counters = nullptr;   // pinned
-    u32* h_bstart = nullptr;     // pinned, 65537
+    u64* h_hist = nullptr;       // pinned, 65536 (the 16-bit histogram on the host: shard planning)
+    unsigned long long* h_upd = nullptr;   // pinned, 2
     u32 nchunks = 1, chunk_len = 32768;      // text striping of the last k_hist16 (scatter stripes)
     u32 hist_per = 1;                        // histogram chunks per stripe
     u32 list_cap[3] = {0, 0, 0};
@@ -88,17 +89,24 @@ struct msufsort_hip_ctx {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int sync_debug = 0;          // MSUFSORT_HIP_SYNC_DEBUG, read once when the context is created
 
+    template <bool W> int set_mid_attrs()
+    {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>()));
+        return MSUFSORT_HIP_OK;
+    }
+
     int set_attrs()
     {
         if (attrs_set) return MSUFSORT_HIP_OK;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan16), hipFuncAttributeMaxDynamicSharedMemorySize, SCAN16_LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>()));
+        TRY(set_mid_attrs<false>());
+        TRY(set_mid_attrs<true>());
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_fast2_lds_bytes<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast2<CLS_B_THREADS, CLS_B_ITEMS, FAST_BITS_B, FAST2_TL_B>),
@@ -107,10 +115,33 @@ struct msufsort_hip_ctx {
         return MSUFSORT_HIP_OK;
     }
 
+    // buffers whose size does not depend on the number of suffixes (histogram, offsets, level-0 set-up)
+    int ensure_fixed(u32 hist_chunks)
+    {
+        TRY(seg0.ensure(256 * sizeof(Desc)));
+        TRY(child_cnt.ensure(65536 * 4));
+        TRY(cursor0.ensure(128 * 256 * 4));
+        TRY(seg0_base.ensure(256 * 4));
+        TRY(stripe_sums.ensure(128 * 256 * 4));
+        TRY(alpha.ensure(256));
+        TRY(hist_partial.ensure((size_t)std::max<u32>(hist_chunks, 256u) * 65536 * 4));
+        TRY(hist.ensure(65536 * 8));
+        TRY(hist_clip.ensure(65536 * 4));
+        TRY(bstart.ensure(65537 * 4));
+        TRY(counters.ensure(C_NCOUNTERS * 4));
+        TRY(child_start.ensure(65536 * 4));
+        TRY(cursor.ensure(65536 * 4));
+        TRY(tile_start.ensure(257 * 4));
+        return MSUFSORT_HIP_OK;
+    }
+
+    // buffers that scale with the number of suffixes ONE build sorts (a shard's m, not the input's)
     int ensure_workspace(u64 m)
     {
+        TRY(ensure_fixed(256));
         if (cap_for_m >= m) return MSUFSORT_HIP_OK;
         u64 cap = m + m / 4 + (2u << 20);        // + room for the neutral tails of chunked output reservations
+        if (cap > 0xfffffff0ull) { set_error("a build of %llu suffixes exceeds the 32-bit record offsets of one shard; use more shards", (unsigned long long)m); return MSUFSORT_HIP_ERR_TOO_LARGE; }
         for (auto& b : rec) TRY(b.ensure(cap * 8));
         for (auto& b : pool_rec) TRY(b.ensure(cap * 8));
         for (auto& b : pool_hdr) TRY(b.ensure(cap * 8));
@@ -123,22 +154,12 @@ struct msufsort_hip_ctx {
             TRY(large_round[s].ensure((size_t)large_cap * sizeof(Desc)));
             TRY(lvl[s].ensure((size_t)large_cap * sizeof(Desc)));
         }
-        TRY(seg0.ensure(256 * sizeof(Desc)));
         size_t nchild = std::max<size_t>(65536, (size_t)large_cap * 256);
         TRY(child_start.ensure(nchild * 4));
-        TRY(child_cnt.ensure(65536 * 4));
         TRY(cursor.ensure(nchild * 4));
         TRY(seg_hist.ensure(nchild * 4));
-        TRY(cursor0.ensure(128 * 256 * 4));
-        TRY(seg0_base.ensure(256 * 4));
-        TRY(stripe_sums.ensure(128 * 256 * 4));
-        TRY(alpha.ensure(256));
         TRY(tile_start.ensure(((size_t)std::max<u32>(large_cap, 256) + 1) * 4));
         TRY(trivial.ensure((size_t)std::max<u32>(large_cap, 256) * 4));
-        TRY(hist_partial.ensure((size_t)256 * 65536 * 4));
-        TRY(hist.ensure(65536 * 4));
-        TRY(bstart.ensure(65537 * 4));
-        TRY(counters.ensure(C_NCOUNTERS * 4));
         TRY(doneB.ensure((size_t)list_cap[1] * 4));
         TRY(doneC.ensure((size_t)list_cap[2] * 4));
         cap_m = cap;
@@ -152,9 +173,22 @@ struct msufsort_hip_ctx {
         for (auto& b : pool_rec) b.release();
         for (auto& b : pool_hdr) b.release();
         for (int s = 0; s < 2; ++s) { for (int c = 0; c < 3; ++c) lists[s][c].release(); large_round[s].release(); lvl[s].release(); }
-        alpha.release(); seg0.release(); seg0_base.release(); stripe_sums.release(); hist_partial.release(); hist.release(); bstart.release(); child_start.release(); child_cnt.release();
+        alpha.release(); seg0.release(); seg0_base.release(); stripe_sums.release(); hist_partial.release(); hist.release(); hist_clip.release(); bstart.release(); child_start.release(); child_cnt.release();
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
+        grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release();
+        cap_m = 0; cap_for_m = 0;
+    }
+
+    // frees the sort workspace (records, pools, lists) but keeps the small fixed buffers: single-process builds of very
+    // large inputs need the memory for the rank array
+    void release_sort_workspace()
+    {
+        for (auto& b : rec) b.release();
+        for (auto& b : pool_rec) b.release();
+        for (auto& b : pool_hdr) b.release();
+        for (int s = 0; s < 2; ++s) { for (int c = 0; c < 3; ++c) lists[s][c].release(); large_round[s].release(); lvl[s].release(); }
+        seg_hist.release(); trivial.release(); doneB.release(); doneC.release();
         cap_m = 0; cap_for_m = 0;
     }
 
@@ -196,13 +230,8 @@ __global__ void k_last_nonzero(const u8* __restrict__ text, u64 n, unsigned long
     if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
 }
 
-__global__ void k_dbg_scan_sa(const u32* sa_local, u32 ms, u32 n, u32* out)
-{
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < ms; i += (u64)gridDim.x * blockDim.x)
-        if (sa_local[i] >= n) { u32 k = atomicAdd(&out[0], 1u); if (k < 8) { out[1 + 2 * k] = (u32)i; out[2 + 2 * k] = sa_local[i]; } }
-}
-
 inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+inline u32 grid_for(u64 items, u32 per_block = 256, u32 cap = 65536u) { return (u32)std::min<u64>(std::max<u64>((items + per_block - 1) / per_block, 1), cap); }
 
 // number of trailing 0x00 bytes of the device text
 int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out)
@@ -236,184 +265,149 @@ int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out)
         }                                                                                            \
     } while (0)
 
-struct ShardPlan {
-    u32 klo = 0, khi = 65536;
-    u64 row_lo = 0, row_hi = 0;     // rows of the full SA (n+1 rows) owned by this shard
-};
-
-// hist16 + reduce (+ scan for the given key range).  Leaves hist/bstart and the level-0/1 set-up on the device.
+// hist16 + reduce.  Leaves the global 16-bit histogram (u32 narrow / u64 wide) in c->hist.
+template <bool W>
 int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
 {
-    // scatter stripes: at most 128, each a multiple of 32 KiB; histogram chunks: 1 or 2 per stripe, so that
-    // large inputs give every CU a workgroup (one workgroup per chunk, 136 KiB of LDS each)
+    // scatter stripes: at most 128, each a multiple of 32 KiB; histogram chunks: a power of two per stripe, so that
+    // large inputs give every CU a workgroup (one workgroup per chunk, 136 KiB of LDS each) and no chunk exceeds 16 MiB
+    // (capacity of k_hist16's overflow list)
     u32 nchunks = (u32)std::min<u64>(128, std::max<u64>(1, (m + 65535) / 65536));
     u64 chunk_len = (m + nchunks - 1) / nchunks;
     chunk_len = (chunk_len + 32767) / 32768 * 32768;
-    const u32 per = chunk_len >= 131072 ? 2 : 1;
+    u32 per = chunk_len >= 131072 ? 2 : 1;
+    while (chunk_len / per > (16u << 20)) per *= 2;
+    if (chunk_len > 0xffff8000ull) { set_error("input too large for 128 scatter stripes"); return MSUFSORT_HIP_ERR_TOO_LARGE; }
     const u32 hchunks = nchunks * per;
     TRY(c->set_attrs());          // (k_hist16 takes 136 KiB of dynamic LDS; shard planning reaches this before any build)
+    TRY(c->ensure_fixed(hchunks));
     c->nchunks = nchunks; c->chunk_len = (u32)chunk_len; c->hist_per = per;
-    hipLaunchKernelGGL(k_hist16, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, (u32)m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>());
-    hipLaunchKernelGGL(k_reduce16, dim3(256), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), hchunks, c->hist.as<u32>());
+    hipLaunchKernelGGL(k_hist16, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>());
+    hipLaunchKernelGGL(k_reduce16<W>, dim3(256), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), hchunks, c->hist.as<typename Wd<W>::hist_t>());
     HIP_TRY(hipGetLastError());
     return MSUFSORT_HIP_OK;
 }
 
+template <bool W>
 void run_scan(msufsort_hip_ctx* c, u32 klo, u32 khi, u64 z)
 {
-    hipLaunchKernelGGL(k_scan16, dim3(1), dim3(1024), SCAN16_LDS_BYTES, c->stream, c->hist.as<u32>(), c->bstart.as<u32>(), klo, khi,
+    const u32* h32 = c->hist.as<u32>();
+    if (W) {   // 64-bit global counts -> the shard's own 32-bit counts (everything outside [klo, khi) reads as 0)
+        hipLaunchKernelGGL(k_hist_clip, dim3(256), dim3(256), 0, c->stream, c->hist.as<u64>(), klo, khi, c->hist_clip.as<u32>(), c->counters.as<u32>());
+        h32 = c->hist_clip.as<u32>();
+    }
+    hipLaunchKernelGGL(k_scan16, dim3(1), dim3(1024), SCAN16_LDS_BYTES, c->stream, h32, c->bstart.as<u32>(), klo, khi,
                        c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->seg0_base.as<u32>(),
                        c->seg0.as<Desc>(), c->tile_start.as<u32>(), c->counters.as<u32>(), (u32)z);
-    hipLaunchKernelGGL(k_scan16_post, dim3(64), dim3(1024), 0, c->stream, c->hist.as<u32>(), c->bstart.as<u32>(), klo, khi,
+    hipLaunchKernelGGL(k_scan16_post, dim3(64), dim3(1024), 0, c->stream, h32, c->bstart.as<u32>(), klo, khi,
                        c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->counters.as<u32>());
-    hipLaunchKernelGGL(k_alphabet, dim3(1), dim3(256), 0, c->stream, c->hist.as<u32>(), c->alpha.as<u8>(), c->counters.as<u32>());
+    hipLaunchKernelGGL(k_alphabet<W>, dim3(1), dim3(256), 0, c->stream, c->hist.as<typename Wd<W>::hist_t>(), c->alpha.as<u8>(), c->counters.as<u32>());
     (void)hipMemsetAsync(c->stripe_sums.p, 0, (size_t)c->nchunks * 256 * 4, c->stream);
     hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks * 4), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), c->hist_per, klo, khi, c->stripe_sums.as<u32>());
     hipLaunchKernelGGL(k_stripes, dim3(256), dim3(128), 0, c->stream, c->stripe_sums.as<u32>(), c->nchunks,
                        c->seg0_base.as<u32>(), c->cursor0.as<u32>());
 }
 
-int plan_shards(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64 z, u64 m, int n_shards, std::vector<u32>& cuts, std::vector<u64>& rows)
+// Host-only: split the 16-bit key space into n_shards count-balanced contiguous ranges (SURVEY 8(e)).
+// bstart[65537] = exclusive prefix of the 16-bit histogram over the m = n - z radix-sorted suffixes.
+void plan_cuts64(const u64* bstart, u64 n, u64 z, int n_shards, u32* cuts, u64* rows)
 {
-    cuts.assign(n_shards + 1, 0);
-    rows.assign(n_shards + 1, 0);
-    cuts[n_shards] = 65536;
-    rows[n_shards] = n + 1;
-    if (m == 0 || n_shards == 1) { if (n_shards > 1) for (int g = 1; g < n_shards; ++g) { cuts[g] = 65536; rows[g] = n + 1; } return MSUFSORT_HIP_OK; }
-    TRY(run_hist(c, d_text, m));
-    run_scan(c, 0, 65536, z);
-    HIP_TRY(hipMemcpyAsync(c->h_bstart, c->bstart.p, 65537 * 4, hipMemcpyDeviceToHost, c->stream));
+    const u64 m = n - z;
+    cuts[0] = 0; rows[0] = 0;
+    cuts[n_shards] = 65536; rows[n_shards] = n + 1;
+    for (int g = 1; g < n_shards; ++g) {
+        const u64 target = (u64)((unsigned __int128)m * (u64)g / (u64)n_shards);
+        u32 k = (u32)(std::lower_bound(bstart, bstart + 65536, target) - bstart);
+        if (k < cuts[g - 1]) k = cuts[g - 1];
+        cuts[g] = k;
+        rows[g] = 1 + z + bstart[k];
+    }
+}
+
+struct ShardCuts {
+    std::vector<u32> cuts;       // first 16-bit key of every shard (n_shards + 1)
+    std::vector<u64> rows;       // first suffix-array row of every shard
+    std::vector<u64> rank0;      // global rank (row - 1) of every shard's first radix-sorted suffix
+};
+
+// Runs the histogram, brings it to the host and plans the shards.  Leaves the histogram on the device (hist_done).
+template <bool W>
+int plan_shards(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64 z, int n_shards, ShardCuts& sc)
+{
+    const u64 m = n - z;
+    sc.cuts.assign(n_shards + 1, 0); sc.rows.assign(n_shards + 1, 0); sc.rank0.assign(n_shards + 1, z);
+    sc.cuts[n_shards] = 65536; sc.rows[n_shards] = n + 1;
+    if (m == 0) { for (int g = 1; g < n_shards; ++g) { sc.cuts[g] = 65536; sc.rows[g] = n + 1; } return MSUFSORT_HIP_OK; }
+    TRY(run_hist<W>(c, d_text, m));
+    HIP_TRY(hipMemcpyAsync(c->h_hist, c->hist.p, 65536 * sizeof(typename Wd<W>::hist_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<int64_t> r64(n_shards + 1);
-    msufsort_hip_plan_cuts(c->h_bstart, (int64_t)n, (int64_t)z, n_shards, cuts.data(), r64.data());
-    for (int g = 0; g <= n_shards; ++g) rows[g] = (u64)r64[g];
+    std::vector<u64> bs(65537);
+    bs[0] = 0;
+    for (u32 k = 0; k < 65536; ++k) bs[k + 1] = bs[k] + (W ? c->h_hist[k] : (u64)reinterpret_cast<const u32*>(c->h_hist)[k]);
+    plan_cuts64(bs.data(), n, z, n_shards, sc.cuts.data(), sc.rows.data());
+    for (int g = 0; g <= n_shards; ++g) sc.rank0[g] = z + bs[sc.cuts[g]];
     return MSUFSORT_HIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// The suffix-array build for one shard.  d_sa_local points at the row of the shard's first radix-sorted
-// suffix (global row 1 + z + bstart[klo]); `with_head` also writes SA[0] and the trailing-zero rows.
+// One round of the engine below the two-byte buckets: partition levels for the large segments, LDS sorts for the
+// rest (with the repeat-with-exact-reservations fallback).  Shared by the suffix-array build (text rounds and, for
+// narrow single-GPU builds, in-place prefix doubling) and by the stateless doubling step of sharded / wide builds.
 // ------------------------------------------------------------------------------------------------
-// d_grp_rows (optional, same indexing as d_sa_rows): receives the tie-group head row of every slice row when a
-// sharded build stops with unresolved groups (return value MSUFSORT_HIP_UNRESOLVED).
-// resume_depth > 0: d_sa_rows / d_grp_rows hold the COMPLETE arrays of such builds; rebuild the state from them
-// and finish with prefix doubling from that depth.
-#define MSUFSORT_HIP_UNRESOLVED 1
-int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of this shard's slice */, u64 slice_row_lo,
-             u64 z, u32 klo, u32 khi, bool with_head, const msufsort_hip_opts* opts, bool hist_done,
-             u32* d_grp_rows = nullptr, u64 resume_depth = 0, u64 slice_rows = 0)
-{
-    const int verbose = opts ? opts->verbose : 0;
-    const bool sharded = opts && opts->n_shards > 1;
-    const bool auto_switch = !(opts && opts->text_rounds > 0) && !getenv("MSUFSORT_HIP_TEXT_ROUNDS");
-    int text_rounds = (opts && opts->text_rounds > 0) ? opts->text_rounds : 24;
-    u64 prev_active = 0;
-    bool exact_sticky = false;
-    bool fast_gave_up = false;       // k_sort_fast2 was tried on packed keys in a later round and mostly refused
-    const bool force_retry = getenv("MSUFSORT_HIP_FORCE_RETRY") != nullptr;   // test hook: every round's first sort attempt is
-                                                                             // thrown away and repeated with exact reservations
-    if (const char* e = getenv("MSUFSORT_HIP_TEXT_ROUNDS")) text_rounds = std::max(1, atoi(e));
-    const u64 m = n - z;
-    hipStream_t st = c->stream;
-    auto& tm = c->tm;
-    memset(&tm, 0, sizeof tm);
-    tm.n = (int64_t)n; tm.m = (int64_t)m;
-    TRY(c->set_attrs());
-    HIP_TRY(hipEventRecord(c->ev[0], st));
-    if (with_head) hipLaunchKernelGGL(k_sa_head, dim3(cdiv(std::max<u64>(z, 1), 256)), dim3(256), 0, st, d_sa_rows, (u32)n, (u32)z);
-    if (m == 0) {
-        if (d_grp_rows && resume_depth == 0 && slice_rows) hipLaunchKernelGGL(k_grp_iota, dim3(cdiv(slice_rows, 256)), dim3(256), 0, st, d_grp_rows, slice_rows, (u32)slice_row_lo);
-        HIP_TRY(hipEventRecord(c->ev[5], st)); HIP_TRY(hipStreamSynchronize(st)); return MSUFSORT_HIP_OK;
-    }
-    TRY(c->ensure_workspace(m));
-    u32* counters = c->counters.as<u32>();
-    HIP_TRY(hipMemsetAsync(counters, 0, C_NCOUNTERS * 4, st));
-    RecBufs bufs{{c->rec[0].as<u64>(), c->rec[1].as<u64>(), c->rec[2].as<u64>()}};
-
-    const bool resume = resume_depth > 0;
-    u64 rank0 = z;
-    u32* sa_local = d_sa_rows + (1 + z - slice_row_lo);
-    if (!resume) {
-        // ---- round 0: 16-bit histogram, offsets, two 8-bit scatter levels ----
-        if (!hist_done) TRY(run_hist(c, d_text, m));
-        HIP_TRY(hipEventRecord(c->ev[1], st));
-        run_scan(c, klo, khi, z);
-        // rows of this shard's radix-sorted suffixes start at global row 1 + z + bstart[klo]
-        if (klo == 0) rank0 = z;
-        else { HIP_TRY(hipMemcpyAsync(c->h_bstart, c->bstart.p, 65537 * 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); rank0 = z + c->h_bstart[klo]; }
-        sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
-        hipLaunchKernelGGL(k_scatter0, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, (u32)m, klo, khi, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0], c->alpha.as<u8>(), counters, getenv("MSUFSORT_HIP_NO_PACK") ? 0u : 1u);
-        HIP_TRY(hipEventRecord(c->ev[2], st));
-        DBG("k_scatter0");
-        hipLaunchKernelGGL(k_partition, dim3(cdiv(cdiv(m, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
-                           c->tile_start.as<u32>(), 24u, c->cursor.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u);
-        HIP_TRY(hipEventRecord(c->ev[3], st));
-        DBG("k_partition L1");
-
-    }
-    int cur = 0;                 // slot of the current round's lists / pool
-    u32 sb = 1, nb = 2;          // record buffer holding the current segments / receiving next round's
+template <bool W>
+struct Rounds {
+    typedef typename Wd<W>::sa_t sa_t;
+    static constexpr u32 KL = klow<W>();
+    msufsort_hip_ctx* c = nullptr;
+    hipStream_t st = nullptr;
+    u32* counters = nullptr;
+    RecBufs bufs{};
+    sa_t* sa_local = nullptr;        // row of the shard's first radix-sorted suffix
+    u32* isa32 = nullptr;            // MODE_ISA (narrow, in place)
+    u32* grp_out = nullptr;          // MODE_DEFER
+    int cur = 0;                     // slot of the current round's lists / pool
+    u32 sb = 1, nb = 2;              // record buffer holding the current segments / receiving next round's
     u32 mode = MODE_TEXT;
-    u64 depth = 5;               // text bytes consumed after round 0: bucket bytes 0,1 + key bytes 2,3,4
-    u32 asigma = 256, cpk = 4, zlow = 0;   // dense alphabet code of the gather rounds (k_alphabet; known after round 0):
-                                            // number of codes, symbols per key, left shift; cpk == 4: plain 4-byte windows
-    auto make_lists = [&](int slot) {
+    int round = 0;
+    u32 discard = 0;
+    u32 klo = 0, khi = 65536;
+    u32 cpk = W ? 3u : 4u;
+    int verbose = 0;
+    bool exact_sticky = false, fast_gave_up = false, force_retry = false, no_pack = false;
+    u32 nA = 0, nB = 0, nC = 0, nP = 0;
+
+    Lists make_lists(int slot) const
+    {
         Lists L;
-        for (int k = 0; k < 3; ++k) { L.cls[k] = c->lists[slot][k].as<Desc>(); L.cap[k] = c->list_cap[k]; }
+        for (int k = 0; k < 3; ++k) { L.cls[k] = c->lists[slot][k].template as<Desc>(); L.cap[k] = c->list_cap[k]; }
         L.cnt_idx = slot ? C_LIST1 : C_LIST0;
         return L;
-    };
-    auto alts = [&](u32 s, u32 nx, u32 a[3]) { u32 third = 3 - s - nx; a[s] = third; a[third] = s; a[nx] = nx; };
-
-    int round = 0;
-    if (!resume) {
-        // children of the 65,536 two-byte buckets
-        {
-            u32 a[3]; a[0] = 1; a[1] = 0; a[2] = 2;
-            hipLaunchKernelGGL(k_children, dim3(256), dim3(256), 0, st, bufs, c->seg0.as<Desc>(), 256u, c->child_start.as<u32>(), c->child_cnt.as<u32>(),
-                               (const u32*)nullptr, a[0], a[1], a[2], 24u, sa_local, (u32*)nullptr, (u32)MODE_TEXT,
-                               c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), (u32)std::min<u64>(c->cap_m, 0xffffffffu),
-                               make_lists(cur), c->lvl[0].as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters);
-        }
-        DBG("k_children L1");
-        TRY(c->read_counters());
-
-    } else {
-        // ---- resume: complete (SA, grp) arrays of a sharded build -> state of a round that is about to start ----
-        u32* grp_local = d_grp_rows + (1 + z);
-        const u32 hv[2] = {(u32)m, (u32)z};
-        HIP_TRY(hipMemcpyAsync(counters + C_MS, hv, 8, hipMemcpyHostToDevice, st));      // C_MS, C_RANK0
-        TRY(c->isa.ensure((size_t)(n + 1) * 4));
-        const u32 g = std::min<u32>(cdiv(m + z, 256), 65536u);
-        hipLaunchKernelGGL(k_isa_from_grp, dim3(g), dim3(256), 0, st, sa_local, grp_local, (u32)m, c->isa.as<u32>(), (u32)n, (u32)z);
-        cur = 0; sb = 2; nb = 0; mode = MODE_ISA; depth = resume_depth; round = 1;
-        hipLaunchKernelGGL(k_import_groups, dim3(cdiv(m, 256)), dim3(256), 0, st, sa_local, grp_local, (u32)m, (u32)(1 + z),
-                           bufs.p[sb], sb, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)C_POOL0, (u32)std::min<u64>(c->cap_m, 0xffffffffu),
-                           make_lists(cur), c->large_round[cur].as<Desc>(), c->large_cap, (u32)(C_LIST0 + 3), (u32)C_LTILES0, counters);
-        const u32 mm = (u32)m;
-        HIP_TRY(hipMemcpyAsync(counters + C_SEG0, &mm, 4, hipMemcpyHostToDevice, st));
-        DBG("import");
-        TRY(c->read_counters());
-        const u64 actP = c->h_counters[C_POOL0];
-        if (actP) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actP, 256), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, (u32)C_POOL0,
-                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), asigma, cpk, zlow);
-        hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(m, 256), 65536u)), dim3(256), 0, st, bufs.p[sb], counters, (u32)C_SEG0,
-                           d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), asigma, cpk, zlow);
-        depth *= 2; tm.doubling_rounds++; tm.rounds++;
-        HIP_TRY(hipEventRecord(c->ev[1], st)); HIP_TRY(hipEventRecord(c->ev[2], st)); HIP_TRY(hipEventRecord(c->ev[3], st)); HIP_TRY(hipEventRecord(c->ev[4], st));
     }
-    for (;; ++round) {
+    u32 cap32() const { return (u32)std::min<u64>(c->cap_m, 0xffffffffu); }
+
+    // children of the 65,536 two-byte buckets (after the level-1 partition of round 0)
+    int children_level1()
+    {
+        hipLaunchKernelGGL(k_children<W>, dim3(256), dim3(256), 0, st, bufs, c->seg0.template as<Desc>(), 256u, c->child_start.template as<u32>(), c->child_cnt.template as<u32>(),
+                           (const u32*)nullptr, 1u, 0u, 2u, 24u, sa_local, (u32*)nullptr, (u32*)nullptr, (u32)MODE_TEXT,
+                           c->pool_rec[cur].template as<u64>(), c->pool_hdr[cur].template as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), cap32(),
+                           make_lists(cur), c->lvl[0].template as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters);
+        DBG("k_children L1");
+        return c->read_counters();
+    }
+
+    int levels_and_sorts()
+    {
         const int nxt = cur ^ 1;
         u32 a[3];
-        alts(sb, nb, a);
+        { const u32 third = 3 - sb - nb; a[sb] = third; a[third] = sb; a[nb] = nb; }
         if (round == 0) { a[0] = 1; a[1] = 0; a[2] = 2; }   // round 0 ping-pongs between buffers 0 and 1
-        const u32 cap32 = (u32)std::min<u64>(c->cap_m, 0xffffffffu);
         // ---- partition levels for large segments ----
         {
             Desc* src_list; u32 nl, ntiles; int lp;       // lp = index of the lvl list used as destination
             u32 shift;
             if (round == 0) {
-                src_list = c->lvl[0].as<Desc>(); nl = c->h_counters[C_LVL0]; ntiles = c->h_counters[C_LVLT0]; lp = 1;
+                src_list = c->lvl[0].template as<Desc>(); nl = c->h_counters[C_LVL0]; ntiles = c->h_counters[C_LVLT0]; lp = 1;
                 // Two-byte buckets just above the class-C limit (1.2 .. 2 GiB of random bytes) should not be cut into
                 // 256 crumbs of ~100 records each (17 M class-A segments through the slow LSD sort): the level splits
                 // on an 8-bit window that starts only `b` bits below the consumed key byte - the rest of the window
@@ -423,52 +417,51 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 while (b < 8 && ((u64)c->h_counters[C_HMAX] >> b) > (u64)CAP_C * 3 / 4) ++b;
                 shift = 24 - b;
             }
-            else { src_list = c->large_round[cur].as<Desc>(); nl = c->h_counters[(cur ? C_LIST1 : C_LIST0) + 3]; ntiles = c->h_counters[cur ? C_LTILES1 : C_LTILES0]; lp = 0; shift = 24; }
+            else { src_list = c->large_round[cur].template as<Desc>(); nl = c->h_counters[(cur ? C_LIST1 : C_LIST0) + 3]; ntiles = c->h_counters[cur ? C_LTILES1 : C_LTILES0]; lp = 0; shift = 24; }
             while (nl > 0) {
-                // (small alphabets: k_scatter0 left only the top bl0 of the 24 key bits non-zero; a level that reaches below
-                // them ends round 0's splitting)
+                // (small alphabets: k_scatter0 left only the top bits of the key below the bucket byte non-zero; a level that
+                // reaches below them ends round 0's splitting)
                 const u32 sg0 = c->h_counters[C_ASIGMA];
-                const bool packed0 = round == 0 && !getenv("MSUFSORT_HIP_NO_PACK") && sg0 >= 2 && sg0 <= 84;
-                u32 bl0 = 0;
-                if (packed0) while (bl0 < 32 && (((u64)sg0 * sg0 * sg0 - 1) >> bl0) != 0) ++bl0;
-                const bool last = (shift == 0) || (packed0 && shift <= 24 - bl0);
+                const bool packed0 = round == 0 && !no_pack && sg0 >= 2 && sg0 <= 84;
+                const u32 bl0 = packed0 ? s0_digit_bits<W>(sg0) : 0u;
+                const bool last = (shift <= KL) || (packed0 && shift <= 24 - bl0);
                 const u32 cnt_idx = lp ? C_LVL1 : C_LVL0, til_idx = lp ? C_LVLT1 : C_LVLT0;
                 hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << cnt_idx) | (1u << til_idx));
-                hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, src_list, nl, c->tile_start.as<u32>());
+                hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, src_list, nl, c->tile_start.template as<u32>());
                 HIP_TRY(hipMemsetAsync(c->seg_hist.p, 0, (size_t)nl * 256 * 4, st));
                 HIP_TRY(hipMemsetAsync(c->trivial.p, 0, (size_t)nl * 4, st));
-                hipLaunchKernelGGL(k_count, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.as<u32>(), shift, c->seg_hist.as<u32>());
+                hipLaunchKernelGGL(k_count, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.template as<u32>(), shift, c->seg_hist.template as<u32>());
                 DBG("k_count");
-                hipLaunchKernelGGL(k_segscan, dim3(nl), dim3(256), 0, st, src_list, nl, c->seg_hist.as<u32>(), c->child_start.as<u32>(), c->cursor.as<u32>(), c->trivial.as<u32>());
+                hipLaunchKernelGGL(k_segscan, dim3(nl), dim3(256), 0, st, src_list, nl, c->seg_hist.template as<u32>(), c->child_start.template as<u32>(), c->cursor.template as<u32>(), c->trivial.template as<u32>());
                 DBG("k_segscan");
-                hipLaunchKernelGGL(k_partition, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.as<u32>(), shift,
-                                   c->cursor.as<u32>(), c->trivial.as<u32>(), a[0], a[1], a[2]);
+                hipLaunchKernelGGL(k_partition, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.template as<u32>(), shift,
+                                   c->cursor.template as<u32>(), c->trivial.template as<u32>(), a[0], a[1], a[2]);
                 DBG("k_partition level");
-                hipLaunchKernelGGL(k_children, dim3(nl), dim3(256), 0, st, bufs, src_list, nl, c->child_start.as<u32>(), c->seg_hist.as<u32>(),
-                                   c->trivial.as<u32>(), a[0], a[1], a[2], shift, sa_local, c->isa.as<u32>(), mode,
-                                   c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), cap32,
-                                   make_lists(cur), c->lvl[lp].as<Desc>(), c->large_cap, cnt_idx, til_idx, counters);
+                hipLaunchKernelGGL(k_children<W>, dim3(nl), dim3(256), 0, st, bufs, src_list, nl, c->child_start.template as<u32>(), c->seg_hist.template as<u32>(),
+                                   c->trivial.template as<u32>(), a[0], a[1], a[2], shift, sa_local, isa32, grp_out, mode,
+                                   c->pool_rec[cur].template as<u64>(), c->pool_hdr[cur].template as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), cap32(),
+                                   make_lists(cur), c->lvl[lp].template as<Desc>(), c->large_cap, cnt_idx, til_idx, counters);
                 DBG("k_children level");
                 TRY(c->read_counters());
-                src_list = c->lvl[lp].as<Desc>();
+                src_list = c->lvl[lp].template as<Desc>();
                 nl = c->h_counters[cnt_idx];
                 ntiles = c->h_counters[til_idx];
                 lp ^= 1;
                 if (last) {
                     if (nl > 0) {
-                        hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, src_list, nl, c->tile_start.as<u32>());
-                        hipLaunchKernelGGL(k_carry_alloc, dim3(cdiv(nl, 256)), dim3(256), 0, st, src_list, nl, c->trivial.as<u32>(),
-                                           DESC_BUF(32, nb), (u32)(nxt ? C_SEG1 : C_SEG0), cap32,
-                                           c->large_round[nxt].as<Desc>(), c->large_cap, (u32)((nxt ? C_LIST1 : C_LIST0) + 3), (u32)(nxt ? C_LTILES1 : C_LTILES0), counters);
-                        hipLaunchKernelGGL(k_carry_copy, dim3(ntiles), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.as<u32>(), c->trivial.as<u32>(),
-                                           sa_local, c->isa.as<u32>(), mode, bufs.p[nb], counters);
+                        hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, src_list, nl, c->tile_start.template as<u32>());
+                        hipLaunchKernelGGL(k_carry_alloc, dim3(cdiv(nl, 256)), dim3(256), 0, st, src_list, nl, c->trivial.template as<u32>(),
+                                           DESC_BUF(32, nb), (u32)(nxt ? C_SEG1 : C_SEG0), cap32(),
+                                           c->large_round[nxt].template as<Desc>(), c->large_cap, (u32)((nxt ? C_LIST1 : C_LIST0) + 3), (u32)(nxt ? C_LTILES1 : C_LTILES0), counters);
+                        hipLaunchKernelGGL(k_carry_copy<W>, dim3(ntiles), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.template as<u32>(), c->trivial.template as<u32>(),
+                                           sa_local, isa32, grp_out, mode, bufs.p[nb], counters);
                         // what the carry reserved must survive a repeated sort attempt (see the retry below)
                         hipLaunchKernelGGL(k_copy_idx, dim3(1), dim3(64), 0, st, counters, (u32)C_CARRY, (u32)(nxt ? C_SEG1 : C_SEG0));
                         DBG("k_carry");
                     }
                     break;
                 }
-                shift = shift >= 8 ? shift - 8 : 0;
+                shift = shift >= 8 + KL ? shift - 8 : KL;
             }
         }
         // ---- LDS sorts of everything that fits ----
@@ -478,152 +471,243 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         // buffers.  The sorts only read this round's records, and what they write (rows, ranks, next round's
         // records) is rebuilt identically by a second run, so an overflowing attempt is simply repeated with exact
         // reservations (one global atomic per request, no waste: the live records always fit).
-        u32 nA = 0, nB = 0, nC = 0, nP = 0;
+        nA = nB = nC = nP = 0;
         // once a round has overflowed, the following ones start exact while the tied set stays that large
         if (exact_sticky && (u64)c->h_counters[cur ? C_POOL1 : C_POOL0] + c->h_counters[cur ? C_SEG1 : C_SEG0] < c->cap_m / 2) exact_sticky = false;
         for (int attempt = exact_sticky ? 1 : 0; ; ++attempt) {
-        Emit em;
-        em.pool_rec = c->pool_rec[nxt].as<u64>(); em.pool_hdr = c->pool_hdr[nxt].as<u64>();
-        em.seg_rec = bufs.p[nb]; em.seg_buf = DESC_BUF(32, nb);
-        em.pool_cnt_idx = nxt ? C_POOL1 : C_POOL0; em.seg_cnt_idx = nxt ? C_SEG1 : C_SEG0;
-        em.pool_cap = cap32; em.seg_cap = cap32;
-        {   // chunk = what the persistent workgroups reserve per global atomic; slack <= active/16 per kernel
-            const u64 act = (u64)c->h_counters[cur ? C_POOL1 : C_POOL0] + c->h_counters[cur ? C_SEG1 : C_SEG0] + (round == 0 ? m : 0);
-            const u64 ch = std::min<u64>(4096, std::max<u64>(32, act / (16 * 8192)));
-            em.pool_chunk = attempt == 0 ? (u32)ch : 0u; em.seg_chunk = em.pool_chunk;
-        }
-        em.lists = make_lists(nxt);
-        // The chunk above is sized for the 8192-workgroup launches (class A, tiny pool).  The class-B / class-C sorts
-        // run 1024 / 256 workgroups whose segments emit thousands of records each: with the small chunk nearly every
-        // segment goes to the two global counters (one returning atomic per segment, ~90 per us chip-wide), so they
-        // take proportionally larger chunks (same total of open chunk tails).
-        Emit emB = em, emC = em;
-        emB.pool_chunk = emB.seg_chunk = (u32)std::min<u64>(65536, (u64)em.seg_chunk * 8);
-        emC.pool_chunk = emC.seg_chunk = (u32)std::min<u64>(262144, (u64)em.seg_chunk * 32);
-        const u32 base = cur ? C_LIST1 : C_LIST0;
-        nA = c->h_counters[base + 0]; nB = c->h_counters[base + 1]; nC = c->h_counters[base + 2];
-        nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
-        // k_sort_fast needs spread-out keys.  The 16-bit histogram already tells: if its largest bucket is far
-        // above the mean the input is text-like and every attempt (reading the records, a serialised LDS-atomic
-        // phase, rejection) would be wasted work - go straight to the LSD sort.
-        const u64 ms_shard = c->h_counters[C_MS];
-        const bool spread = (u64)c->h_counters[C_HMAX] * (u64)(khi - klo) <= 8ull * std::max<u64>(ms_shard, 1);   // max <= 8 x mean
-        // Later rounds of a small-alphabet input sort dense base-sigma keys: if the symbols are about evenly used
-        // (largest two-byte bucket <= 2 x the mean of the non-empty ones: random DNA, base64, hex dumps) the children of
-        // the partition levels are as spread out as random bytes.  The attempt is dropped for the rest of the build as
-        // soon as a round hands more than a quarter of its segments back (tandem repeats, text).
-        // (round 0's dense digits give class-B children of a few hundred records: the 2^13-entry table of k_sort_fast2 costs
-        // more than it saves there - measured on 16..80-symbol random texts - so the dense keys only count from round 1 on)
-        // ... and only for alphabets of up to 16 codes (>= 8 symbols per key): measured, a 17-code hex text loses 11 ms to it
-        const bool dense_uniform = round >= 1 && cpk >= 8u &&
-                                   (u64)c->h_counters[C_HMAX] * (u64)std::max<u32>(c->h_counters[C_HNZ], 1u) <= 2ull * std::max<u64>(ms_shard, 1);
-        const bool use_fast = getenv("MSUFSORT_HIP_NO_FAST") == nullptr &&
-                              (spread || (dense_uniform && !fast_gave_up) || getenv("MSUFSORT_HIP_FORCE_FAST"));
-        if (use_fast && (nB || nC)) hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << C_FBB) | (1u << C_FBC));
-        if (nC) {
-            const u32* ids = nullptr;
-            if (use_fast) {
-                k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_fast2_lds_bytes<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C>(), st>>>(
-                    bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneC.as<u32>(), (u32)C_FBC);
-                DBG("k_sort_fast C");
+            Emit em;
+            em.pool_rec = c->pool_rec[nxt].template as<u64>(); em.pool_hdr = c->pool_hdr[nxt].template as<u64>();
+            em.seg_rec = bufs.p[nb]; em.seg_buf = DESC_BUF(32, nb);
+            em.pool_cnt_idx = nxt ? C_POOL1 : C_POOL0; em.seg_cnt_idx = nxt ? C_SEG1 : C_SEG0;
+            em.pool_cap = cap32(); em.seg_cap = cap32();
+            em.discard = discard; em.grp_out = grp_out;
+            {   // chunk = what the persistent workgroups reserve per global atomic; slack <= active/16 per kernel
+                const u64 act = (u64)c->h_counters[cur ? C_POOL1 : C_POOL0] + c->h_counters[cur ? C_SEG1 : C_SEG0] + (round == 0 ? c->h_counters[C_MS] : 0);
+                const u64 ch = std::min<u64>(4096, std::max<u64>(32, act / (16 * 8192)));
+                em.pool_chunk = attempt == 0 ? (u32)ch : 0u; em.seg_chunk = em.pool_chunk;
+            }
+            em.lists = make_lists(nxt);
+            // The chunk above is sized for the 8192-workgroup launches (class A, tiny pool).  The class-B / class-C sorts
+            // run 1024 / 256 workgroups whose segments emit thousands of records each: with the small chunk nearly every
+            // segment goes to the two global counters (one returning atomic per segment, ~90 per us chip-wide), so they
+            // take proportionally larger chunks (same total of open chunk tails).
+            Emit emB = em, emC = em;
+            emB.pool_chunk = emB.seg_chunk = (u32)std::min<u64>(65536, (u64)em.seg_chunk * 8);
+            emC.pool_chunk = emC.seg_chunk = (u32)std::min<u64>(262144, (u64)em.seg_chunk * 32);
+            const u32 base = cur ? C_LIST1 : C_LIST0;
+            nA = c->h_counters[base + 0]; nB = c->h_counters[base + 1]; nC = c->h_counters[base + 2];
+            nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
+            // k_sort_fast needs spread-out keys.  The 16-bit histogram already tells: if its largest bucket is far
+            // above the mean the input is text-like and every attempt (reading the records, a serialised LDS-atomic
+            // phase, rejection) would be wasted work - go straight to the LSD sort.
+            const u64 ms_shard = c->h_counters[C_MS];
+            const bool spread = (u64)c->h_counters[C_HMAX] * (u64)(khi - klo) <= 8ull * std::max<u64>(ms_shard, 1);   // max <= 8 x mean
+            // Later rounds of a small-alphabet input sort dense base-sigma keys: if the symbols are about evenly used
+            // (largest two-byte bucket <= 2 x the mean of the non-empty ones: random DNA, base64, hex dumps) the children of
+            // the partition levels are as spread out as random bytes.  The attempt is dropped for the rest of the build as
+            // soon as a round hands more than a quarter of its segments back (tandem repeats, text).
+            // (round 0's dense digits give class-B children of a few hundred records: the 2^13-entry table of k_sort_fast2 costs
+            // more than it saves there - measured on 16..80-symbol random texts - so the dense keys only count from round 1 on)
+            // ... and only for alphabets of up to 16 codes (>= 8 symbols per key): measured, a 17-code hex text loses 11 ms to it
+            const bool dense_uniform = round >= 1 && cpk >= 8u &&
+                                       (u64)c->h_counters[C_HMAX] * (u64)std::max<u32>(c->h_counters[C_HNZ], 1u) <= 2ull * std::max<u64>(ms_shard, 1);
+            // (k_sort_fast2 exists for narrow records and text keys only)
+            const bool use_fast = !W && mode == MODE_TEXT && getenv("MSUFSORT_HIP_NO_FAST") == nullptr &&
+                                  (spread || (dense_uniform && !fast_gave_up) || getenv("MSUFSORT_HIP_FORCE_FAST"));
+            if (use_fast && (nB || nC)) hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << C_FBB) | (1u << C_FBC));
+            if (nC) {
+                const u32* ids = nullptr;
+                if constexpr (!W) {
+                    if (use_fast) {
+                        k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_fast2_lds_bytes<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C>(), st>>>(
+                            bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, em, counters, c->doneC.template as<u32>(), (u32)C_FBC);
+                        DBG("k_sort_fast C");
 #ifdef FAST2_PROF
-                {
-                    unsigned long long h[16];
-                    hipStreamSynchronize(st);
-                    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fast2_prof), sizeof h);
-                    fprintf(stderr, "[fast2 prof] nC=%u cycles/1e6:", nC);
-                    for (int i = 0; i < 12; ++i) fprintf(stderr, " p%d=%.1f", i, h[i] / 1e6);
-                    fprintf(stderr, "\n");
-                    memset(h, 0, sizeof h);
-                    hipMemcpyToSymbol(HIP_SYMBOL(g_fast2_prof), h, sizeof h);
-                }
+                        {
+                            unsigned long long h[16];
+                            hipStreamSynchronize(st);
+                            hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fast2_prof), sizeof h);
+                            fprintf(stderr, "[fast2 prof] nC=%u cycles/1e6:", nC);
+                            for (int i = 0; i < 12; ++i) fprintf(stderr, " p%d=%.1f", i, h[i] / 1e6);
+                            fprintf(stderr, "\n");
+                            memset(h, 0, sizeof h);
+                            hipMemcpyToSymbol(HIP_SYMBOL(g_fast2_prof), h, sizeof h);
+                        }
 #endif
-                ids = c->doneC.as<u32>();
+                        ids = c->doneC.template as<u32>();
+                    }
+                }
+                k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
+                    bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, emC, counters, ids, (u32)C_FBC);
+                DBG("k_sort_mid C");
             }
-            k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
-                bufs, c->lists[cur][2].as<Desc>(), nC, sa_local, c->isa.as<u32>(), mode, emC, counters, ids, (u32)C_FBC);
-            DBG("k_sort_mid C");
-        }
-        if (c->sync_debug) {
-            for (int k = 0; k < 3; ++k) {
-                const u32 cnt = c->h_counters[base + k];
-                if (!cnt) continue;
-                (void)c->aux0.ensure(256);
-                (void)hipMemsetAsync(c->aux0.p, 0, 256, st);
-                hipLaunchKernelGGL(k_dbg_check_descs, dim3(1024), dim3(256), 0, st, c->lists[cur][k].as<Desc>(), cnt, cap32, (u32)c->h_counters[C_MS], c->aux0.as<u32>());
-                u32 h[40];
-                (void)hipMemcpyAsync(h, c->aux0.p, 160, hipMemcpyDeviceToHost, st);
-                (void)hipStreamSynchronize(st);
-                fprintf(stderr, "[dbg] class %d: %u descriptors, %u bad", k, cnt, h[0]);
-                for (u32 q = 0; q < std::min<u32>(h[0], 6); ++q) fprintf(stderr, " (#%u off %u len %u sa %u buf 0x%x)", h[1 + 5 * q], h[2 + 5 * q], h[3 + 5 * q], h[4 + 5 * q], h[5 + 5 * q]);
-                fprintf(stderr, "\n");
+            if (c->sync_debug) {
+                for (int k = 0; k < 3; ++k) {
+                    const u32 cnt = c->h_counters[base + k];
+                    if (!cnt) continue;
+                    (void)c->aux0.ensure(256);
+                    (void)hipMemsetAsync(c->aux0.p, 0, 256, st);
+                    hipLaunchKernelGGL(k_dbg_check_descs, dim3(1024), dim3(256), 0, st, c->lists[cur][k].template as<Desc>(), cnt, cap32(), (u32)c->h_counters[C_MS], c->aux0.template as<u32>());
+                    u32 h[40];
+                    (void)hipMemcpyAsync(h, c->aux0.p, 160, hipMemcpyDeviceToHost, st);
+                    (void)hipStreamSynchronize(st);
+                    fprintf(stderr, "[dbg] class %d: %u descriptors, %u bad", k, cnt, h[0]);
+                    for (u32 q = 0; q < std::min<u32>(h[0], 6); ++q) fprintf(stderr, " (#%u off %u len %u sa %u buf 0x%x)", h[1 + 5 * q], h[2 + 5 * q], h[3 + 5 * q], h[4 + 5 * q], h[5 + 5 * q]);
+                    fprintf(stderr, "\n");
+                }
+            }
+            if (nB) {
+                const u32* ids = nullptr;
+                if constexpr (!W) {
+                    if (use_fast) {
+                        k_sort_fast2<CLS_B_THREADS, CLS_B_ITEMS, FAST_BITS_B, FAST2_TL_B><<<dim3(std::min<u32>(nB, 256u * 4u)), dim3(CLS_B_THREADS), sort_fast2_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, FAST_BITS_B, FAST2_TL_B>(), st>>>(
+                            bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, em, counters, c->doneB.template as<u32>(), (u32)C_FBB);
+                        DBG("k_sort_fast B");
+                        ids = c->doneB.template as<u32>();
+                    }
+                }
+                k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
+                    bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, emB, counters, ids, (u32)C_FBB);
+                DBG("k_sort_mid B");
+            }
+            if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
+                        bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, (const u32*)nullptr, 0u);
+            DBG("k_sort_mid A");
+            if (nP) hipLaunchKernelGGL(k_sort_tiny<W>, dim3(std::min<u32>(cdiv(nP, 256), 8192u)), dim3(256), 0, st, c->pool_rec[cur].template as<u64>(), c->pool_hdr[cur].template as<u64>(),
+                                       (u32)(cur ? C_POOL1 : C_POOL0), sa_local, isa32, mode,
+                                       em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32(), em.pool_chunk, counters, grp_out, discard);
+            DBG("k_sort_tiny");
+            if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
+            TRY(c->read_counters(attempt == 0));
+            if (attempt == 0 && force_retry) c->h_counters[C_ERR] |= 0x8000u;      // test hook: MSUFSORT_HIP_FORCE_RETRY=1
+            if (c->h_counters[C_ERR] == 0) {
+                if (use_fast && !spread && (u64)(c->h_counters[C_FBB] + c->h_counters[C_FBC]) * 4 > (u64)nB + nC) fast_gave_up = true;
+                break;
+            }
+            if (c->h_counters[C_ERR] & ~0x8000u) exact_sticky = true;    // (the test hook repeats EVERY round's first attempt)
+            {   // attempt 0 ran out of room: forget what it reserved for the next round and go again
+                if (verbose) fprintf(stderr, "[msufsort_hip] round %d: reservation slack exhausted (flags 0x%x), repeating with exact reservations\n", round, c->h_counters[C_ERR]);
+                const u32 nP_ = nxt ? C_POOL1 : C_POOL0, nS_ = nxt ? C_SEG1 : C_SEG0, nL_ = nxt ? C_LIST1 : C_LIST0;
+                // (carried large segments already sit at the start of next round's segment array, their descriptors in
+                // its large list: the segment counter goes back to the end of the carry, not to 0, and the large list stays)
+                hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << nP_) | (0x7u << nL_) | (1u << C_ERR));
+                hipLaunchKernelGGL(k_copy_idx, dim3(1), dim3(64), 0, st, counters, nS_, (u32)C_CARRY);
             }
         }
-        if (nB) {
-            const u32* ids = nullptr;
-            if (use_fast) {
-                k_sort_fast2<CLS_B_THREADS, CLS_B_ITEMS, FAST_BITS_B, FAST2_TL_B><<<dim3(std::min<u32>(nB, 256u * 4u)), dim3(CLS_B_THREADS), sort_fast2_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, FAST_BITS_B, FAST2_TL_B>(), st>>>(
-                    bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, em, counters, c->doneB.as<u32>(), (u32)C_FBB);
-                DBG("k_sort_fast B");
-                ids = c->doneB.as<u32>();
-            }
-            k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
-                bufs, c->lists[cur][1].as<Desc>(), nB, sa_local, c->isa.as<u32>(), mode, emB, counters, ids, (u32)C_FBB);
-            DBG("k_sort_mid B");
-        }
-        if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
-                    bufs, c->lists[cur][0].as<Desc>(), nA, sa_local, c->isa.as<u32>(), mode, em, counters, (const u32*)nullptr, 0u);
-        DBG("k_sort_mid A");
-        if (nP) hipLaunchKernelGGL(k_sort_tiny, dim3(std::min<u32>(cdiv(nP, 256), 8192u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(),
-                                   (u32)(cur ? C_POOL1 : C_POOL0), sa_local, c->isa.as<u32>(), mode,
-                                   em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32, em.pool_chunk, counters);
-        DBG("k_sort_tiny");
-        if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
-        TRY(c->read_counters(attempt == 0));
-        if (attempt == 0 && force_retry) c->h_counters[C_ERR] |= 0x8000u;      // test hook: MSUFSORT_HIP_FORCE_RETRY=1
-        if (c->h_counters[C_ERR] == 0) {
-            if (use_fast && !spread && (u64)(c->h_counters[C_FBB] + c->h_counters[C_FBC]) * 4 > (u64)nB + nC) fast_gave_up = true;
-            break;
-        }
-        if (c->h_counters[C_ERR] & ~0x8000u) exact_sticky = true;    // (the test hook repeats EVERY round's first attempt)
-        {   // attempt 0 ran out of room: forget what it reserved for the next round and go again
-            if (verbose) fprintf(stderr, "[msufsort_hip] round %d: reservation slack exhausted (flags 0x%x), repeating with exact reservations\n", round, c->h_counters[C_ERR]);
-            const u32 nP_ = nxt ? C_POOL1 : C_POOL0, nS_ = nxt ? C_SEG1 : C_SEG0, nL_ = nxt ? C_LIST1 : C_LIST0;
-            // (carried large segments already sit at the start of next round's segment array, their descriptors in
-            // its large list: the segment counter goes back to the end of the carry, not to 0, and the large list stays)
-            hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << nP_) | (0x7u << nL_) | (1u << C_ERR));
-            hipLaunchKernelGGL(k_copy_idx, dim3(1), dim3(64), 0, st, counters, nS_, (u32)C_CARRY);
-        }
-        }
+        return MSUFSORT_HIP_OK;
+    }
 
+    // rotate buffers and slots after a completed round; zero the counters the round after next will fill
+    void advance()
+    {
+        const int nxt = cur ^ 1;
+        cur = nxt;
+        { const u32 third = 3 - sb - nb; sb = nb; nb = (round == 0) ? 0u : third; if (nb == sb) nb = (sb + 1) % 3; }
+        const u32 oP = cur ? C_POOL0 : C_POOL1, oS = cur ? C_SEG0 : C_SEG1, oL = cur ? C_LIST0 : C_LIST1, oT = cur ? C_LTILES0 : C_LTILES1;
+        hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters,
+                           (1u << oP) | (1u << oS) | (0xfu << oL) | (1u << oT) | (1u << C_CARRY));
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// The suffix-array build for one shard.  d_sa_rows points at row `slice_row_lo` of the suffix array (the shard's first
+// row); `with_head` also writes SA[0] and the trailing-zero rows.  rank0 = global rank of the shard's first
+// radix-sorted suffix (z + number of suffixes with smaller 16-bit keys).
+// d_grp_rows (optional, same indexing as d_sa_rows): receives the LOCAL tie-group head row of every slice row when the
+// build stops with unresolved groups (return value MSUFSORT_HIP_UNRESOLVED): sharded builds, and every wide build
+// (their prefix doubling is the distributed one further down).
+// ------------------------------------------------------------------------------------------------
+#define MSUFSORT_HIP_UNRESOLVED 1
+template <bool W>
+int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_rows /* row 0 of this shard's slice */, u64 slice_row_lo,
+             u64 z, u32 klo, u32 khi, u64 rank0, bool with_head, const msufsort_hip_opts* opts, bool hist_done,
+             u32* d_grp_rows = nullptr, u64 slice_rows = 0)
+{
+    typedef typename Wd<W>::sa_t sa_t;
+    const int verbose = opts ? opts->verbose : 0;
+    const bool sharded = W || (opts && opts->n_shards > 1);
+    const bool auto_switch = !(opts && opts->text_rounds > 0) && !getenv("MSUFSORT_HIP_TEXT_ROUNDS");
+    int text_rounds = (opts && opts->text_rounds > 0) ? opts->text_rounds : 24;
+    u64 prev_active = 0;
+    if (const char* e = getenv("MSUFSORT_HIP_TEXT_ROUNDS")) text_rounds = std::max(1, atoi(e));
+    const u64 m = n - z;
+    hipStream_t st = c->stream;
+    auto& tm = c->tm;
+    memset(&tm, 0, sizeof tm);
+    tm.n = (int64_t)n; tm.m = (int64_t)m;
+    TRY(c->set_attrs());
+    HIP_TRY(hipEventRecord(c->ev[0], st));
+    if (with_head) hipLaunchKernelGGL(k_sa_head<W>, dim3(grid_for(std::max<u64>(z, 1))), dim3(256), 0, st, d_sa_rows, n, z);
+    auto finish_groups = [&]() { if (d_grp_rows && slice_rows) hipLaunchKernelGGL(k_grp_iota, dim3(grid_for(slice_rows)), dim3(256), 0, st, d_grp_rows, slice_rows, 0u); };
+    const u64 ms = slice_rows ? slice_rows - (with_head ? 1 + z : 0) : m;      // suffixes this build sorts (the shard's, from the planned bounds)
+    if (m == 0 || ms == 0) {
+        finish_groups();
+        HIP_TRY(hipEventRecord(c->ev[5], st)); HIP_TRY(hipStreamSynchronize(st)); return MSUFSORT_HIP_OK;
+    }
+    TRY(c->ensure_workspace(ms));           // (before anything points into it; growing it reallocates buffers the scan fills)
+    u32* counters = c->counters.as<u32>();
+    Rounds<W> R;
+    R.c = c; R.st = st; R.counters = counters;
+    R.klo = klo; R.khi = khi; R.verbose = verbose;
+    R.force_retry = getenv("MSUFSORT_HIP_FORCE_RETRY") != nullptr;   // test hook: every round's first sort attempt is thrown away
+    R.no_pack = getenv("MSUFSORT_HIP_NO_PACK") != nullptr;
+
+    // ---- round 0: 16-bit histogram, offsets, two 8-bit scatter levels ----
+    if (!hist_done) TRY(run_hist<W>(c, d_text, m));
+    HIP_TRY(hipMemsetAsync(counters, 0, C_NCOUNTERS * 4, st));
+    HIP_TRY(hipEventRecord(c->ev[1], st));
+    run_scan<W>(c, klo, khi, z);
+    R.bufs = RecBufs{{c->rec[0].as<u64>(), c->rec[1].as<u64>(), c->rec[2].as<u64>()}};
+    RecBufs& bufs = R.bufs;
+    sa_t* sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
+    R.sa_local = sa_local;
+    hipLaunchKernelGGL(k_scatter0<W>, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, m, klo, khi, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0], c->alpha.as<u8>(), counters, R.no_pack ? 0u : 1u);
+    HIP_TRY(hipEventRecord(c->ev[2], st));
+    DBG("k_scatter0");
+    hipLaunchKernelGGL(k_partition, dim3(cdiv(cdiv(ms, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
+                       c->tile_start.as<u32>(), 24u, c->cursor.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u);
+    HIP_TRY(hipEventRecord(c->ev[3], st));
+    DBG("k_partition L1");
+
+    u64 depth = 5;               // text bytes consumed after round 0 (narrow: bucket bytes 0,1 + key bytes 2,3,4); set below for wide
+    KeySpec ks{};                // dense alphabet code of the gather rounds (k_alphabet; known after round 0)
+    ks.sigma = 256; ks.cpk = W ? 3u : 4u; ks.zlow = 0; ks.dig_shift = 0; ks.dig_mask = 0xffffffu;
+
+    TRY(R.children_level1());
+    if ((u64)c->h_counters[C_MS] != ms && slice_rows) { set_error("slice bounds disagree with the histogram (%u suffixes on the device, %llu planned)", c->h_counters[C_MS], (unsigned long long)ms); return MSUFSORT_HIP_ERR_INTERNAL; }
+
+    for (;; ++R.round) {
+        const int round = R.round;
+        TRY(R.levels_and_sorts());
+        const int nxt = R.cur ^ 1;
         const u32 nb_base = nxt ? C_LIST1 : C_LIST0;
         const u64 actP = c->h_counters[nxt ? C_POOL1 : C_POOL0], actS = c->h_counters[nxt ? C_SEG1 : C_SEG0];
         if (verbose)
             fprintf(stderr, "[msufsort_hip] round %d mode %s depth %llu: sorted A=%u B=%u C=%u tiny=%u -> next tiny=%llu seg=%llu (A=%u B=%u C=%u L=%u)\n",
-                    round, mode == MODE_TEXT ? "text" : "isa", (unsigned long long)depth, nA, nB, nC, nP, (unsigned long long)actP, (unsigned long long)actS,
+                    round, R.mode == MODE_TEXT ? "text" : "isa", (unsigned long long)depth, R.nA, R.nB, R.nC, R.nP, (unsigned long long)actP, (unsigned long long)actS,
                     c->h_counters[nb_base], c->h_counters[nb_base + 1], c->h_counters[nb_base + 2], c->h_counters[nb_base + 3]);
         if (round == 0) tm.unresolved_after_round0 = (int64_t)(actP + actS);
         if (actP + actS == 0) break;
-        if (round == 0 && !resume) {     // key packing for the gather rounds (k_alphabet ran with the histogram)
+        if (round == 0) {     // key packing for the gather rounds (k_alphabet ran with the histogram)
             const u32 b = c->h_counters[C_ABITS], sg = c->h_counters[C_ASIGMA];
-            if (b >= 2 && sg >= 2 && !getenv("MSUFSORT_HIP_NO_PACK")) {
+            const bool packed0 = !R.no_pack && sg >= 2 && sg <= 84;
+            if (W) depth = packed0 ? 2 + s0_symbols<W>(sg) : 4;
+            if (b >= 2 && sg >= 2 && !R.no_pack) {
                 u64 p = 1; u32 k = 0;
-                while (k < 16 && p * sg <= (1ull << 32)) { p *= sg; ++k; }       // sigma^k <= 2^32
-                if (k >= 5) {                                                     // (sigma <= 84: at least one symbol more than a 4-byte window)
+                while (k < 16 && p * sg <= (1ull << (W ? 24 : 32))) { p *= sg; ++k; }       // sigma^k <= 2^(key bits)
+                if (k >= (W ? 4u : 5u)) {                                          // at least one symbol more than a plain window
                     u32 bl = 0; while (bl < 32 && ((p - 1) >> bl) != 0) ++bl;     // bits of the largest key
-                    asigma = sg; cpk = k; zlow = 32 - bl;
+                    ks.sigma = sg; ks.cpk = k; ks.zlow = 32 - bl;
                 }
             }
-            if (verbose) fprintf(stderr, "[msufsort_hip] alphabet: %u codes (%u bits) -> %u symbols per key\n", sg, b, cpk);
+            R.cpk = ks.cpk;
+            if (verbose) fprintf(stderr, "[msufsort_hip] alphabet: %u codes (%u bits) -> %u symbols per key\n", sg, b, ks.cpk);
         }
 
         // ---- prepare next round ----
-        cur = nxt;
-        { u32 third = 3 - sb - nb; sb = nb; nb = (round == 0) ? 0u : third; if (nb == sb) nb = (sb + 1) % 3; }
+        R.advance();
+        const int cur = R.cur;
         const u32 curP = cur ? C_POOL1 : C_POOL0, curS = cur ? C_SEG1 : C_SEG0, curL = cur ? C_LIST1 : C_LIST0;
-        const u32 oP = cur ? C_POOL0 : C_POOL1, oS = cur ? C_SEG0 : C_SEG1, oL = cur ? C_LIST0 : C_LIST1, oT = cur ? C_LTILES0 : C_LTILES1;
-        hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters,
-                           (1u << oP) | (1u << oS) | (0xfu << oL) | (1u << oT) | (1u << C_CARRY));
         // Switch from key gathers to prefix doubling after text_rounds rounds, or (default policy) as soon as the
         // tied set stops shrinking: a round that keeps > 70 % of the previous round's ties means long repeats,
         // where every further 4-byte round is wasted and doubling (log2 LCP rounds) wins despite the ISA build.
@@ -635,14 +719,14 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
         const bool stalled = auto_switch && !sharded && round >= 2 && (double)depth >= std::max(13.0, 1.3 * need) &&
                              (actP + actS) * 10 > prev_active * 7;
         prev_active = actP + actS;
-        if (mode == MODE_TEXT && (round + 1 > text_rounds || stalled)) {
+        if (R.mode == MODE_TEXT && (round + 1 > text_rounds || stalled)) {
             if (sharded) {
                 if (!d_grp_rows) { set_error("ties deeper than %llu bytes in a sharded build and no group buffer was given", (unsigned long long)depth); return MSUFSORT_HIP_ERR_UNSUPPORTED; }
-                // publish the tie groups of my slice; the caller gathers (SA, grp) and finishes with msufsort_hip_finish_sa_dev
-                u32* grp_local = d_grp_rows + (1 + rank0 - slice_row_lo);
-                const u32 row0 = (u32)(1 + rank0);
-                hipLaunchKernelGGL(k_grp_iota, dim3(std::min<u32>(cdiv(std::max<u64>(slice_rows, 1), 256), 65536u)), dim3(256), 0, st, d_grp_rows, slice_rows, (u32)slice_row_lo);
-                if (actP) hipLaunchKernelGGL(k_grp_pool, dim3(std::min<u32>(cdiv(actP, 256), 65536u)), dim3(256), 0, st, c->pool_hdr[cur].as<u64>(), counters, curP, grp_local, row0);
+                // publish the tie groups of my slice (local rows); the caller continues with the distributed doubling
+                const u32 row0 = (u32)(1 + rank0 - slice_row_lo);
+                u32* grp_local = d_grp_rows + row0;
+                hipLaunchKernelGGL(k_grp_iota, dim3(grid_for(std::max<u64>(slice_rows, 1))), dim3(256), 0, st, d_grp_rows, slice_rows, 0u);
+                if (actP) hipLaunchKernelGGL(k_grp_pool, dim3(grid_for(actP)), dim3(256), 0, st, c->pool_hdr[cur].as<u64>(), counters, curP, grp_local, row0);
                 for (int k = 0; k < 3; ++k) {
                     const u32 cnt = c->h_counters[curL + k];
                     if (cnt) hipLaunchKernelGGL(k_grp_segs, dim3(cnt), dim3(256), 0, st, c->lists[cur][k].as<Desc>(), cnt, grp_local, row0);
@@ -651,56 +735,274 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, u32* d_sa_rows /* row 0 of 
                 HIP_TRY(hipEventRecord(c->ev[5], st));
                 HIP_TRY(hipStreamSynchronize(st));
                 HIP_TRY(hipGetLastError());
+                float ms_ = 0;
+                (void)hipEventElapsedTime(&ms_, c->ev[0], c->ev[5]); tm.total_ms = ms_;
                 tm.reserved[0] = (int64_t)depth;
                 return MSUFSORT_HIP_UNRESOLVED;
             }
-            // switch to prefix doubling: build the inverse suffix array
-            TRY(c->isa.ensure((size_t)(n + 1) * 4));
-            if (c->sync_debug) {
-                TRY(c->aux0.ensure(256));
-                HIP_TRY(hipMemsetAsync(c->aux0.p, 0, 256, st));
-                hipLaunchKernelGGL(k_dbg_scan_sa, dim3(4096), dim3(256), 0, st, sa_local, (u32)c->h_counters[C_MS], (u32)n, c->aux0.as<u32>());
-                u32 h[32];
-                HIP_TRY(hipMemcpyAsync(h, c->aux0.p, 128, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                fprintf(stderr, "[dbg] bad SA rows before isa build: %u", h[0]);
-                for (u32 k = 0; k < std::min<u32>(h[0], 8); ++k) fprintf(stderr, " (row %u val %u)", h[1 + 2 * k], h[2 + 2 * k]);
-                fprintf(stderr, "\n");
+            if constexpr (!W) {
+                // switch to prefix doubling: build the inverse suffix array
+                TRY(c->isa.ensure((size_t)(n + 1) * 4));
+                u32* isa = c->isa.as<u32>();
+                hipLaunchKernelGGL(k_isa_init, dim3(grid_for(m + z)), dim3(256), 0, st, sa_local, counters, isa, (u32)n, (u32)z);
+                DBG("k_isa_init");
+                if (actP) hipLaunchKernelGGL(k_isa_pool, dim3(grid_for(actP)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), counters, curP, isa);
+                DBG("k_isa_pool");
+                for (int k = 0; k < 3; ++k) {
+                    const u32 cnt = c->h_counters[curL + k];
+                    if (cnt) hipLaunchKernelGGL(k_isa_segs, dim3(cnt), dim3(256), 0, st, bufs, c->lists[cur][k].as<Desc>(), cnt, counters, isa);
+                }
+                if (u32 cnt = c->h_counters[curL + 3]) hipLaunchKernelGGL(k_isa_segs, dim3(cnt), dim3(256), 0, st, bufs, c->large_round[cur].as<Desc>(), cnt, counters, isa);
+                DBG("isa build");
+                R.mode = MODE_ISA;
+                R.isa32 = isa;
             }
-            hipLaunchKernelGGL(k_isa_init, dim3(std::min<u32>(cdiv(m + z, 256), 65536u)), dim3(256), 0, st, sa_local, counters, c->isa.as<u32>(), (u32)n, (u32)z);
-            DBG("k_isa_init");
-            if (actP) hipLaunchKernelGGL(k_isa_pool, dim3(std::min<u32>(cdiv(actP, 256), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), counters, curP, c->isa.as<u32>());
-            DBG("k_isa_pool");
-            for (int k = 0; k < 3; ++k) {
-                const u32 cnt = c->h_counters[curL + k];
-                if (cnt) hipLaunchKernelGGL(k_isa_segs, dim3(cnt), dim3(256), 0, st, bufs, c->lists[cur][k].as<Desc>(), cnt, counters, c->isa.as<u32>());
-            }
-            if (u32 cnt = c->h_counters[curL + 3]) hipLaunchKernelGGL(k_isa_segs, dim3(cnt), dim3(256), 0, st, bufs, c->large_round[cur].as<Desc>(), cnt, counters, c->isa.as<u32>());
-            DBG("isa build");
-            mode = MODE_ISA;
         }
         // refill keys of all still-tied suffixes
-        if (actP) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
-                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), asigma, cpk, zlow);
-        if (actS) hipLaunchKernelGGL(k_refill, dim3(std::min<u32>(cdiv(actS, 1024), 65536u)), dim3(256), 0, st, bufs.p[sb], counters, curS,
-                                     d_text, c->isa.as<u32>(), (u32)n, depth, mode, c->alpha.as<u8>(), asigma, cpk, zlow);
+        ks.depth = depth;
+        const sa_t* isa_any = nullptr;
+        if constexpr (!W) isa_any = R.isa32;
+        if (actP) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
+                                     d_text, isa_any, n, R.mode, c->alpha.as<u8>(), ks);
+        if (actS) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actS, 1024), 65536u)), dim3(256), 0, st, bufs.p[R.sb], counters, curS,
+                                     d_text, isa_any, n, R.mode, c->alpha.as<u8>(), ks);
         DBG("k_refill");
-        if (mode == MODE_TEXT) depth += cpk; else { depth *= 2; tm.doubling_rounds++; }
+        if (R.mode == MODE_TEXT) depth += ks.cpk; else { depth *= 2; tm.doubling_rounds++; }
         tm.rounds++;
     }
-    if (d_grp_rows && !resume)
-        hipLaunchKernelGGL(k_grp_iota, dim3(std::min<u32>(cdiv(std::max<u64>(slice_rows, 1), 256), 65536u)), dim3(256), 0, st, d_grp_rows, slice_rows, (u32)slice_row_lo);
+    finish_groups();
     HIP_TRY(hipEventRecord(c->ev[5], st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); tm.total_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); tm.hist16_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); tm.scatter0_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); tm.scatter1_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); tm.bucket_sort_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); tm.refine_ms = ms;
+    float ms_ = 0;
+    (void)hipEventElapsedTime(&ms_, c->ev[0], c->ev[5]); tm.total_ms = ms_;
+    (void)hipEventElapsedTime(&ms_, c->ev[0], c->ev[1]); tm.hist16_ms = ms_;
+    (void)hipEventElapsedTime(&ms_, c->ev[1], c->ev[2]); tm.scatter0_ms = ms_;
+    (void)hipEventElapsedTime(&ms_, c->ev[2], c->ev[3]); tm.scatter1_ms = ms_;
+    (void)hipEventElapsedTime(&ms_, c->ev[3], c->ev[4]); tm.bucket_sort_ms = ms_;
+    (void)hipEventElapsedTime(&ms_, c->ev[4], c->ev[5]); tm.refine_ms = ms_;
     return MSUFSORT_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Distributed prefix doubling (see the block comment above k_grp_iota in sa_kernels.hip.h).
+// ------------------------------------------------------------------------------------------------
+struct Digits { u32 npass; u32 shift[2], mask[2]; };
+
+// narrow: the rank is the key.  wide: 24 key bits per pass; ranks up to n need bit_length(n) bits.
+template <bool W>
+Digits plan_digits(u64 n)
+{
+    Digits d{1, {0, 0}, {0xffffffffu, 0}};
+    if (!W) return d;
+    u32 kb = 24;
+    if (const char* e = getenv("MSUFSORT_HIP_DIGIT_BITS")) kb = (u32)std::min(24, std::max(2, atoi(e)));   // test hook: narrower passes
+    u32 B = 0;
+    while (B < 63 && (n >> B) != 0) ++B;
+    if (B <= kb) { d.mask[0] = 0xffffffu; return d; }
+    const u32 S = std::min<u32>(B - kb, 24u);          // (B <= 48 always holds for 40-bit indices)
+    d.npass = 2;
+    d.shift[0] = S; d.mask[0] = 0xffffffu;
+    d.shift[1] = 0; d.mask[1] = (1u << S) - 1u;
+    return d;
+}
+
+// One sort pass of a doubling step over the rows of one slice (stateless: everything is rebuilt from rows + grp).
+// Returns the number of rows that were still tied BEFORE the pass in *tied_in (0: nothing to do).
+template <bool W>
+int double_pass(msufsort_hip_ctx* c, u64 n, typename Wd<W>::sa_t* d_sa_slice, u32* d_grp_slice, u64 rows,
+                const typename Wd<W>::sa_t* d_isa, u64 h, u32 dig_shift, u32 dig_mask, int verbose, u64* tied_in)
+{
+    hipStream_t st = c->stream;
+    if (rows > 0xfffffff0ull) { set_error("slice of %llu rows: too large for one shard", (unsigned long long)rows); return MSUFSORT_HIP_ERR_TOO_LARGE; }
+    const u32 m = (u32)rows;
+    *tied_in = 0;
+    if (m < 2) return MSUFSORT_HIP_OK;
+    TRY(c->set_attrs());
+    TRY(c->ensure_workspace(m));
+    u32* counters = c->counters.as<u32>();
+    HIP_TRY(hipMemsetAsync(counters, 0, C_NCOUNTERS * 4, st));
+    const u32 hv[2] = {m, 0u};
+    HIP_TRY(hipMemcpyAsync(counters + C_MS, hv, 8, hipMemcpyHostToDevice, st));      // C_MS, C_RANK0
+    Rounds<W> R;
+    R.c = c; R.st = st; R.counters = counters;
+    R.bufs = RecBufs{{c->rec[0].as<u64>(), c->rec[1].as<u64>(), c->rec[2].as<u64>()}};
+    R.sa_local = d_sa_slice; R.grp_out = d_grp_slice;
+    R.cur = 0; R.sb = 2; R.nb = 0; R.mode = MODE_DEFER; R.round = 1; R.discard = 1; R.verbose = verbose;
+    R.force_retry = false;
+    hipLaunchKernelGGL(k_import_groups<W>, dim3(cdiv(m, 256)), dim3(256), 0, st, d_sa_slice, d_grp_slice, m, R.sb,
+                       c->pool_rec[0].as<u64>(), c->pool_hdr[0].as<u64>(), (u32)C_POOL0, R.cap32(),
+                       R.make_lists(0), c->large_round[0].as<Desc>(), c->large_cap, (u32)(C_LIST0 + 3), (u32)C_LTILES0, counters);
+    DBG("k_import_groups");
+    TRY(c->read_counters());
+    const u64 actP = c->h_counters[C_POOL0];
+    const u64 nseg = (u64)c->h_counters[C_LIST0] + c->h_counters[C_LIST0 + 1] + c->h_counters[C_LIST0 + 2] + c->h_counters[C_LIST0 + 3];
+    *tied_in = actP + nseg;            // (a count of pool rows + segments: only its being zero matters)
+    if (actP + nseg == 0) return MSUFSORT_HIP_OK;
+    KeySpec ks{};
+    ks.depth = h; ks.sigma = 256; ks.cpk = W ? 3u : 4u; ks.zlow = 0; ks.dig_shift = dig_shift; ks.dig_mask = dig_mask;
+    if (actP) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[0].as<u64>(), counters, (u32)C_POOL0,
+                                 (const u8*)nullptr, d_isa, n, (u32)MODE_DEFER, (const u8*)nullptr, ks);
+    if (nseg) hipLaunchKernelGGL(k_refill_rows<W>, dim3(std::min<u32>(cdiv(m, 1024), 65536u)), dim3(256), 0, st, d_sa_slice, d_grp_slice, m, R.bufs.p[R.sb], d_isa, n, ks);
+    DBG("doubling refill");
+    TRY(R.levels_and_sorts());
+    if (verbose)
+        fprintf(stderr, "[msufsort_hip] doubling pass h=%llu digit>>%u: rows %u, sorted A=%u B=%u C=%u L=%u tiny=%u\n", (unsigned long long)h, dig_shift, m,
+                R.nA, R.nB, R.nC, c->h_counters[C_LIST0 + 3], R.nP);
+    return MSUFSORT_HIP_OK;
+}
+
+// One doubling step for one slice: remember the groups (grp_prev), then one or two sort passes.
+template <bool W>
+int double_sort(msufsort_hip_ctx* c, u64 n, typename Wd<W>::sa_t* d_sa_slice, u32* d_grp_slice, u32* d_grp_prev_slice, u64 rows,
+                const typename Wd<W>::sa_t* d_isa, u64 h, int verbose, u64* tied_in)
+{
+    const Digits dg = plan_digits<W>(n);
+    HIP_TRY(hipMemcpyAsync(d_grp_prev_slice, d_grp_slice, (size_t)rows * 4, hipMemcpyDeviceToDevice, c->stream));
+    u64 t0 = 0;
+    for (u32 p = 0; p < dg.npass; ++p) {
+        u64 t = 0;
+        TRY((double_pass<W>(c, n, d_sa_slice, d_grp_slice, rows, d_isa, h, dg.shift[p], dg.mask[p], verbose, &t)));
+        if (p == 0) t0 = t;
+        if (t == 0) break;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    *tied_in = t0;
+    return MSUFSORT_HIP_OK;
+}
+
+// rank updates of the rows [r0, r1) of a slice -> d_out (capacity `cap` updates); *count = updates, *tied = rows still tied
+template <bool W>
+int emit_updates(msufsort_hip_ctx* c, const typename Wd<W>::sa_t* d_sa_slice, const u32* d_grp_slice, const u32* d_grp_prev_slice, u64 rows, u64 slice_lo,
+                 u64 r0, u64 r1, u64* d_out, u64 cap, u64* count, u64* tied)
+{
+    TRY(c->upd_cnt.ensure(16));
+    HIP_TRY(hipMemsetAsync(c->upd_cnt.p, 0, 16, c->stream));
+    if (r1 > r0)
+        hipLaunchKernelGGL(k_emit_updates<W>, dim3(grid_for(r1 - r0, 256, 16384u)), dim3(256), 0, c->stream, d_sa_slice, d_grp_slice, d_grp_prev_slice, rows, r0, r1, slice_lo,
+                           d_out, cap, c->upd_cnt.as<unsigned long long>());
+    HIP_TRY(hipMemcpyAsync(c->h_upd, c->upd_cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    if (c->h_upd[0] > cap) { set_error("rank-update window overflow (%llu > %llu)", c->h_upd[0], (unsigned long long)cap); return MSUFSORT_HIP_ERR_INTERNAL; }
+    *count = c->h_upd[0]; *tied = c->h_upd[1];
+    return MSUFSORT_HIP_OK;
+}
+
+template <bool W>
+int apply_updates(msufsort_hip_ctx* c, const u64* d_upd, u64 count, typename Wd<W>::sa_t* d_isa)
+{
+    if (count) hipLaunchKernelGGL(k_apply_updates<W>, dim3(grid_for(count, 256, 65536u)), dim3(256), 0, c->stream, d_upd, count, d_isa);
+    HIP_TRY(hipGetLastError());
+    return MSUFSORT_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Single-process build with G logical shards on one GPU: what the int64 entry points run for inputs beyond 2^31 - 2
+// bytes, what `n_shards` > 1 asks of msufsort_hip_make_sa_*_dev, and what the C-ABI multi-GPU entry runs per device.
+// The shards take turns on the one workspace; every slice is written straight into the caller's array.
+// ------------------------------------------------------------------------------------------------
+template <bool W>
+int build_logical(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa, int G, const msufsort_hip_opts* opts_in)
+{
+    typedef typename Wd<W>::sa_t sa_t;
+    hipStream_t st = c->stream;
+    const int verbose = opts_in ? opts_in->verbose : 0;
+    u64 z = 0;
+    TRY(trailing_zeros(c, d_text, n, &z));
+    ShardCuts sc;
+    TRY(plan_shards<W>(c, d_text, n, z, G, sc));
+    TRY(c->grp_full.ensure((size_t)(n + 1) * 4));
+    u32* grp = c->grp_full.as<u32>();
+    msufsort_hip_opts o{};
+    if (opts_in) o = *opts_in;
+    o.n_shards = std::max(G, 2);          // (forces the "publish groups" exit; a single wide shard takes it anyway)
+    if (o.text_rounds <= 0) o.text_rounds = W ? 3 : 8;
+    bool any = false;
+    u64 depth = 0;
+    msufsort_hip_timings acc{};
+    auto t_start = std::chrono::steady_clock::now();
+    for (int g = 0; g < G; ++g) {
+        const u64 lo = sc.rows[g], hi = sc.rows[g + 1];
+        if (hi == lo) continue;
+        o.shard = g;
+        const int r = build_sa<W>(c, d_text, n, d_sa + lo, lo, z, sc.cuts[g], sc.cuts[g + 1], sc.rank0[g], g == 0, &o, n - z > 0, grp + lo, hi - lo);
+        if (r < 0) return r;
+        acc.hist16_ms += c->tm.hist16_ms; acc.scatter0_ms += c->tm.scatter0_ms; acc.scatter1_ms += c->tm.scatter1_ms;
+        acc.bucket_sort_ms += c->tm.bucket_sort_ms; acc.refine_ms += c->tm.refine_ms; acc.rounds = std::max(acc.rounds, c->tm.rounds);
+        acc.unresolved_after_round0 += c->tm.unresolved_after_round0;
+        if (r == MSUFSORT_HIP_UNRESOLVED) {
+            const u64 d = (u64)c->tm.reserved[0];
+            if (any && d != depth) { set_error("shards stopped at different depths (%llu, %llu)", (unsigned long long)depth, (unsigned long long)d); return MSUFSORT_HIP_ERR_INTERNAL; }
+            any = true; depth = d;
+        }
+    }
+    int steps = 0;
+    double dbl_ms = 0;
+    if (any) {
+        auto t_d = std::chrono::steady_clock::now();
+        TRY(c->grp_prev.ensure((size_t)(n + 1) * 4));
+        TRY(c->isa.ensure((size_t)(n + 2) * sizeof(sa_t)));
+        sa_t* isa = c->isa.as<sa_t>();
+        u32* grp_prev = c->grp_prev.as<u32>();
+        for (int g = 0; g < G; ++g) {
+            const u64 lo = sc.rows[g], hi = sc.rows[g + 1];
+            if (hi > lo) hipLaunchKernelGGL(k_isa_from_slice<W>, dim3(grid_for(hi - lo)), dim3(256), 0, st, d_sa + lo, grp + lo, hi - lo, lo, isa);
+        }
+        const u64 win = std::min<u64>(n + 1, 1ull << 27);          // rows per rank-update window
+        TRY(c->upd.ensure((size_t)win * (W ? 16 : 8)));
+        std::vector<char> live(G, 1);
+        for (u64 h = depth;; h *= 2, ++steps) {
+            u64 tied_total = 0;
+            for (int g = 0; g < G; ++g) {
+                const u64 lo = sc.rows[g], hi = sc.rows[g + 1];
+                if (hi == lo || !live[g]) continue;
+                u64 t = 0;
+                TRY((double_sort<W>(c, n, d_sa + lo, grp + lo, grp_prev + lo, hi - lo, isa, h, verbose, &t)));
+                if (t == 0) live[g] = 0;           // (grp_prev == grp for this slice: no updates either)
+            }
+            // the ranks are read-only while ANY shard still sorts with them: the updates of all shards are applied afterwards
+            for (int g = 0; g < G; ++g) {
+                const u64 lo = sc.rows[g], hi = sc.rows[g + 1];
+                if (hi == lo || !live[g]) continue;
+                for (u64 r0 = 0; r0 < hi - lo; r0 += win) {
+                    const u64 r1 = std::min(hi - lo, r0 + win);
+                    u64 cnt = 0, tied = 0;
+                    TRY((emit_updates<W>(c, d_sa + lo, grp + lo, grp_prev + lo, hi - lo, lo, r0, r1, c->upd.as<u64>(), win, &cnt, &tied)));
+                    TRY((apply_updates<W>(c, c->upd.as<u64>(), cnt, isa)));
+                    tied_total += tied;
+                }
+            }
+            if (verbose) fprintf(stderr, "[msufsort_hip] doubling step %d (h = %llu): %llu rows still tied\n", steps, (unsigned long long)h, (unsigned long long)tied_total);
+            if (tied_total == 0) { ++steps; break; }
+            if (h > 2 * n + 2) { set_error("prefix doubling did not converge"); return MSUFSORT_HIP_ERR_INTERNAL; }
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        dbl_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d).count();
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    acc.n = (int64_t)n; acc.m = (int64_t)(n - z);
+    acc.doubling_rounds = steps;
+    acc.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    acc.reserved[0] = (int64_t)depth;
+    acc.reserved[1] = G;
+    acc.other_ms = dbl_ms;              // wall time of the distributed doubling phase
+    c->tm = acc;
+    return MSUFSORT_HIP_OK;
+}
+
+// number of logical shards a single-process build needs so that one shard's workspace (~70 B per suffix) fits
+int auto_shards(u64 n, bool wide)
+{
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
+    const u64 fixed = (n + 1) * (wide ? 8 + 4 + 4 : 4 + 4 + 4);          // rank array + grp + grp_prev
+    const u64 avail = free_b > fixed + ((u64)8 << 30) ? free_b - fixed - ((u64)8 << 30) : ((u64)4 << 30);
+    u64 per = std::min<u64>(avail / 80, wide ? (1ull << 30) : (1ull << 31));
+    per = std::max<u64>(per, 1u << 20);
+    return (int)std::max<u64>(1, (n + per - 1) / per);
 }
 
 int zero_pad(msufsort_hip_ctx* c, u8* d_text, u64 n)
@@ -712,7 +1014,14 @@ int zero_pad(msufsort_hip_ctx* c, u8* d_text, u64 n)
 int check_n(int64_t n)
 {
     if (n < 0) { set_error("negative length"); return MSUFSORT_HIP_ERR_BAD_ARG; }
-    if (n > 0x7ffffffeLL) { set_error("n = %lld exceeds the int32 limit 2^31-2", (long long)n); return MSUFSORT_HIP_ERR_TOO_LARGE; }
+    if (n > 0x7ffffffeLL) { set_error("n = %lld exceeds the int32 limit 2^31-2 (use the int64 entry points)", (long long)n); return MSUFSORT_HIP_ERR_TOO_LARGE; }
+    return MSUFSORT_HIP_OK;
+}
+
+int check_n64(int64_t n)
+{
+    if (n < 0) { set_error("negative length"); return MSUFSORT_HIP_ERR_BAD_ARG; }
+    if (n > (int64_t)((1ull << 40) - 2)) { set_error("n = %lld exceeds the 40-bit index limit", (long long)n); return MSUFSORT_HIP_ERR_TOO_LARGE; }
     return MSUFSORT_HIP_OK;
 }
 
@@ -740,7 +1049,7 @@ const char* msufsort_hip_strerror(int status)
         case MSUFSORT_HIP_OK: return "ok";
         case MSUFSORT_HIP_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
         case MSUFSORT_HIP_ERR_BAD_ARG: return "bad argument";
-        case MSUFSORT_HIP_ERR_TOO_LARGE: return "input too large for the int32 interface";
+        case MSUFSORT_HIP_ERR_TOO_LARGE: return "input too large for this interface";
         case MSUFSORT_HIP_ERR_HIP: return "HIP runtime error";
         case MSUFSORT_HIP_ERR_NOMEM: return "out of device memory";
         case MSUFSORT_HIP_ERR_INTERNAL: return "internal error";
@@ -764,8 +1073,9 @@ int msufsort_hip_ctx_create(msufsort_hip_ctx** out, int32_t device, int64_t max_
     if (e != hipSuccess) { delete c; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return MSUFSORT_HIP_ERR_HIP; }
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     (void)hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), C_NCOUNTERS * 4, hipHostMallocDefault);
-    (void)hipHostMalloc(reinterpret_cast<void**>(&c->h_bstart), 65537 * 4, hipHostMallocDefault);
-    if (!c->h_counters || !c->h_bstart) { msufsort_hip_ctx_destroy(c); set_error("hipHostMalloc failed"); return MSUFSORT_HIP_ERR_NOMEM; }
+    (void)hipHostMalloc(reinterpret_cast<void**>(&c->h_hist), 65536 * 8, hipHostMallocDefault);
+    (void)hipHostMalloc(reinterpret_cast<void**>(&c->h_upd), 16, hipHostMallocDefault);
+    if (!c->h_counters || !c->h_hist || !c->h_upd) { msufsort_hip_ctx_destroy(c); set_error("hipHostMalloc failed"); return MSUFSORT_HIP_ERR_NOMEM; }
     if (max_n > 0) {
         int r = c->ensure_workspace((u64)max_n);
         if (r) { msufsort_hip_ctx_destroy(c); return r; }
@@ -782,7 +1092,8 @@ void msufsort_hip_ctx_destroy(msufsort_hip_ctx* c)
     c->release_all();
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
-    if (c->h_bstart) (void)hipHostFree(c->h_bstart);
+    if (c->h_hist) (void)hipHostFree(c->h_hist);
+    if (c->h_upd) (void)hipHostFree(c->h_upd);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -793,6 +1104,15 @@ int msufsort_hip_ctx_sync(msufsort_hip_ctx* c)
 {
     if (!c) return MSUFSORT_HIP_ERR_BAD_ARG;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_ctx_trim(msufsort_hip_ctx* c)
+{
+    if (!c) return MSUFSORT_HIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->release_all();
     return MSUFSORT_HIP_OK;
 }
 
@@ -810,93 +1130,157 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     HIP_TRY(hipSetDevice(c->device));
     if (n == 0) { HIP_TRY(hipMemsetAsync(d_sa_out, 0, 4, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); return MSUFSORT_HIP_OK; }
     TRY(zero_pad(c, d_text, (u64)n));
+    if (opts && opts->n_shards > 1 && opts->shard < 0)      // shard = -1: all n_shards logical shards, one after the other, on this GPU
+        return build_logical<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), opts->n_shards, opts);
     u64 z = 0;
     TRY(trailing_zeros(c, d_text, (u64)n, &z));
     msufsort_hip_opts o{};
     if (opts) o = *opts;
     o.n_shards = 1; o.shard = 0;
-    return build_sa(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 65536, true, &o, false);
+    return build_sa<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 65536, z, true, &o, false);
 }
 
 int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t n_shards, int64_t* bounds)
 {
     if (!c || !bounds || n_shards < 1 || (n > 0 && !d_text)) return MSUFSORT_HIP_ERR_BAD_ARG;
-    TRY(check_n(n));
+    TRY(check_n64(n));
     HIP_TRY(hipSetDevice(c->device));
     if (n == 0) { for (int g = 0; g <= n_shards; ++g) bounds[g] = g ? 1 : 0; return MSUFSORT_HIP_OK; }
     TRY(zero_pad(c, d_text, (u64)n));
     u64 z = 0;
     TRY(trailing_zeros(c, d_text, (u64)n, &z));
-    TRY(c->ensure_workspace((u64)n - z));
-    std::vector<u32> cuts; std::vector<u64> rows;
-    TRY(plan_shards(c, d_text, (u64)n, z, (u64)n - z, n_shards, cuts, rows));
-    for (int g = 0; g <= n_shards; ++g) bounds[g] = (int64_t)rows[g];
+    ShardCuts sc;
+    if (n > 0x7ffffffeLL) TRY((plan_shards<true>(c, d_text, (u64)n, z, n_shards, sc)));
+    else TRY((plan_shards<false>(c, d_text, (u64)n, z, n_shards, sc)));
+    for (int g = 0; g <= n_shards; ++g) bounds[g] = (int64_t)sc.rows[g];
     return MSUFSORT_HIP_OK;
 }
 
-static int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_slice_out, int32_t* d_grp_slice_out,
-                              int64_t slice_capacity, int64_t* slice_lo, int64_t* slice_hi, const msufsort_hip_opts* opts);
+}  // extern "C"
 
-int msufsort_hip_make_sa_shard_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_slice_out, int64_t slice_capacity,
-                                   int64_t* slice_lo, int64_t* slice_hi, const msufsort_hip_opts* opts)
-{
-    return make_sa_shard_impl(c, d_text, n, d_slice_out, nullptr, slice_capacity, slice_lo, slice_hi, opts);
-}
-
-int msufsort_hip_make_sa_shard_groups_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_slice_out, int32_t* d_grp_slice_out,
-                                          int64_t slice_capacity, int64_t* slice_lo, int64_t* slice_hi, int64_t* depth_out,
-                                          const msufsort_hip_opts* opts)
-{
-    if (!d_grp_slice_out) return MSUFSORT_HIP_ERR_BAD_ARG;
-    const int r = make_sa_shard_impl(c, d_text, n, d_slice_out, d_grp_slice_out, slice_capacity, slice_lo, slice_hi, opts);
-    if (depth_out) *depth_out = (r == MSUFSORT_HIP_UNRESOLVED) ? c->tm.reserved[0] : 0;
-    return r;
-}
-
-int msufsort_hip_finish_sa_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_sa_full, int32_t* d_grp_full, int64_t depth,
-                               const msufsort_hip_opts* opts)
-{
-    if (!c || !d_text || !d_sa_full || !d_grp_full || n <= 0 || depth <= 0) return MSUFSORT_HIP_ERR_BAD_ARG;
-    TRY(check_n(n));
-    HIP_TRY(hipSetDevice(c->device));
-    TRY(zero_pad(c, d_text, (u64)n));
-    u64 z = 0;
-    TRY(trailing_zeros(c, d_text, (u64)n, &z));
-    msufsort_hip_opts o{};
-    if (opts) o = *opts;
-    o.n_shards = 1; o.shard = 0;
-    return build_sa(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_full), 0, z, 0, 65536, false, &o, true,
-                    reinterpret_cast<u32*>(d_grp_full), (u64)depth, (u64)n + 1);
-}
-
-static int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_slice_out, int32_t* d_grp_slice_out,
-                              int64_t slice_capacity, int64_t* slice_lo, int64_t* slice_hi, const msufsort_hip_opts* opts)
+namespace {
+template <bool W>
+int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, typename Wd<W>::sa_t* d_slice_out, uint32_t* d_grp_slice_out,
+                       int64_t slice_capacity, int64_t* slice_lo, int64_t* slice_hi, const msufsort_hip_opts* opts)
 {
     if (!c || !d_slice_out || !opts || opts->n_shards < 1 || opts->shard < 0 || opts->shard >= opts->n_shards || (n > 0 && !d_text)) return MSUFSORT_HIP_ERR_BAD_ARG;
-    TRY(check_n(n));
+    TRY(W ? check_n64(n) : check_n(n));
     HIP_TRY(hipSetDevice(c->device));
     if (n == 0) {
         if (slice_lo) *slice_lo = 0;
         if (slice_hi) *slice_hi = opts->shard == 0 ? 1 : 0;
-        if (opts->shard == 0) { HIP_TRY(hipMemsetAsync(d_slice_out, 0, 4, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+        if (opts->shard == 0) {
+            HIP_TRY(hipMemsetAsync(d_slice_out, 0, sizeof(typename Wd<W>::sa_t), c->stream));
+            if (d_grp_slice_out) HIP_TRY(hipMemsetAsync(d_grp_slice_out, 0, 4, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
         return MSUFSORT_HIP_OK;
     }
     TRY(zero_pad(c, d_text, (u64)n));
     u64 z = 0;
     TRY(trailing_zeros(c, d_text, (u64)n, &z));
     const u64 m = (u64)n - z;
-    TRY(c->ensure_workspace(m));
-    std::vector<u32> cuts; std::vector<u64> rows;
-    TRY(plan_shards(c, d_text, (u64)n, z, m, opts->n_shards, cuts, rows));
+    ShardCuts sc;
+    TRY(plan_shards<W>(c, d_text, (u64)n, z, opts->n_shards, sc));
     const int g = opts->shard;
-    const u64 lo = rows[g], hi = rows[g + 1];
+    const u64 lo = sc.rows[g], hi = sc.rows[g + 1];
     if (slice_lo) *slice_lo = (int64_t)lo;
     if (slice_hi) *slice_hi = (int64_t)hi;
     if ((int64_t)(hi - lo) > slice_capacity) { set_error("slice needs %llu rows, capacity %lld", (unsigned long long)(hi - lo), (long long)slice_capacity); return MSUFSORT_HIP_ERR_BAD_ARG; }
     if (hi == lo) return MSUFSORT_HIP_OK;
-    const bool hist_done = (m > 0 && opts->n_shards > 1);
-    return build_sa(c, d_text, (u64)n, reinterpret_cast<u32*>(d_slice_out), lo, z, cuts[g], cuts[g + 1], g == 0, opts, hist_done,
-                    reinterpret_cast<u32*>(d_grp_slice_out), 0, hi - lo);
+    return build_sa<W>(c, d_text, (u64)n, d_slice_out, lo, z, sc.cuts[g], sc.cuts[g + 1], sc.rank0[g], g == 0, opts, m > 0, d_grp_slice_out, hi - lo);
+}
+
+__global__ __launch_bounds__(256) void k_widen(const int32_t* __restrict__ in, u64 rows, int64_t* __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < rows; i += (u64)gridDim.x * 256u) out[i] = (int64_t)in[i];
+}
+}  // namespace
+
+extern "C" {
+
+int msufsort_hip_make_sa_shard_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_slice_out, int64_t slice_capacity,
+                                   int64_t* slice_lo, int64_t* slice_hi, const msufsort_hip_opts* opts)
+{
+    return make_sa_shard_impl<false>(c, d_text, n, reinterpret_cast<u32*>(d_slice_out), nullptr, slice_capacity, slice_lo, slice_hi, opts);
+}
+
+int msufsort_hip_make_sa_shard_groups_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_slice_out, uint32_t* d_grp_slice_out,
+                                          int64_t slice_capacity, int64_t* slice_lo, int64_t* slice_hi, int64_t* depth_out,
+                                          const msufsort_hip_opts* opts)
+{
+    if (!d_grp_slice_out) return MSUFSORT_HIP_ERR_BAD_ARG;
+    const int r = make_sa_shard_impl<false>(c, d_text, n, reinterpret_cast<u32*>(d_slice_out), d_grp_slice_out, slice_capacity, slice_lo, slice_hi, opts);
+    if (depth_out) *depth_out = (r == MSUFSORT_HIP_UNRESOLVED) ? c->tm.reserved[0] : 0;
+    return r;
+}
+
+int msufsort_hip_make_sa_shard_groups_i64_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int64_t* d_slice_out, uint32_t* d_grp_slice_out,
+                                              int64_t slice_capacity, int64_t* slice_lo, int64_t* slice_hi, int64_t* depth_out,
+                                              const msufsort_hip_opts* opts)
+{
+    if (!d_grp_slice_out) return MSUFSORT_HIP_ERR_BAD_ARG;
+    const int r = make_sa_shard_impl<true>(c, d_text, n, reinterpret_cast<u64*>(d_slice_out), d_grp_slice_out, slice_capacity, slice_lo, slice_hi, opts);
+    if (depth_out) *depth_out = (r == MSUFSORT_HIP_UNRESOLVED) ? c->tm.reserved[0] : 0;
+    return r;
+}
+
+// ---- distributed prefix doubling: the per-shard pieces (msufsort_amd/dist.py and the single-process drivers use them) ----
+int msufsort_hip_isa_from_slice_dev(msufsort_hip_ctx* c, const void* d_sa_slice, const uint32_t* d_grp_slice, int64_t lo, int64_t hi,
+                                    void* d_isa, int32_t index_bytes)
+{
+    if (!c || !d_sa_slice || !d_grp_slice || !d_isa || lo < 0 || hi < lo || (index_bytes != 4 && index_bytes != 8)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (hi > lo) {
+        if (index_bytes == 8) hipLaunchKernelGGL(k_isa_from_slice<true>, dim3(grid_for((u64)(hi - lo))), dim3(256), 0, c->stream, static_cast<const u64*>(d_sa_slice), d_grp_slice, (u64)(hi - lo), (u64)lo, static_cast<u64*>(d_isa));
+        else hipLaunchKernelGGL(k_isa_from_slice<false>, dim3(grid_for((u64)(hi - lo))), dim3(256), 0, c->stream, static_cast<const u32*>(d_sa_slice), d_grp_slice, (u64)(hi - lo), (u64)lo, static_cast<u32*>(d_isa));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_double_sort_dev(msufsort_hip_ctx* c, int64_t n, void* d_sa_slice, uint32_t* d_grp_slice, uint32_t* d_grp_prev_slice,
+                                 int64_t lo, int64_t hi, const void* d_isa, int64_t h, int32_t index_bytes, const msufsort_hip_opts* opts,
+                                 int64_t* tied_before)
+{
+    if (!c || !d_sa_slice || !d_grp_slice || !d_grp_prev_slice || !d_isa || n <= 0 || lo < 0 || hi < lo || h <= 0 || (index_bytes != 4 && index_bytes != 8)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    u64 t = 0;
+    const int verbose = opts ? opts->verbose : 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (hi > lo) {
+        if (index_bytes == 8) TRY((double_sort<true>(c, (u64)n, static_cast<u64*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), static_cast<const u64*>(d_isa), (u64)h, verbose, &t)));
+        else TRY((double_sort<false>(c, (u64)n, static_cast<u32*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), static_cast<const u32*>(d_isa), (u64)h, verbose, &t)));
+    }
+    c->tm.refine_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();     // this shard's sort work of the step
+    if (tied_before) *tied_before = (int64_t)t;
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_emit_updates_dev(msufsort_hip_ctx* c, const void* d_sa_slice, const uint32_t* d_grp_slice, const uint32_t* d_grp_prev_slice,
+                                  int64_t lo, int64_t hi, int64_t r0, int64_t r1, void* d_updates, int64_t capacity, int32_t index_bytes,
+                                  int64_t* count, int64_t* tied_rows)
+{
+    if (!c || !d_sa_slice || !d_grp_slice || !d_grp_prev_slice || !d_updates || lo < 0 || hi < lo || r0 < 0 || r1 < r0 || r1 > hi - lo || capacity < 0 ||
+        (index_bytes != 4 && index_bytes != 8)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    u64 cnt = 0, tied = 0;
+    if (index_bytes == 8) TRY((emit_updates<true>(c, static_cast<const u64*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), (u64)lo, (u64)r0, (u64)r1, static_cast<u64*>(d_updates), (u64)capacity, &cnt, &tied)));
+    else TRY((emit_updates<false>(c, static_cast<const u32*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), (u64)lo, (u64)r0, (u64)r1, static_cast<u64*>(d_updates), (u64)capacity, &cnt, &tied)));
+    if (count) *count = (int64_t)cnt;
+    if (tied_rows) *tied_rows = (int64_t)tied;
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_apply_updates_dev(msufsort_hip_ctx* c, const void* d_updates, int64_t count, void* d_isa, int32_t index_bytes)
+{
+    if (!c || count < 0 || (count > 0 && (!d_updates || !d_isa)) || (index_bytes != 4 && index_bytes != 8)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (index_bytes == 8) TRY((apply_updates<true>(c, static_cast<const u64*>(d_updates), (u64)count, static_cast<u64*>(d_isa))));
+    else TRY((apply_updates<false>(c, static_cast<const u64*>(d_updates), (u64)count, static_cast<u32*>(d_isa))));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MSUFSORT_HIP_OK;
 }
 
 int msufsort_hip_make_sa_i32_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64_t n, int32_t* sa_out, const msufsort_hip_opts* opts)
@@ -924,31 +1308,33 @@ int msufsort_hip_make_sa_i32(const uint8_t* text, int64_t n, int32_t* sa_out, co
     return msufsort_hip_make_sa_i32_ctx(t.c, text, n, sa_out, opts);
 }
 
-// ---- 64-bit output: the int32 rows, widened on the device ----
-namespace {
-__global__ __launch_bounds__(256) void k_widen(const int32_t* __restrict__ in, u64 rows, int64_t* __restrict__ out)
-{
-    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < rows; i += (u64)gridDim.x * 256u) out[i] = (int64_t)in[i];
-}
-}
-
+// ---- 64-bit output.  n <= 2^31 - 2: the narrow build, widened on the device (unless opts->force_wide).  Larger inputs
+// (and force_wide): wide records (40-bit indices), logical shards that take turns on this GPU, distributed doubling. ----
 int msufsort_hip_make_sa_i64_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int64_t* d_sa_out, const msufsort_hip_opts* opts)
 {
     if (!c || !d_sa_out || n < 0 || (n > 0 && !d_text)) return MSUFSORT_HIP_ERR_BAD_ARG;
-    TRY(check_n(n));
+    TRY(check_n64(n));
     HIP_TRY(hipSetDevice(c->device));
-    TRY(c->sa_own.ensure(((size_t)n + 1) * 4));
-    TRY(msufsort_hip_make_sa_i32_dev(c, d_text, n, c->sa_own.as<int32_t>(), opts));
-    hipLaunchKernelGGL(k_widen, dim3(std::min<u32>(cdiv((u64)n + 1, 256), 1u << 20)), dim3(256), 0, c->stream, c->sa_own.as<int32_t>(), (u64)n + 1, d_sa_out);
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipGetLastError());
-    return MSUFSORT_HIP_OK;
+    if (n == 0) { HIP_TRY(hipMemsetAsync(d_sa_out, 0, 8, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); return MSUFSORT_HIP_OK; }
+    const bool wide = n > 0x7ffffffeLL || (opts && opts->force_wide);
+    if (!wide) {
+        TRY(c->sa_own.ensure(((size_t)n + 1) * 4));
+        TRY(msufsort_hip_make_sa_i32_dev(c, d_text, n, c->sa_own.as<int32_t>(), opts));
+        hipLaunchKernelGGL(k_widen, dim3(std::min<u32>(cdiv((u64)n + 1, 256), 1u << 20)), dim3(256), 0, c->stream, c->sa_own.as<int32_t>(), (u64)n + 1, d_sa_out);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipGetLastError());
+        return MSUFSORT_HIP_OK;
+    }
+    TRY(zero_pad(c, d_text, (u64)n));
+    int G = auto_shards((u64)n, true);
+    if (opts && opts->n_shards > G) G = opts->n_shards;
+    return build_logical<true>(c, d_text, (u64)n, reinterpret_cast<u64*>(d_sa_out), G, opts);
 }
 
 int msufsort_hip_make_sa_i64_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64_t n, int64_t* sa_out, const msufsort_hip_opts* opts)
 {
     if (!c || !sa_out || (n > 0 && !text)) return MSUFSORT_HIP_ERR_BAD_ARG;
-    TRY(check_n(n));
+    TRY(check_n64(n));
     if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
     HIP_TRY(hipSetDevice(c->device));
     TRY(c->text_own.ensure((size_t)n + MSUFSORT_HIP_TEXT_PAD));
@@ -963,30 +1349,20 @@ int msufsort_hip_make_sa_i64_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64
 int msufsort_hip_make_sa_i64(const uint8_t* text, int64_t n, int64_t* sa_out, const msufsort_hip_opts* opts)
 {
     if (!sa_out || (n > 0 && !text)) return MSUFSORT_HIP_ERR_BAD_ARG;
-    TRY(check_n(n));
+    TRY(check_n64(n));
     if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
     TmpCtx t;
     TRY(msufsort_hip_ctx_create(&t.c, opts ? opts->device : 0, 0));
     return msufsort_hip_make_sa_i64_ctx(t.c, text, n, sa_out, opts);
 }
 
-// Host-only: split the 16-bit key space into n_shards count-balanced contiguous ranges (SURVEY 8(e)).
-// bstart[65537] = exclusive prefix of the 16-bit histogram over the m = n - z radix-sorted suffixes.
-// cuts[n_shards+1] = first key of every shard; rows[n_shards+1] = first SA row of every shard
-// (row 0 = the empty suffix; rows 1..z = the trailing-zero-run suffixes, both owned by shard 0).
-int msufsort_hip_plan_cuts(const uint32_t* bstart, int64_t n, int64_t z, int32_t n_shards, uint32_t* cuts, int64_t* rows)
+// Host-only: balanced key-range cuts from the exclusive prefix bstart[65537] of the 16-bit histogram (see plan_cuts64).
+int msufsort_hip_plan_cuts(const uint64_t* bstart, int64_t n, int64_t z, int32_t n_shards, uint32_t* cuts, int64_t* rows)
 {
     if (!bstart || !cuts || !rows || n_shards < 1 || n < 0 || z < 0 || z > n) return MSUFSORT_HIP_ERR_BAD_ARG;
-    const u64 m = (u64)(n - z);
-    cuts[0] = 0; rows[0] = 0;
-    cuts[n_shards] = 65536; rows[n_shards] = n + 1;
-    for (int g = 1; g < n_shards; ++g) {
-        const u64 target = m * (u64)g / (u64)n_shards;
-        u32 k = (u32)(std::lower_bound(bstart, bstart + 65536, (u32)target) - bstart);
-        if (k < cuts[g - 1]) k = cuts[g - 1];
-        cuts[g] = k;
-        rows[g] = (int64_t)(1 + (u64)z + bstart[k]);
-    }
+    std::vector<u64> r(n_shards + 1);
+    plan_cuts64(bstart, (u64)n, (u64)z, n_shards, cuts, r.data());
+    for (int g = 0; g <= n_shards; ++g) rows[g] = (int64_t)r[g];
     return MSUFSORT_HIP_OK;
 }
 
@@ -995,10 +1371,8 @@ int msufsort_hip_debug_hist16_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t 
     if (!c || !d_text || !d_hist || n <= 0) return MSUFSORT_HIP_ERR_BAD_ARG;
     TRY(check_n(n));
     HIP_TRY(hipSetDevice(c->device));
-    TRY(c->set_attrs());
     TRY(zero_pad(c, d_text, (u64)n));
-    TRY(c->ensure_workspace((u64)n));
-    TRY(run_hist(c, d_text, (u64)n));
+    TRY(run_hist<false>(c, d_text, (u64)n));
     HIP_TRY(hipMemcpyAsync(d_hist, c->hist.p, 65536 * 4, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MSUFSORT_HIP_OK;

@@ -18,14 +18,42 @@
 //
 // Records are 64-bit: (key32 << 32) | suffix_index.  key32 is a big-endian window of the text
 // (get_value, cpp:129-143) or, in prefix-doubling rounds, the rank of suffix index+h.
+//
+// Index width (template parameter W of the kernels that look inside a record):
+//   narrow (W = false): (key32 << 32) | index32; suffix-array rows and ranks are u32.  Inputs up to 2^31 - 2 bytes
+//                       (the reference's own suffix_index is int32, msufsort.h:47, with two flag bits, h:84-93).
+//   wide   (W = true):  (key24 << 40) | index40; rows and ranks are u64 (int64 output).  The upper word of a record is
+//                       key24 << 8 | index bits 32..39, so everything that treats that word as "the key" still sorts
+//                       correctly (the low byte only orders equal keys arbitrarily) - provided tie tests and LSD passes
+//                       ignore its low KLOW = 8 bits.  Partition levels use key bytes at the same bit positions in both
+//                       layouts (bits 56.., 48.., 40..); the fourth byte (bits 32..39) exists only in narrow records.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef uint8_t u8;
 typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
+
+template <bool W> struct Wd { typedef u32 sa_t; typedef u32 hist_t; };
+template <> struct Wd<true> { typedef u64 sa_t; typedef u64 hist_t; };
+template <bool W> __host__ __device__ constexpr u32 klow() { return W ? 8u : 0u; }
+// full suffix index from the two words a sort kernel carries per record
+template <bool W> __device__ __forceinline__ typename Wd<W>::sa_t full_idx(u32 keyword, u32 lo)
+{
+    if constexpr (W) return ((u64)(keyword & 255u) << 32) | (u64)lo; else return lo;
+}
+template <bool W> __device__ __forceinline__ typename Wd<W>::sa_t rec_idx(u64 r)
+{
+    if constexpr (W) return r & 0xffffffffffull; else return (u32)r;
+}
+// key = left-aligned 32-bit key word (wide: only its top 24 bits are kept)
+template <bool W> __device__ __forceinline__ u64 make_rec(u32 key, typename Wd<W>::sa_t idx)
+{
+    if constexpr (W) return ((u64)(key & 0xffffff00u) << 32) | (u64)idx; else return ((u64)key << 32) | (u64)idx;
+}
 
 struct Desc {            // one segment = run of records that are equal on everything consumed so far
     u32 rec_off;         // first record (in record buffer `buf`)
@@ -94,7 +122,10 @@ enum {
 #define S0_TILE (S0_THREADS * S0_POS)        // text positions per workgroup
 
 #define MODE_TEXT 0
-#define MODE_ISA 1
+#define MODE_ISA 1          // prefix doubling, ranks updated in place by the sorts (narrow single-GPU builds)
+#define MODE_DEFER 2        // prefix doubling of a sharded / wide build: the rank array is read-only during a step; the sorts
+                            // write grp_out[row] = first row of the row's tie group (coalesced, next to the suffix-array
+                            // rows) and the rank updates are derived from it afterwards (k_emit_updates / k_apply_updates)
 
 struct Lists {            // destination lists for segments discovered by a kernel
     Desc* cls[3];         // A, B, C
@@ -111,6 +142,8 @@ struct Emit {             // where still-tied runs go (next round)
     u32 seg_cnt_idx;
     u32 pool_cap, seg_cap;
     u32 pool_chunk, seg_chunk;   // persistent workgroups reserve output room in chunks of this many slots
+    u32 discard;                 // 1: the caller rebuilds next round's state itself (stateless doubling step): emit nothing
+    u32* grp_out;                // MODE_DEFER: tie-group head of every row (same indexing as the suffix-array rows)
     Lists lists;
 };
 
@@ -206,7 +239,7 @@ __device__ __forceinline__ void h16_add(u32* h_lds, u32 lo, u32 hi, int j)
     atomicAdd(&h_lds[k & 0x7fffu], ((k >> 15) & 1u) * 0xffffu + 1u);      // + 1 or + 0x10000
 }
 
-__global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u32 m, u32 chunk_len, u32 nchunks,
+__global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u64 m, u32 chunk_len, u32 nchunks,
                                                  u32* __restrict__ partial)
 {
     extern __shared__ u32 h_lds[];
@@ -301,11 +334,12 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u3
 }
 
 // sums the per-chunk partials (indexed by the memory-order key) and stores them under the big-endian key
-__global__ __launch_bounds__(256) void k_reduce16(const u32* __restrict__ partial, u32 nchunks, u32* __restrict__ hist)
+template <bool W>
+__global__ __launch_bounds__(256) void k_reduce16(const u32* __restrict__ partial, u32 nchunks, typename Wd<W>::hist_t* __restrict__ hist)
 {
     // 256 workgroups (one per CU) x 256 keys; four independent partial sums keep four loads in flight per lane
     const u32 kle = blockIdx.x * 256u + threadIdx.x;           // T[i] | T[i+1] << 8
-    u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    typename Wd<W>::hist_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     u32 c = 0;
     for (; c + 4 <= nchunks; c += 4) {
         s0 += partial[(u64)c * 65536u + kle]; s1 += partial[(u64)(c + 1) * 65536u + kle];
@@ -313,6 +347,15 @@ __global__ __launch_bounds__(256) void k_reduce16(const u32* __restrict__ partia
     }
     for (; c < nchunks; ++c) s0 += partial[(u64)c * 65536u + kle];
     hist[((kle & 255u) << 8) | (kle >> 8)] = s0 + s1 + s2 + s3;
+}
+
+// wide builds: the global counts are 64-bit; a shard works on its own key range, whose counts and offsets fit 32 bits
+__global__ __launch_bounds__(256) void k_hist_clip(const u64* __restrict__ hist64, u32 klo, u32 khi, u32* __restrict__ hist32, u32* __restrict__ counters)
+{
+    const u32 k = blockIdx.x * 256u + threadIdx.x;
+    const u64 v = (k >= klo && k < khi) ? hist64[k] : 0ull;
+    if (v > 0xffffffffull) atomicOr(&counters[C_ERR], 0x100u);
+    hist32[k] = (u32)v;
 }
 
 #define SCAN16_LDS_BYTES ((32768u + 1024u + 32u) * 4u)
@@ -469,7 +512,21 @@ __global__ __launch_bounds__(128) void k_stripes(const u32* __restrict__ sums, u
     if (c < nchunks) cursor0[c * 256u + b] = seg0_base[b] + e;
 }
 
-__global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ text, u32 m, u32 klo, u32 khi, u32 chunk_len,
+// number of dense key symbols of round 0 and where their base-sigma number sits in the key word (host and device agree):
+// narrow: 3 symbols in the 24 bits below the bucket byte; wide: the 16 bits between the bucket byte and the index byte
+// hold 3 symbols when sigma^3 <= 2^16, else 2
+template <bool W> __host__ __device__ inline u32 s0_symbols(u32 sigma) { return (!W || (u64)sigma * sigma * sigma <= 65536ull) ? 3u : 2u; }
+template <bool W> __host__ __device__ inline u32 s0_digit_bits(u32 sigma)      // bits of the largest dense number
+{
+    u64 p = 1;
+    for (u32 k = 0; k < s0_symbols<W>(sigma); ++k) p *= sigma;
+    u32 b = 0;
+    while (b < 32 && ((p - 1) >> b) != 0) ++b;
+    return b;
+}
+
+template <bool W>
+__global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ text, u64 m, u32 klo, u32 khi, u32 chunk_len,
                                                          u32* __restrict__ cursor0, u64* __restrict__ out,
                                                          const u8* __restrict__ code, const u32* __restrict__ counters, u32 allow_pack)
 {
@@ -481,7 +538,8 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
     __shared__ u8 s_code[256];
     const u32 sigma = counters[C_ASIGMA];
     const bool tiny = allow_pack != 0u && sigma >= 2u && sigma <= 84u;        // kernel-uniform
-    const u32 dshift = tiny ? 24u - (32u - (u32)__clz((int)(sigma * sigma * sigma - 1u))) : 0u;
+    const u32 nsym = tiny ? s0_symbols<W>(sigma) : 3u;
+    const u32 dshift = tiny ? 24u - s0_digit_bits<W>(sigma) : 0u;             // (wide: 8 + 16 - bits)
     __shared__ __attribute__((aligned(16))) u64 stage[S0_TILE];
     __shared__ __attribute__((aligned(16))) u8 sbin[S0_TILE];
     __shared__ u32 hist[256], lstart[256], gbase[256];
@@ -525,15 +583,16 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
             if (!tiny) {
 #pragma unroll
                 for (int q = 1; q <= 4; ++q)
-                    key = (key << 8) | ((w[(j + q) >> 2] >> (8 * ((j + q) & 3))) & 255u);
+                    key = (key << 8) | ((w[(j + q) >> 2] >> (8 * ((j + q) & 3))) & 255u);      // (wide: the 4th byte is dropped by make_rec)
             } else {
                 u32 dg = 0;
 #pragma unroll
-                for (int q = 2; q <= 4; ++q) dg = dg * sigma + (u32)s_code[(w[(j + q) >> 2] >> (8 * ((j + q) & 3))) & 255u];
+                for (int q = 2; q <= 4; ++q)
+                    if ((u32)q < 2u + nsym) dg = dg * sigma + (u32)s_code[(w[(j + q) >> 2] >> (8 * ((j + q) & 3))) & 255u];
                 key = (((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u) << 24) | (dg << dshift);
             }
             const u32 slot = lstart[b0] + rank[j];
-            stage[slot] = ((u64)key << 32) | (u64)(u32)(base + j);
+            stage[slot] = make_rec<W>(key, (typename Wd<W>::sa_t)(base + j));
             sbin[slot] = (u8)b0;
         }
     }
@@ -665,10 +724,11 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
 // Route the 256 children of every partitioned segment by size (partition scheduling, cpp:1652-1683,
 // becomes a size-class dispatch): 1 -> final, 2..32 -> tiny pool, 33..CAP_C -> LDS-sort lists,
 // larger -> next partition level.
+template <bool W>
 __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __restrict__ parents, u32 nseg,
                                                   const u32* __restrict__ child_start, const u32* __restrict__ child_cnt,
                                                   const u32* __restrict__ trivial, u32 alt0, u32 alt1, u32 alt2, u32 child_kbits,
-                                                  u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                  typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32* __restrict__ grp_out, u32 mode,
                                                   u64* __restrict__ pool_rec, u64* __restrict__ pool_hdr, u32 pool_cnt_idx, u32 pool_cap,
                                                   Lists lists, Desc* __restrict__ lvl_dst, u32 lvl_cap, u32 lvl_cnt_idx, u32 lvl_tiles_idx,
                                                   u32* __restrict__ counters)
@@ -689,9 +749,10 @@ __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __re
     const u64* src = bufs.p[buf] + start;
     const u32 rank0 = counters[C_RANK0];
     if (cnt == 1) {
-        const u32 idx = (u32)src[0];
+        const auto idx = rec_idx<W>(src[0]);
         sa_out[sa] = idx;
         if (mode == MODE_ISA) isa[idx] = rank0 + sa + 1u;
+        if (mode == MODE_DEFER) grp_out[sa] = sa;
     }
     {   // tiny children: one pool allocation per wave
         const u32 want = (cnt > 1 && cnt <= TINY_MAX) ? cnt : 0u;
@@ -779,9 +840,10 @@ __global__ __launch_bounds__(256) void k_carry_alloc(const Desc* __restrict__ li
     carry_base[s] = b;
 }
 
+template <bool W>
 __global__ __launch_bounds__(P1_THREADS) void k_carry_copy(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                            const u32* __restrict__ tile_start, const u32* __restrict__ carry_base,
-                                                           u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                           typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32* __restrict__ grp_out, u32 mode,
                                                            u64* __restrict__ seg_rec, const u32* __restrict__ counters)
 {
     __shared__ u32 s_seg;
@@ -802,8 +864,9 @@ __global__ __launch_bounds__(P1_THREADS) void k_carry_copy(RecBufs bufs, const D
         if (p < d.len) {
             const u64 r = src[p];
             seg_rec[base + p] = r;
-            sa_out[d.sa_off + p] = (u32)r;
+            sa_out[d.sa_off + p] = rec_idx<W>(r);
             if (mode == MODE_ISA) isa[(u32)r] = rank0 + d.sa_off + 1u;
+            if (mode == MODE_DEFER) grp_out[d.sa_off + p] = d.sa_off;
         }
     }
 }
@@ -815,13 +878,14 @@ __global__ __launch_bounds__(P1_THREADS) void k_carry_copy(RecBufs bufs, const D
 // the end of the text must stay the smallest symbol), code(b) = 1 + number of smaller non-zero byte values that
 // occur in the text.  The byte values that occur are the first bytes of the non-empty 16-bit buckets.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_alphabet(const u32* __restrict__ hist /* 65536, big-endian key */, u8* __restrict__ code /* 256 */,
+template <bool W>
+__global__ __launch_bounds__(256) void k_alphabet(const typename Wd<W>::hist_t* __restrict__ hist /* 65536, big-endian key, WHOLE text */, u8* __restrict__ code /* 256 */,
                                                   u32* __restrict__ counters)
 {
     __shared__ u32 s_in[256], s_out[256];
     const u32 b = threadIdx.x;
     u32 any = 0;
-    for (u32 k = 0; k < 256u; ++k) any |= hist[b * 256u + k];
+    for (u32 k = 0; k < 256u; ++k) any |= hist[b * 256u + k] != 0 ? 1u : 0u;
     s_in[b] = (b != 0 && any != 0) ? 1u : 0u;
     __syncthreads();
     const u32 total = scan256_first_wave(s_in, s_out);
@@ -841,22 +905,45 @@ __global__ __launch_bounds__(256) void k_alphabet(const u32* __restrict__ hist /
 // zero beyond the end - 4 bytes, or (small alphabets) up to 16 symbols of the dense alphabet code read as one number
 // in base sigma; in prefix-doubling rounds key = rank of suffix index + h (0 past n).
 // ------------------------------------------------------------------------------------------------
+// Prefix-doubling keys.  narrow: the rank itself (32 bits).  wide: ranks have up to 40 bits but a record only 24 key bits,
+// so a doubling step sorts in two passes over the same (read-only) rank array - first on digit A = rank >> dig_shift,
+// then, inside the groups that tie on it, on digit B = rank & dig_mask (the passes are ordinary rounds of the engine).
+struct KeySpec {
+    u64 depth;            // text: characters consumed so far; doubling: h
+    u32 sigma, cpk, zlow; // text, dense code: alphabet size, symbols per key, left shift of the base-sigma number
+    u32 dig_shift;        // doubling, wide: key24 = (rank >> dig_shift) & dig_mask
+    u32 dig_mask;
+};
+
+template <bool W>
+__device__ __forceinline__ u32 rank_key(const typename Wd<W>::sa_t* __restrict__ isa, u64 pos, u64 n, const KeySpec& ks)
+{
+    if (pos >= n) return 0u;                   // (the empty suffix has rank value 0 as well)
+    if constexpr (W) return (u32)((isa[pos] >> ks.dig_shift) & ks.dig_mask) << 8;
+    else return isa[pos];
+}
+
+template <bool W>
 __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32* __restrict__ counters, u32 cnt_idx,
-                                                const u8* __restrict__ text, const u32* __restrict__ isa,
-                                                u32 n, u64 depth, u32 mode, const u8* __restrict__ code, u32 sigma, u32 cpk, u32 zlow)
+                                                const u8* __restrict__ text, const typename Wd<W>::sa_t* __restrict__ isa,
+                                                u64 n, u32 mode, const u8* __restrict__ code, KeySpec ks)
 {
     // packed: key = (sum code(c_i) sigma^(cpk-1-i)) << zlow - the symbols read as ONE number in base sigma (denser than
     // bit fields: 13 DNA symbols per key instead of 10), left-aligned so that the top bits stay evenly used
+    typedef typename Wd<W>::sa_t idx_t;
     __shared__ u8 s_code[256];
-    const bool packed = mode == MODE_TEXT && cpk != 4u;
+    const u32 sigma = ks.sigma, cpk = ks.cpk, zlow = ks.zlow;
+    const u64 depth = ks.depth;
+    const bool packed = mode == MODE_TEXT && cpk != (W ? 3u : 4u);
     if (packed) { s_code[threadIdx.x] = code[threadIdx.x]; __syncthreads(); }
     const u32 count = counters[cnt_idx];
     constexpr int U = 4;                       // independent gathers in flight per lane (latency bound otherwise)
     for (u64 base = (u64)blockIdx.x * 256u * U + threadIdx.x; base < count; base += (u64)gridDim.x * 256u * U) {
-        u32 idx[U], key[U];
+        idx_t idx[U];
+        u32 key[U];
         bool v[U];
 #pragma unroll
-        for (int k = 0; k < U; ++k) { const u64 i = base + (u64)k * 256u; v[k] = i < count; idx[k] = v[k] ? (u32)rec[i] : 0u; }
+        for (int k = 0; k < U; ++k) { const u64 i = base + (u64)k * 256u; v[k] = i < count; idx[k] = v[k] ? rec_idx<W>(rec[i]) : (idx_t)0; }
         if (!packed) {
 #pragma unroll
             for (int k = 0; k < U; ++k) {
@@ -866,8 +953,8 @@ __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32
                     if (mode == MODE_TEXT) {
                         u32 w;
                         __builtin_memcpy(&w, text + pos, 4);      // text is padded with >= 64 zero bytes
-                        key[k] = __builtin_bswap32(w);
-                    } else key[k] = isa[pos];
+                        key[k] = __builtin_bswap32(w);             // (wide: make_rec keeps the first three bytes)
+                    } else key[k] = rank_key<W>(isa, pos, n, ks);
                 }
             }
         } else {
@@ -888,7 +975,36 @@ __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32
             }
         }
 #pragma unroll
-        for (int k = 0; k < U; ++k) if (v[k]) rec[base + (u64)k * 256u] = ((u64)key[k] << 32) | idx[k];
+        for (int k = 0; k < U; ++k) if (v[k]) rec[base + (u64)k * 256u] = make_rec<W>(key[k], idx[k]);
+    }
+}
+
+// Stateless doubling step (MODE_DEFER): the segment records of a shard are rebuilt from its suffix-array rows with
+// identity placement - the record of (local) row r lives at rec[r] - and only for rows of groups larger than TINY_MAX
+// (grp[head + TINY_MAX] == head); rows of smaller groups travel through the tiny pool (k_import_groups + k_refill).
+template <bool W>
+__global__ __launch_bounds__(256) void k_refill_rows(const typename Wd<W>::sa_t* __restrict__ sa_rows, const u32* __restrict__ grp, u32 m,
+                                                     u64* __restrict__ rec, const typename Wd<W>::sa_t* __restrict__ isa, u64 n, KeySpec ks)
+{
+    constexpr int U = 4;
+    for (u64 base = (u64)blockIdx.x * 256u * U + threadIdx.x; base < m; base += (u64)gridDim.x * 256u * U) {
+        typename Wd<W>::sa_t idx[U];
+        bool v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const u64 r = base + (u64)k * 256u;
+            v[k] = false; idx[k] = 0;
+            if (r < m) {
+                const u32 g = grp[r];
+                v[k] = (u64)g + TINY_MAX < m && grp[g + TINY_MAX] == g;
+                if (v[k]) idx[k] = sa_rows[r];
+            }
+        }
+        u32 key[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) key[k] = v[k] ? rank_key<W>(isa, (u64)idx[k] + ks.depth, n, ks) : 0u;
+#pragma unroll
+        for (int k = 0; k < U; ++k) if (v[k]) rec[base + (u64)k * 256u] = make_rec<W>(key[k], idx[k]);
     }
 }
 
@@ -908,20 +1024,21 @@ constexpr size_t sort_mid_lds_bytes()
     return (size_t)CAP * 4 + (size_t)WC * 4 + 256 * 4 * 2 + (size_t)(CAP / 64) * (8 * 3 + 4 * 2) + 8 * 4 + 24 * 4;
 }
 
-template <int THREADS, int ITEMS>
+template <int THREADS, int ITEMS, bool W>
 __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc d,
-                                                 u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                 typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                  const Emit& em, u32* __restrict__ counters)
 {
+    constexpr u32 KL = klow<W>();                   // low bits of the key word that are not key (wide: index bits 32..39)
     // Output room (tiny pool, segment array, descriptor lists) is reserved from the global counters in CHUNKS
     // kept in LDS (ach[]): one returning global atomic per chunk instead of per segment - on text-like input
     // millions of segments emit tie runs every round and the shared counters were the bottleneck.
     // Unused chunk tails are overwritten with neutral entries (len 0) that every consumer skips.
     constexpr int CAP = THREADS * ITEMS;
-    constexpr int W = THREADS / 64;
+    constexpr int NWV = THREADS / 64;
     constexpr int NW = CAP / 64;                    // bitmap words
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int WCNT = W * 256 + 8;                           // LSD per-wave digit counters
+    constexpr int WCNT = NWV * 256 + 8;                           // LSD per-wave digit counters
     u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP
     u32* wcnt = ex + CAP;                                       // WCNT
     u32* tot = wcnt + WCNT;                                     // 256
@@ -943,7 +1060,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     const u32 lane = t & 63u, wv = t >> 6;
     // every wave takes the same number of consecutive 64-record rows (wave-major order keeps the LSD passes stable);
     // with a fixed ITEMS rows per wave a short segment would be sorted by one wave while the others idle
-    const u32 rpw = ((len + 63u) / 64u + W - 1) / W;            // rows per wave, <= ITEMS because len <= CAP
+    const u32 rpw = ((len + 63u) / 64u + NWV - 1) / NWV;            // rows per wave, <= ITEMS because len <= CAP
     const u32 wbase = wv * 64u * rpw;
     const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -964,7 +1081,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     __syncthreads();
     if (lane == 0 && diff) atomicOr(&misc[0], diff);
     __syncthreads();
-    diff = misc[0];
+    diff = misc[0] & (0xffffffffu << KL);           // (wide: the index byte never decides an LSD pass; equal keys keep their order)
     // number of item rows this wave takes part in (rows with at least one valid element)
     int rows = 0;
     if (wbase < len) { const u32 rem = len - wbase; rows = (int)((rem + 63u) / 64u); if (rows > (int)rpw) rows = (int)rpw; }
@@ -979,7 +1096,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 #pragma nounroll
     for (u32 shift = 0; shift < 32 && !sorted_done; shift += 8) {
         if (((diff >> shift) & 255u) == 0) continue;            // byte equal everywhere: pass not needed
-        for (u32 i = t; i < (u32)W * 256u; i += THREADS) wcnt[i] = 0;
+        for (u32 i = t; i < (u32)NWV * 256u; i += THREADS) wcnt[i] = 0;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -1003,7 +1120,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
         for (u32 dg = t; dg < 256u; dg += THREADS) {
             u32 run = 0;
 #pragma unroll
-            for (int w = 0; w < W; ++w) { const u32 c = wcnt[w * 256 + dg]; wcnt[w * 256 + dg] = run; run += c; }
+            for (int w = 0; w < NWV; ++w) { const u32 c = wcnt[w * 256 + dg]; wcnt[w * 256 + dg] = run; run += c; }
             tot[dg] = run;
         }
         __syncthreads();
@@ -1037,7 +1154,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     for (int j = 0; j < ITEMS; ++j)
         if (j < rows) {
             const u32 p = wbase + j * 64 + lane;
-            const bool eqn = (p + 1 < len) && (key[j] == ex[p + 1]);
+            const bool eqn = (p + 1 < len) && ((key[j] >> KL) == (ex[p + 1] >> KL));
             const u64 bal = __ballot(eqn);
             if (lane == 0) bm_eq[p >> 6] = bal;
             any_eq |= (bal != 0);
@@ -1095,8 +1212,9 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                 const u32 s = below ? (u32)((w << 6) + 64 - __clzll((long long)below)) : pre_tiny[w];
                 const u32 e = above ? (u32)((w << 6) + __ffsll((long long)above) - 1) : pre_seg[w];
                 rs[j] = s; rl[j] = e - s + 1;
-                sa_out[d.sa_off + p] = idx[j];
+                sa_out[d.sa_off + p] = full_idx<W>(key[j], idx[j]);
                 if (mode == MODE_ISA && (s != 0 || (d.buf & DESC_STALE))) isa[idx[j]] = rank0 + d.sa_off + s + 1u;
+                if (mode == MODE_DEFER) em.grp_out[d.sa_off + p] = d.sa_off + s;
             }
         }
     } else {
@@ -1108,18 +1226,18 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
         __syncthreads();
         u32 c_lt[2] = {0, 0}, c_eq[2] = {0, 0}, c_eqb[2] = {0, 0};
         for (u32 q = 0; q < len; ++q) {
-            const u32 kk = ex[q];
+            const u32 kk = ex[q] >> KL;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const bool e = kk == key[j];
-                c_lt[j] += kk < key[j]; c_eq[j] += e; c_eqb[j] += e & (q < (u32)j * 64u + lane);
+                const bool e = kk == (key[j] >> KL);
+                c_lt[j] += kk < (key[j] >> KL); c_eq[j] += e; c_eqb[j] += e & (q < (u32)j * 64u + lane);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const u32 p = j * 64 + lane;
-            if (p < len) { const u32 f = c_lt[j] + c_eqb[j]; ex[f] = idx[j]; ex[128 + f] = c_lt[j]; ex[256 + f] = c_eq[j]; }
+            if (p < len) { const u32 f = c_lt[j] + c_eqb[j]; ex[f] = idx[j]; ex[128 + f] = c_lt[j]; ex[256 + f] = c_eq[j]; if (W) ex[384 + f] = key[j]; }
         }
         for (u32 i = t; i < (u32)NW; i += THREADS) { bm_eq[i] = 0; bm_tiny[i] = 0; bm_seg[i] = 0; }
         __syncthreads();
@@ -1129,12 +1247,15 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
             rs[j] = p; rl[j] = 1;
             if (j < 2 && p < len) {
                 idx[j] = ex[p]; rs[j] = ex[128 + p]; rl[j] = ex[256 + p];
-                sa_out[d.sa_off + p] = idx[j];
+                if (W) key[j] = ex[384 + p];             // (the index byte travels with the key word)
+                sa_out[d.sa_off + p] = full_idx<W>(key[j], idx[j]);
                 if (mode == MODE_ISA && (rs[j] != 0 || (d.buf & DESC_STALE))) isa[idx[j]] = rank0 + d.sa_off + rs[j] + 1u;
+                if (mode == MODE_DEFER) em.grp_out[d.sa_off + p] = d.sa_off + rs[j];
                 any_eq |= rl[j] > 1;
             }
         }
     }
+    if (em.discard) return;                         // stateless doubling step: the caller rebuilds the groups from grp_out
     if (!__syncthreads_or(any_eq)) return;
 
     // ---- compact still-tied runs into next round's structures ----
@@ -1247,11 +1368,11 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                 const u32 w = p >> 6;
                 if (rl[j] <= TINY_MAX) {
                     const u32 o = base_t + pre_tiny[w] + (u32)__popcll(bm_tiny[w] & lt_mask);
-                    em.pool_rec[o] = (u64)idx[j];
+                    em.pool_rec[o] = (u64)full_idx<W>(key[j], idx[j]);
                     em.pool_hdr[o] = pack_hdr(d.sa_off + rs[j], rl[j], p - rs[j]);
                 } else {
                     const u32 o = base_s + pre_seg[w] + (u32)__popcll(bm_seg[w] & lt_mask);
-                    em.seg_rec[o] = (u64)idx[j];
+                    em.seg_rec[o] = (u64)full_idx<W>(key[j], idx[j]);
                     if (p == rs[j]) {
                         const Desc nd = {o, rl[j], d.sa_off + rs[j], em.seg_buf};
                         const u32 cls = class_of(rl[j]);
@@ -1612,9 +1733,9 @@ constexpr size_t sort_fast_lds_bytes()
 
 // persistent launch: workgroups stride over the list and skip what k_sort_fast already finished
 // (the class-B instance asks for 4 waves per SIMD = 128 VGPRs: one more resident workgroup per CU)
-template <int THREADS, int ITEMS>
+template <int THREADS, int ITEMS, bool W>
 __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
-                                                      u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                      typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                       Emit em, u32* __restrict__ counters, const u32* __restrict__ ids, u32 ids_cnt_idx)
 {
     // ids != nullptr: only the segments k_sort_fast left behind (their count lives in the counters block)
@@ -1629,7 +1750,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(
         for (u32 i = blockIdx.x; i < total; i += gridDim.x) {
             const u32 ni = i + gridDim.x < total ? i + gridDim.x : i;
             const Desc dn = list[ids ? ids[ni] : ni];
-            sort_mid_segment<THREADS, ITEMS>(bufs, d, sa_out, isa, mode, em, counters);
+            sort_mid_segment<THREADS, ITEMS, W>(bufs, d, sa_out, isa, mode, em, counters);
             __syncthreads();
             d = dn;
         }
@@ -1648,11 +1769,13 @@ __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(
 // rank by counting inside the run (the insertion-sort regime of cpp:223-312).  A workgroup owns the
 // runs that START in its 256-slot window and loads a 31-slot halo.
 // ------------------------------------------------------------------------------------------------
+template <bool W>
 __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_rec, const u64* __restrict__ pool_hdr,
-                                                   u32 cnt_idx, u32* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                   u32 cnt_idx, typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                    u64* __restrict__ next_rec, u64* __restrict__ next_hdr, u32 next_cnt_idx, u32 next_cap,
-                                                   u32 chunk, u32* __restrict__ counters)
+                                                   u32 chunk, u32* __restrict__ counters, u32* __restrict__ grp_out, u32 discard)
 {
+    constexpr u32 KL = klow<W>();
     constexpr int WIN = 256, HALO = 32, TOT = WIN + HALO;
     __shared__ u32 lkey[TOT], lrun[TOT];
     __shared__ u32 s_total, s_base, s_cb, s_ce, s_fb, s_fe;      // window total / base; chunk [cb, ce); pending fill [fb, fe)
@@ -1668,7 +1791,7 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const u32 e = t + k * WIN;
-            if (e < TOT && b0 + e < count) { rec[k] = pool_rec[b0 + e]; hdr[k] = pool_hdr[b0 + e]; have[k] = true; lkey[e] = (u32)(rec[k] >> 32); }
+            if (e < TOT && b0 + e < count) { rec[k] = pool_rec[b0 + e]; hdr[k] = pool_hdr[b0 + e]; have[k] = true; lkey[e] = (u32)(rec[k] >> (32 + KL)); }
         }
         __syncthreads();
         u32 n_lt[2], n_eq[2], n_eqb[2], lead[2];
@@ -1689,9 +1812,10 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
                         if (kk == my) { if (!found) { found = true; lead[k] = ls + q; } n_eq[k]++; n_eqb[k] += q < off; }
                     }
                     const u32 row = sa_start + n_lt[k] + n_eqb[k];
-                    sa_out[row] = (u32)rec[k];
+                    sa_out[row] = rec_idx<W>(rec[k]);
                     if (mode == MODE_ISA && (n_lt[k] != 0 || ((hdr[k] >> 48) & 1ull))) isa[(u32)rec[k]] = rank0 + sa_start + n_lt[k] + 1u;
-                    if (n_eq[k] > 1 && n_eqb[k] == 0) lrun[e] = atomicAdd(&s_total, n_eq[k]);
+                    if (mode == MODE_DEFER) grp_out[row] = sa_start + n_lt[k];
+                    if (!discard && n_eq[k] > 1 && n_eqb[k] == 0) lrun[e] = atomicAdd(&s_total, n_eq[k]);
                 }
             }
         }
@@ -1715,7 +1839,7 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
             if (owned[k] && n_eq[k] > 1) {
                 const u32 sa_start = (u32)hdr[k];
                 const u32 o = s_base + lrun[lead[k]] + n_eqb[k];
-                next_rec[o] = (u64)(u32)rec[k];
+                next_rec[o] = (u64)rec_idx<W>(rec[k]);
                 next_hdr[o] = pack_hdr(sa_start + n_lt[k], n_eq[k], n_eqb[k]);
             }
     }
@@ -1756,10 +1880,20 @@ __global__ __launch_bounds__(256) void k_isa_segs(RecBufs bufs, const Desc* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sharded builds with deep ties: a shard that runs out of key-gather rounds publishes, next to
-// its slice of the suffix array, grp[row] = first row of the tie group the row belongs to (its own row when
-// the row is final).  After the all-gatherv every rank rebuilds the complete state from (SA, grp) with
-// k_import_groups / k_isa_from_grp and finishes with prefix doubling (replicated - ranks are global there).
+// Sharded / wide builds with deep ties: prefix doubling distributed over the shards.
+//
+// State of a shard between steps: its suffix-array rows and grp[r] = first row of the tie group of row r (LOCAL rows,
+// relative to the slice; grp[r] == r and grp[r+1] != r for a final row).  The rank array ISA[i] = global row of the head
+// of suffix i's group is REPLICATED and read-only during a step.  One step at offset h, per shard:
+//   k_import_groups   rows -> tiny pool + size-class descriptor lists (identity-placed segment records)
+//   k_refill / k_refill_rows   keys = ISA[i + h]
+//   partition levels + LDS sorts in MODE_DEFER: rows and grp rewritten (coalesced), no rank writes
+//   k_emit_updates    rows whose group head changed -> (suffix, new global head row) pairs
+// then the pairs of ALL shards are exchanged (all-gatherv over RCCL, or simply applied in turn when the shards are
+// logical ones on one GPU) and k_apply_updates scatters them into every replica.  Invariant kept at step boundaries:
+// ISA[SA[r]] == slice_lo + grp[r] for every row of every shard.  This replaces the reference's tandem-repeat machinery
+// (cpp:316-484) and its premise that buckets are independent sort problems (cpp:1652-1683) carries over: a shard only
+// ever sorts its own rows.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_grp_iota(u32* __restrict__ grp_rows, u64 nrows, u32 first_row)
 {
@@ -1784,20 +1918,20 @@ __global__ __launch_bounds__(256) void k_grp_segs(const Desc* __restrict__ list,
     for (u32 p = threadIdx.x; p < d.len; p += 256u) grp_local[d.sa_off + p] = row0 + d.sa_off;
 }
 
-// isa[suffix] = 1 + rank of its group head = the group's first ROW (row r holds rank r-1)
-__global__ __launch_bounds__(256) void k_isa_from_grp(const u32* __restrict__ sa_local, const u32* __restrict__ grp_local, u32 m,
-                                                      u32* __restrict__ isa, u32 n, u32 z)
+// isa[suffix] = global row of its group head (row r holds rank r-1, the empty suffix sits in row 0)
+template <bool W>
+__global__ __launch_bounds__(256) void k_isa_from_slice(const typename Wd<W>::sa_t* __restrict__ sa_rows, const u32* __restrict__ grp, u64 rows, u64 slice_lo,
+                                                        typename Wd<W>::sa_t* __restrict__ isa)
 {
-    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < (u64)m + z; i += (u64)gridDim.x * 256u) {
-        if (i < m) isa[sa_local[i]] = grp_local[i];
-        else { const u32 j = (u32)(i - m); isa[n - 1 - j] = j + 1u; }
-    }
+    for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r < rows; r += (u64)gridDim.x * 256u)
+        isa[sa_rows[r]] = (typename Wd<W>::sa_t)(slice_lo + grp[r]);
 }
 
-// Rebuild pool / segment array / descriptor lists from (SA, grp): the LAST row of every group emits it.
-// Segment records use identity placement (record of row r at rec[r]).
-__global__ __launch_bounds__(256) void k_import_groups(const u32* __restrict__ sa_local, const u32* __restrict__ grp_local, u32 m, u32 row0,
-                                                       u64* __restrict__ seg_rec, u32 seg_buf,
+// Rebuild tiny pool / descriptor lists from (rows, grp): the LAST row of every group emits it.  Segment records use
+// identity placement (record of row r at rec[r]) and are written, with their keys, by k_refill_rows.
+template <bool W>
+__global__ __launch_bounds__(256) void k_import_groups(const typename Wd<W>::sa_t* __restrict__ sa_local, const u32* __restrict__ grp_local, u32 m,
+                                                       u32 seg_buf,
                                                        u64* __restrict__ pool_rec, u64* __restrict__ pool_hdr, u32 pool_cnt_idx, u32 pool_cap,
                                                        Lists lists, Desc* __restrict__ large, u32 large_cap, u32 large_cnt_idx, u32 large_tiles_idx,
                                                        u32* __restrict__ counters)
@@ -1807,9 +1941,8 @@ __global__ __launch_bounds__(256) void k_import_groups(const u32* __restrict__ s
     const u32 lp = live ? (u32)lp64 : 0u;
     u32 g = 0, len = 0;
     if (live) {
-        seg_rec[lp] = (u64)sa_local[lp];
-        g = grp_local[lp] - row0;
-        const bool tail = (lp + 1 == m) || (grp_local[lp + 1] != grp_local[lp]);
+        g = grp_local[lp];
+        const bool tail = (lp + 1 == m) || (grp_local[lp + 1] != g);
         len = tail ? lp - g + 1 : 0u;
     }
     {   // tiny groups: one pool allocation per wave
@@ -1844,10 +1977,65 @@ __global__ __launch_bounds__(256) void k_import_groups(const u32* __restrict__ s
     if (cls == 3) atomicAdd(&counters[large_tiles_idx], (len + P1_TILE - 1) / P1_TILE);
 }
 
-// SA[0] = n and the trailing-zero-run rows (descending index)
-__global__ __launch_bounds__(256) void k_sa_head(u32* __restrict__ sa, u32 n, u32 z)
+// Rank updates of one step for the rows [r0, r1) of a slice: every row whose group head differs from the one it had when
+// the step began (grp_prev) names a suffix whose rank changed.  An update is {suffix, new global head row}: one u64
+// (row << 32 | suffix) in narrow builds, two u64 in wide builds.  out_count[0] = pairs written (stops at cap: the caller
+// sizes the row window so that it cannot overflow), out_count[1] += rows of the window that are still tied.
+template <bool W>
+__global__ __launch_bounds__(256) void k_emit_updates(const typename Wd<W>::sa_t* __restrict__ sa_rows, const u32* __restrict__ grp, const u32* __restrict__ grp_prev,
+                                                      u64 rows, u64 r0, u64 r1, u64 slice_lo, u64* __restrict__ out, u64 cap,
+                                                      unsigned long long* __restrict__ out_count)
 {
-    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
-    if (i == 0) sa[0] = n;
-    if (i < z) sa[1 + i] = n - 1 - (u32)i;
+    __shared__ u32 s_cnt, s_tied;
+    __shared__ unsigned long long s_base;
+    const u64 lt_mask = lane_id() ? (~0ull >> (64 - lane_id())) : 0ull;
+    for (u64 b = r0 + (u64)blockIdx.x * 256u; b < r1; b += (u64)gridDim.x * 256u) {
+        if (threadIdx.x == 0) { s_cnt = 0; s_tied = 0; }
+        __syncthreads();
+        const u64 r = b + threadIdx.x;
+        bool chg = false, tied = false;
+        u32 g = 0;
+        if (r < r1) {
+            g = grp[r];
+            chg = g != grp_prev[r];
+            tied = g != (u32)r || (r + 1 < rows && grp[r + 1] == (u32)r);
+        }
+        const u64 mc = __ballot(chg), mt = __ballot(tied);
+        u32 wbase = 0;
+        if (lane_id() == 0) { if (mc) wbase = atomicAdd(&s_cnt, (u32)__popcll(mc)); if (mt) atomicAdd(&s_tied, (u32)__popcll(mt)); }
+        wbase = __shfl(wbase, 0, 64);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_base = s_cnt ? atomicAdd(&out_count[0], (unsigned long long)s_cnt) : 0ull;
+            if (s_tied) atomicAdd(&out_count[1], (unsigned long long)s_tied);
+        }
+        __syncthreads();
+        if (chg) {
+            const u64 o = s_base + wbase + (u32)__popcll(mc & lt_mask);
+            if (o < cap) {
+                if constexpr (W) { out[2 * o] = sa_rows[r]; out[2 * o + 1] = slice_lo + g; }
+                else out[o] = ((slice_lo + g) << 32) | (u64)sa_rows[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <bool W>
+__global__ __launch_bounds__(256) void k_apply_updates(const u64* __restrict__ upd, u64 count, typename Wd<W>::sa_t* __restrict__ isa)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < count; i += (u64)gridDim.x * 256u) {
+        if constexpr (W) isa[upd[2 * i]] = upd[2 * i + 1];
+        else { const u64 u = upd[i]; isa[(u32)u] = (u32)(u >> 32); }
+    }
+}
+
+// SA[0] = n and the trailing-zero-run rows (descending index)
+template <bool W>
+__global__ __launch_bounds__(256) void k_sa_head(typename Wd<W>::sa_t* __restrict__ sa, u64 n, u64 z)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < (z ? z : 1); i += (u64)gridDim.x * 256u) {
+        if (i == 0) sa[0] = (typename Wd<W>::sa_t)n;
+        if (i < z) sa[1 + i] = (typename Wd<W>::sa_t)(n - 1 - i);
+    }
 }

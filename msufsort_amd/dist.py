@@ -17,8 +17,8 @@ from . import _lib
 
 
 def plan_cuts(bstart, n: int, z: int, n_shards: int):
-    """Host-only: (cuts, rows) for `n_shards` shards from the exclusive 16-bit-key prefix bstart[65537]."""
-    b = np.ascontiguousarray(bstart, dtype=np.uint32)
+    """Host-only: (cuts, rows) for `n_shards` shards from the exclusive 16-bit-key prefix bstart[65537] (uint64)."""
+    b = np.ascontiguousarray(bstart, dtype=np.uint64)
     assert b.size == 65537
     cuts = np.zeros(n_shards + 1, dtype=np.uint32)
     rows = np.zeros(n_shards + 1, dtype=np.int64)
@@ -38,16 +38,12 @@ def select_exchange(dist, device):
         _MODE["mode"] = "bcast"
         return "bcast"
     world, rank = dist.get_world_size(), dist.get_rank()
-    ok = 1
-    try:
-        probe = torch.zeros(world * 4, dtype=torch.int32, device=device)
-        probe[rank * 4:(rank + 1) * 4] = rank + 1
-        _MODE["mode"] = "p2p"
-        allgatherv_slices(probe, [4 * g for g in range(world + 1)], dist)
-        if not bool((probe.view(world, 4) == torch.arange(1, world + 1, device=device, dtype=torch.int32)[:, None]).all()):
-            ok = 0
-    except Exception:  # noqa: BLE001
-        ok = 0
+    # (a probe that RAISES aborts the job: swallowing it here would leave the peers blocked in the grouped exchange)
+    probe = torch.zeros(world * 4, dtype=torch.int32, device=device)
+    probe[rank * 4:(rank + 1) * 4] = rank + 1
+    _MODE["mode"] = "p2p"
+    allgatherv_slices(probe, [4 * g for g in range(world + 1)], dist)
+    ok = int(bool((probe.view(world, 4) == torch.arange(1, world + 1, device=device, dtype=torch.int32)[:, None]).all()))
     flag = torch.tensor([ok], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     _MODE["mode"] = "p2p" if int(flag.item()) == 1 else "bcast"
@@ -97,44 +93,150 @@ def wait_all(works, full=None):
         torch.cuda.synchronize(full.device)
 
 
+class ShardState:
+    """Per-rank buffers of the distributed prefix doubling (allocated on first use, reused by later builds)."""
+
+    def __init__(self):
+        self.isa = None
+        self.grp_prev = None
+        self.upd_local = None
+        self.upd_all = None
+        self.stats = {}
+
+    def ensure(self, n, rows_max, world, index_bytes, device):
+        import torch
+        dt = torch.int64 if index_bytes == 8 else torch.int32
+        if self.isa is None or self.isa.numel() < n + 2 or self.isa.dtype != dt:
+            self.isa = torch.empty(n + 2, dtype=dt, device=device)
+        if self.grp_prev is None or self.grp_prev.numel() < rows_max:
+            self.grp_prev = torch.empty(max(rows_max, 1), dtype=torch.int32, device=device)
+        e = 2 if index_bytes == 8 else 1
+        self.win = max(1, min(rows_max, 1 << 25))
+        if self.upd_local is None or self.upd_local.numel() < self.win * e:
+            self.upd_local = torch.empty(self.win * e, dtype=torch.int64, device=device)
+        if self.upd_all is None or self.upd_all.numel() < self.win * e * world:
+            self.upd_all = torch.empty(self.win * e * world, dtype=torch.int64, device=device)
+
+
+def _distributed_doubling(ctx, n, d_sa_full, d_grp_full, bounds, rank, world, dist, depth, index_bytes, state, verbose=0):
+    """Prefix doubling over the shards (include/msufsort_hip.h, 'Distributed prefix doubling'): every rank sorts only the
+    tie groups of its own slice; the rank array is replicated and refreshed once per step with ONE all-gatherv of the
+    (suffix, new head row) updates of all ranks.  Starts from gathered provisional rows + group heads."""
+    import time
+
+    import torch
+    dev = d_sa_full.device
+    lo, hi = bounds[rank], bounds[rank + 1]
+    rows_max = max(bounds[g + 1] - bounds[g] for g in range(world))
+    state.ensure(n, rows_max, world, index_bytes, dev)
+    isa, e = state.isa, (2 if index_bytes == 8 else 1)
+    one = torch.empty(1, dtype=d_sa_full.dtype, device=dev)
+    sl = d_sa_full[lo:hi] if hi > lo else one
+    gl = d_grp_full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
+    gp = state.grp_prev
+    for g in range(world):
+        if bounds[g + 1] > bounds[g]:
+            ctx.isa_from_slice(d_sa_full[bounds[g]:bounds[g + 1]], d_grp_full[bounds[g]:bounds[g + 1]], bounds[g], bounds[g + 1], isa, index_bytes)
+    st = {"doubling_steps": 0, "sort_ms": 0.0, "exchange_ms": 0.0, "updates": 0, "depth": depth}
+    win = state.win
+    nwin = (rows_max + win - 1) // win
+    h = depth
+    live = hi > lo
+    while True:
+        if live:
+            live = ctx.double_sort(n, sl, gl, gp, lo, hi, isa, h, index_bytes, verbose) > 0
+            st["sort_ms"] += ctx.timings().refine_ms
+        tied_local = 0
+        for w in range(nwin):
+            cnt = tied = 0
+            if live:
+                r0 = min(w * win, hi - lo)
+                r1 = min(r0 + win, hi - lo)
+                cnt, tied = ctx.emit_updates(sl, gl, gp, lo, hi, r0, r1, state.upd_local, win, index_bytes)
+            tied_local += tied
+            t0 = time.perf_counter()
+            counts = torch.zeros(world, dtype=torch.int64, device=dev)
+            counts[rank] = cnt
+            if world > 1:
+                dist.all_reduce(counts)
+            cl = [int(x) for x in counts.tolist()]
+            pre = [0]
+            for x in cl:
+                pre.append(pre[-1] + x * e)
+            if pre[-1]:
+                if cnt:
+                    state.upd_all[pre[rank]:pre[rank + 1]] = state.upd_local[:cnt * e]
+                if dev.type == "cuda":
+                    torch.cuda.current_stream(dev).synchronize()
+                if world > 1:
+                    allgatherv_slices(state.upd_all, pre, dist)
+                st["exchange_ms"] += (time.perf_counter() - t0) * 1e3
+                ctx.apply_updates(state.upd_all, pre[-1] // e, isa, index_bytes)
+                st["updates"] += pre[-1] // e
+        tt = torch.tensor([tied_local], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt)
+        st["doubling_steps"] += 1
+        if int(tt.item()) == 0:
+            break
+        h *= 2
+        if h > 2 * n + 2:
+            raise _lib.MsufsortHipError("distributed prefix doubling did not converge")
+    state.stats = st
+    return st
+
+
 def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist, bounds=None, text_rounds: int = 8,
-                     d_grp_full=None, overlap=False):
+                     d_grp_full=None, overlap=False, index_bytes: int = 4, state=None, verbose: int = 0):
     """One step of the sharded build on this rank: sort my key range into my slice, all-gatherv the slices.
 
-    Deep ties (long repeats) cannot be finished shard-locally - prefix doubling needs the ranks of ALL suffixes.
-    With `d_grp_full` (int32, n+1) every rank also publishes the tie groups of its slice; if any rank stopped with
-    unresolved groups the group slices are gathered too and every rank finishes the complete array by prefix
-    doubling (replicated).  Without it such inputs raise (MSUFSORT_HIP_ERR_UNSUPPORTED).
+    Deep ties (long repeats) cannot be finished by key gathers.  With `d_grp_full` (int32 view of uint32, n+1) every rank
+    also publishes the tie groups of its slice; if any rank stopped with unresolved groups the provisional rows and the
+    group heads are gathered once, every rank builds its replica of the rank array, and the ranks run the DISTRIBUTED
+    prefix doubling: each sorts only its own groups, one all-gatherv of rank updates per step.  The final slices are
+    gathered at the end.  Without `d_grp_full` such inputs raise (MSUFSORT_HIP_ERR_UNSUPPORTED).
+    index_bytes = 8: wide engine (int64 rows; any n up to 2^40 - 2).
 
     overlap=True: returns the pending exchange handles instead of waiting, so the caller can start the next build
     (into ANOTHER output buffer) while the slices travel; finish with `wait_all(works, d_sa_full)`.  If the build
-    turns out to need the finishing pass the exchange is completed here and [] is returned."""
+    turns out to need the doubling phase everything is completed here and [] is returned."""
     import torch
     if bounds is None:
         bounds = ctx.shard_bounds(d_text, n, world)
     lo, hi = bounds[rank], bounds[rank + 1]
     dev = d_sa_full.device
-    sl = d_sa_full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
+    sl = d_sa_full[lo:hi] if hi > lo else torch.empty(1, dtype=d_sa_full.dtype, device=dev)
     if d_grp_full is None:
+        assert index_bytes == 4
         ctx.make_sa_shard(d_text, n, sl, max(hi - lo, 1), rank, world, text_rounds=text_rounds)
         if world > 1:
             works = allgatherv_slices(d_sa_full, bounds, dist, wait=not overlap)
             return works if overlap else []
         return []
     gl = d_grp_full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
-    _, _, unresolved, depth = ctx.make_sa_shard_groups(d_text, n, sl, gl, max(hi - lo, 1), rank, world, text_rounds=text_rounds)
-    flag = torch.tensor([depth if unresolved else 0], dtype=torch.int64, device=dev)
+    _, _, unresolved, depth = ctx.make_sa_shard_groups(d_text, n, sl, gl, max(hi - lo, 1), rank, world, text_rounds=text_rounds,
+                                                       index_bytes=index_bytes, verbose=verbose)
+    # every unresolved rank stopped at the same depth (same number of rounds, same symbols per key): check it instead of
+    # trusting it - doubling from a depth some group does not share would mis-sort silently
+    big = 1 << 62
+    flag = torch.tensor([depth if unresolved else 0, -(depth if unresolved else big)], dtype=torch.int64, device=dev)
     works = []
     if world > 1:
         w = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)       # rides along with the slice exchange
         works = allgatherv_slices(d_sa_full, bounds, dist, wait=False)
         w.wait()
-    depth = int(flag.item())
-    if depth > 0:
+    dmax, dmin = int(flag[0].item()), -int(flag[1].item())
+    if dmax > 0:
+        if dmin != dmax:
+            raise _lib.MsufsortHipError(f"shards stopped their key rounds at different depths ({dmin} .. {dmax})")
         wait_all(works, d_sa_full)
         if world > 1:
             allgatherv_slices(d_grp_full, bounds, dist)
-        ctx.finish_sa(d_text, n, d_sa_full, d_grp_full, depth)
+        if state is None:
+            state = ShardState()
+        _distributed_doubling(ctx, n, d_sa_full, d_grp_full, bounds, rank, world, dist, dmax, index_bytes, state, verbose)
+        if world > 1:
+            allgatherv_slices(d_sa_full, bounds, dist)          # the final rows
         return []
     if overlap:
         return works

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bstart(t):
     tt = np.concatenate([t, np.zeros(1, np.uint8)]).astype(np.uint32)
     h = np.bincount((tt[:-1] << 8) | tt[1:], minlength=65536)
-    return np.concatenate([[0], np.cumsum(h)]).astype(np.uint32)
+    return np.concatenate([[0], np.cumsum(h)]).astype(np.uint64)
 
 
 def test_plan_cuts_balanced_and_monotone():

@@ -25,7 +25,8 @@ def test_bench_two_ranks_one_gpu():
 
 
 def test_bench_two_ranks_deep_ties():
-    """Same flow on DNA with planted tandem repeats: the shards stop unresolved, groups are gathered, every rank finishes."""
+    """Same flow on DNA with planted tandem repeats: the shards stop unresolved and finish with the distributed prefix
+    doubling (each rank sorts its own groups, rank updates are all-gathered once per step)."""
     env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29612", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
@@ -33,7 +34,8 @@ def test_bench_two_ranks_deep_ties():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
-    assert json.loads(lines[-1])["valid"] is True
+    d = json.loads(lines[-1])
+    assert d["valid"] is True and d["doubling"]["doubling_steps"] >= 1 and d["doubling"]["updates"] > 0
 
 
 def test_cpp_dropin_header_builds_and_runs(tmp_path):

@@ -47,7 +47,7 @@ def test_literal_golden(M, oracle_mod, golden):
 
 
 def test_int64_output(M):
-    """msufsort_hip_make_sa_i64: the int32 rows, widened; n = 0 defined."""
+    """msufsort_hip_make_sa_i64 below 2^31 - 1 bytes: the int32 rows, widened; n = 0 defined."""
     t = gen.text_bytes(300001, 5)
     a, b = M.make_suffix_array(t), M.make_suffix_array_i64(t)
     assert b.dtype == np.int64 and (a.astype(np.int64) == b).all()
@@ -206,34 +206,117 @@ def test_logical_shards_concatenate(M, oracle_mod, shards):
         assert (full.cpu().numpy() == want).all()
 
 
+def _deep_inputs():
+    return [gen.dna_tandem_bytes(300000, 9), np.tile(gen.dna_bytes(37, 9), 3000), gen.text_bytes(400000, 21),
+            np.frombuffer(b"ab" * 40000 + b"\x00" * 50, dtype=np.uint8), np.full(70000, 65, np.uint8)]
+
+
+def _want(oracle_mod, t):
+    return oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+
+
 @pytest.mark.parametrize("shards", [2, 5])
-def test_logical_shards_deep_ties_finish(M, oracle_mod, shards):
-    """Sharded build on inputs with long repeats: shards stop with unresolved tie groups, publish them, and the
-    gathered (SA, grp) arrays are finished by prefix doubling - bit-exact against the oracle."""
+def test_logical_shards_deep_ties(M, oracle_mod, shards):
+    """Sharded build on inputs with long repeats, all shards taking turns on one GPU: the shards stop with unresolved
+    tie groups and finish with the DISTRIBUTED prefix doubling (every shard sorts only its own groups; rank updates are
+    exchanged once per step) - bit-exact against the reference."""
     import torch
-    inputs = [gen.dna_tandem_bytes(300000, 9), np.tile(gen.dna_bytes(37, 9), 3000), gen.text_bytes(400000, 21),
-              np.frombuffer(b"ab" * 40000 + b"\x00" * 50, dtype=np.uint8)]
-    for t in inputs:
+    for t in _deep_inputs():
+        n = t.size
+        d = _dev(M, t)
+        ctx = M.DeviceContext(0)
+        sa = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        ctx.make_sa(d, n, sa, logical_shards=shards, text_rounds=1)
+        tm = ctx.timings()
+        assert tm.reserved[1] == shards and tm.reserved[0] == 5 + _symbols_per_key(t) and tm.doubling_rounds >= 1
+        assert (sa.cpu().numpy() == _want(oracle_mod, t)).all()
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+def test_sharded_doubling_pieces(M, oracle_mod, shards):
+    """The same flow through the per-shard C-ABI pieces a multi-process job uses (msufsort_amd/dist.py): shard build with
+    group heads, replicated rank array, double_sort / emit_updates / apply_updates per step, one context per shard."""
+    import torch
+    for t in _deep_inputs()[:3]:
         n = t.size
         d = _dev(M, t)
         full = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
         grp = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        prev = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        isa = torch.empty(n + 2, dtype=torch.int32, device="cuda")
+        upd = torch.empty(n + 1, dtype=torch.int64, device="cuda")
         ctxs = [M.DeviceContext(0) for _ in range(shards)]
         bounds = ctxs[0].shard_bounds(d, n, shards)
         depth = 0
         for g in range(shards):
             lo, hi = bounds[g], bounds[g + 1]
-            sl = full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device="cuda")
-            gl = grp[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device="cuda")
-            l2, h2, unres, dp = ctxs[g].make_sa_shard_groups(d, n, sl, gl, max(hi - lo, 1), g, shards, text_rounds=1)
+            l2, h2, unres, dp = ctxs[g].make_sa_shard_groups(d, n, full[lo:hi], grp[lo:hi], hi - lo, g, shards, text_rounds=1)
             assert (l2, h2) == (lo, hi)
-            depth = max(depth, dp if unres else 0)
-        want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
-        assert depth == 5 + _symbols_per_key(t)              # 5 bytes from round 0 + one key-gather round
+            if unres:
+                assert depth in (0, dp)
+                depth = dp
+        assert depth == 5 + _symbols_per_key(t)
         g_host = grp.cpu().numpy()
-        assert (g_host <= np.arange(n + 1)).all() and (g_host >= 0).all()
-        ctxs[-1].finish_sa(d, n, full, grp, depth)
-        assert (full.cpu().numpy() == want).all()
+        for g in range(shards):          # local heads: never beyond the row itself
+            lo, hi = bounds[g], bounds[g + 1]
+            assert (g_host[lo:hi] <= np.arange(hi - lo)).all() and (g_host[lo:hi] >= 0).all()
+        for g in range(shards):
+            ctxs[g].isa_from_slice(full[bounds[g]:bounds[g + 1]], grp[bounds[g]:bounds[g + 1]], bounds[g], bounds[g + 1], isa)
+        h, steps = depth, 0
+        while True:
+            for g in range(shards):
+                lo, hi = bounds[g], bounds[g + 1]
+                ctxs[g].double_sort(n, full[lo:hi], grp[lo:hi], prev[lo:hi], lo, hi, isa, h)
+            tied = 0
+            for g in range(shards):      # the rank array is read-only until every shard has sorted
+                lo, hi = bounds[g], bounds[g + 1]
+                cnt, td = ctxs[g].emit_updates(full[lo:hi], grp[lo:hi], prev[lo:hi], lo, hi, 0, hi - lo, upd, n + 1)
+                ctxs[g].apply_updates(upd, cnt, isa)
+                tied += td
+            steps += 1
+            if tied == 0:
+                break
+            h *= 2
+            assert steps < 40
+        assert (full.cpu().numpy() == _want(oracle_mod, t)).all()
+
+
+@pytest.mark.parametrize("shards,digit_bits", [(1, 0), (3, 0), (2, 7)])
+def test_wide_engine_parity(M, oracle_mod, monkeypatch, shards, digit_bits):
+    """The wide engine (40-bit indices in 8-byte records, int64 rows, logical shards, distributed doubling with two key
+    digits per step) forced onto small inputs: every row equal to the reference's.  digit_bits narrows the doubling
+    key so that the two-pass (high digit, low digit) path runs at these sizes."""
+    if digit_bits:
+        monkeypatch.setenv("MSUFSORT_HIP_DIGIT_BITS", str(digit_bits))
+    cases = [gen.random_bytes(1 << 20, 3), gen.text_bytes(1 << 19, 4), gen.dna_bytes(1 << 20, 5)] + _deep_inputs() + [
+        np.frombuffer(b"\x00" * 5000 + b"abc" * 3000 + b"\x00" * 777, dtype=np.uint8), gen.sweep_bytes(2, 100000),
+        np.frombuffer(b"banana", dtype=np.uint8), np.frombuffer(b"a", dtype=np.uint8)]
+    for t in cases:
+        sa = M.make_suffix_array_i64(t, force_wide=True, n_shards=shards, text_rounds=1)
+        assert sa.dtype == np.int64 and (sa == _want(oracle_mod, t).astype(np.int64)).all(), (t.size, shards)
+    t = gen.text_bytes(1 << 20, 8)
+    assert (M.make_suffix_array_i64(t, force_wide=True) == _want(oracle_mod, t)).all()          # default rounds / shards
+
+
+def test_wide_engine_device_api(M, oracle_mod):
+    """int64 rows in HBM: wide build, 64-bit on-device checker (incl. negative cases), BWT from int64 rows."""
+    import torch
+    t = gen.dna_tandem_bytes(1 << 21, 6)
+    n = t.size
+    ctx = M.DeviceContext(0)
+    d = _dev(M, t)
+    sa = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.make_sa_i64(d, n, sa, force_wide=True, n_shards=4)
+    assert ctx.timings().reserved[1] >= 4
+    assert ctx.validate_sa(d, n, sa, index_bytes=8) == 0
+    bad = sa.clone(); bad[1000], bad[1001] = sa[1001].item(), sa[1000].item()
+    assert ctx.validate_sa(d, n, bad, index_bytes=8) > 0
+    bad = sa.clone(); bad[7] = sa[8]
+    assert ctx.validate_sa(d, n, bad, index_bytes=8) > 0
+    bwt = torch.empty(n, dtype=torch.uint8, device="cuda")
+    sent = ctx.bwt_from_sa(d, n, sa, bwt, index_bytes=8)
+    wb, ws = oracle_mod.forward_bwt(t)
+    assert sent == ws and (bwt.cpu().numpy() == wb).all()
 
 
 def test_large_random_properties(M):
