@@ -133,8 +133,13 @@ int msufsort_hip_make_sa_shard_groups_i64_dev(msufsort_hip_ctx* ctx, uint8_t* d_
  * isa[i] = global row of the head of suffix i's group (n + 1 entries of index_bytes = 4 or 8) is replicated and read-only
  * during a step.  One step at offset h (h starts at *depth_out and doubles):
  *   every rank:  msufsort_hip_double_sort_dev      sorts its tied groups by isa[i + h]; rewrites slice rows + group heads
- *                msufsort_hip_emit_updates_dev     rows [r0, r1) of the slice whose group head changed -> updates
- *                                                  (index_bytes 4: one uint64 = new_row << 32 | suffix; 8: {suffix, new_row})
+ *                                                  (*emit_items = work items the emit pass has to scan: the context keeps
+ *                                                  the list of still-tied rows of its slice between steps, so a step costs
+ *                                                  time in proportion to what is tied, not to the slice)
+ *                msufsort_hip_emit_updates_dev     work items [i0, i1) of emit_items: rows whose group head changed ->
+ *                                                  updates (index_bytes 4: one uint64 = new_row << 32 | suffix; 8: {suffix,
+ *                                                  new_row}); windows in ascending order, the one with i1 == items_total
+ *                                                  closes the step
  *   exchange:    all-gatherv of the updates (RCCL), then on every rank
  *                msufsort_hip_apply_updates_dev    isa[suffix] = new_row, for the updates of ALL ranks
  * until no rank has tied rows left.  msufsort_hip_isa_from_slice_dev initialises a replica from one (gathered) slice. */
@@ -142,10 +147,11 @@ int msufsort_hip_isa_from_slice_dev(msufsort_hip_ctx* ctx, const void* d_sa_slic
                                     int64_t lo, int64_t hi, void* d_isa, int32_t index_bytes);
 int msufsort_hip_double_sort_dev(msufsort_hip_ctx* ctx, int64_t n, void* d_sa_slice, uint32_t* d_grp_slice,
                                  uint32_t* d_grp_prev_slice, int64_t lo, int64_t hi, const void* d_isa, int64_t h,
-                                 int32_t index_bytes, const msufsort_hip_opts* opts, int64_t* tied_before);
+                                 int32_t index_bytes, const msufsort_hip_opts* opts, int64_t* tied_before, int64_t* emit_items);
 int msufsort_hip_emit_updates_dev(msufsort_hip_ctx* ctx, const void* d_sa_slice, const uint32_t* d_grp_slice,
-                                  const uint32_t* d_grp_prev_slice, int64_t lo, int64_t hi, int64_t r0, int64_t r1,
-                                  void* d_updates, int64_t capacity, int32_t index_bytes, int64_t* count, int64_t* tied_rows);
+                                  const uint32_t* d_grp_prev_slice, int64_t lo, int64_t hi, int64_t i0, int64_t i1,
+                                  int64_t items_total, void* d_updates, int64_t capacity, int32_t index_bytes,
+                                  int64_t* count, int64_t* tied_rows);
 int msufsort_hip_apply_updates_dev(msufsort_hip_ctx* ctx, const void* d_updates, int64_t count, void* d_isa,
                                    int32_t index_bytes);
 /* Slice bounds only (all shards), without sorting: bounds[n_shards + 1], in SA rows. */

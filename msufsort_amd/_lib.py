@@ -87,8 +87,8 @@ def lib():
     L.msufsort_hip_make_sa_shard_groups_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(Opts)]
     L.msufsort_hip_make_sa_shard_groups_i64_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(Opts)]
     L.msufsort_hip_isa_from_slice_dev.argtypes = [vp, vp, vp, i64, i64, vp, i32]
-    L.msufsort_hip_double_sort_dev.argtypes = [vp, i64, vp, vp, vp, i64, i64, vp, i64, i32, C.POINTER(Opts), C.POINTER(i64)]
-    L.msufsort_hip_emit_updates_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, vp, i64, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.msufsort_hip_double_sort_dev.argtypes = [vp, i64, vp, vp, vp, i64, i64, vp, i64, i32, C.POINTER(Opts), C.POINTER(i64), C.POINTER(i64)]
+    L.msufsort_hip_emit_updates_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, vp, i64, i32, C.POINTER(i64), C.POINTER(i64)]
     L.msufsort_hip_apply_updates_dev.argtypes = [vp, vp, i64, vp, i32]
     L.msufsort_hip_ctx_trim.argtypes = [vp]
     L.msufsort_hip_validate_sa_i64_dev.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]

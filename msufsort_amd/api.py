@@ -197,19 +197,21 @@ class DeviceContext:
     def isa_from_slice(self, d_sa_slice, d_grp_slice, lo: int, hi: int, d_isa, index_bytes=4):
         _lib.check(self._L.msufsort_hip_isa_from_slice_dev(self._h, self._ptr(d_sa_slice), self._ptr(d_grp_slice), lo, hi, self._ptr(d_isa), index_bytes), "isa_from_slice")
 
-    def double_sort(self, n: int, d_sa_slice, d_grp_slice, d_grp_prev_slice, lo: int, hi: int, d_isa, h: int, index_bytes=4, verbose=0) -> int:
-        """One doubling step's sort work for this slice; returns how many groups were tied when it began (0: slice final)."""
+    def double_sort(self, n: int, d_sa_slice, d_grp_slice, d_grp_prev_slice, lo: int, hi: int, d_isa, h: int, index_bytes=4, verbose=0):
+        """One doubling step's sort work for this slice; returns (groups tied when it began - 0: slice final,
+        work items the emit pass has to scan)."""
         o = _opts(self.device, verbose)
-        t = C.c_int64(0)
+        t, items = C.c_int64(0), C.c_int64(0)
         _lib.check(self._L.msufsort_hip_double_sort_dev(self._h, n, self._ptr(d_sa_slice), self._ptr(d_grp_slice), self._ptr(d_grp_prev_slice), lo, hi,
-                                                        self._ptr(d_isa), h, index_bytes, C.byref(o), C.byref(t)), "double_sort")
-        return int(t.value)
+                                                        self._ptr(d_isa), h, index_bytes, C.byref(o), C.byref(t), C.byref(items)), "double_sort")
+        return int(t.value), int(items.value)
 
-    def emit_updates(self, d_sa_slice, d_grp_slice, d_grp_prev_slice, lo: int, hi: int, r0: int, r1: int, d_updates, capacity: int, index_bytes=4):
-        """Rank updates of slice rows [r0, r1) -> d_updates; returns (count, tied_rows)."""
+    def emit_updates(self, d_sa_slice, d_grp_slice, d_grp_prev_slice, lo: int, hi: int, i0: int, i1: int, items_total: int, d_updates, capacity: int,
+                     index_bytes=4):
+        """Rank updates of work items [i0, i1) -> d_updates; returns (count, tied_rows).  i1 == items_total closes the step."""
         cnt, tied = C.c_int64(0), C.c_int64(0)
-        _lib.check(self._L.msufsort_hip_emit_updates_dev(self._h, self._ptr(d_sa_slice), self._ptr(d_grp_slice), self._ptr(d_grp_prev_slice), lo, hi, r0, r1,
-                                                         self._ptr(d_updates), capacity, index_bytes, C.byref(cnt), C.byref(tied)), "emit_updates")
+        _lib.check(self._L.msufsort_hip_emit_updates_dev(self._h, self._ptr(d_sa_slice), self._ptr(d_grp_slice), self._ptr(d_grp_prev_slice), lo, hi, i0, i1,
+                                                         items_total, self._ptr(d_updates), capacity, index_bytes, C.byref(cnt), C.byref(tied)), "emit_updates")
         return int(cnt.value), int(tied.value)
 
     def apply_updates(self, d_updates, count: int, d_isa, index_bytes=4):

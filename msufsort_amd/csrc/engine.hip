@@ -65,6 +65,18 @@ struct DevBuf {
 
 }  // namespace
 
+// Tied rows of one slice between doubling steps (unordered list of local rows), so that a step costs time in
+// proportion to what is still tied, not to the slice.  A list holds at most rows / 4 entries; slices with more tied
+// rows are scanned completely (act == nullptr in the kernels) and need the caller's full grp_prev copy instead.
+struct ActiveSet {
+    DevBuf act[2], prev, cnt;          // cnt: 4 x u64 = {updates, tied rows, next list length, next list overflow}
+    u64 count = 0, cap = 0;
+    int cur = 0;
+    bool valid = false;
+    const void* key_sa = nullptr; u64 key_rows = 0;     // which slice the list describes
+    void release() { act[0].release(); act[1].release(); prev.release(); cnt.release(); valid = false; count = 0; cap = 0; }
+};
+
 struct msufsort_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -74,6 +86,7 @@ struct msufsort_hip_ctx {
     DevBuf lists[2][3], large_round[2], lvl[2], seg0;
     DevBuf alpha, seg0_base, stripe_sums, hist_partial, hist, hist_clip, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
     DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, aux3, doneB, doneC;
+    std::vector<ActiveSet> active;                // per logical shard (index 0: the per-shard C-ABI pieces)
     DevBuf grp_full, grp_prev, upd, upd_cnt;      // single-process sharded builds: tie-group heads (all rows), their copy at the
                                                   // start of a doubling step, rank updates of one row window
     u32* h_counters = nullptr;   // pinned
@@ -177,6 +190,8 @@ struct msufsort_hip_ctx {
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
         grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release();
+        for (auto& a : active) a.release();
+        active.clear();
         cap_m = 0; cap_for_m = 0;
     }
 
@@ -810,7 +825,7 @@ Digits plan_digits(u64 n)
 // One sort pass of a doubling step over the rows of one slice (stateless: everything is rebuilt from rows + grp).
 // Returns the number of rows that were still tied BEFORE the pass in *tied_in (0: nothing to do).
 template <bool W>
-int double_pass(msufsort_hip_ctx* c, u64 n, typename Wd<W>::sa_t* d_sa_slice, u32* d_grp_slice, u64 rows,
+int double_pass(msufsort_hip_ctx* c, u64 n, typename Wd<W>::sa_t* d_sa_slice, u32* d_grp_slice, u64 rows, const u32* act, u32 nact,
                 const typename Wd<W>::sa_t* d_isa, u64 h, u32 dig_shift, u32 dig_mask, int verbose, u64* tied_in)
 {
     hipStream_t st = c->stream;
@@ -830,7 +845,7 @@ int double_pass(msufsort_hip_ctx* c, u64 n, typename Wd<W>::sa_t* d_sa_slice, u3
     R.sa_local = d_sa_slice; R.grp_out = d_grp_slice;
     R.cur = 0; R.sb = 2; R.nb = 0; R.mode = MODE_DEFER; R.round = 1; R.discard = 1; R.verbose = verbose;
     R.force_retry = false;
-    hipLaunchKernelGGL(k_import_groups<W>, dim3(cdiv(m, 256)), dim3(256), 0, st, d_sa_slice, d_grp_slice, m, R.sb,
+    hipLaunchKernelGGL(k_import_groups<W>, dim3(cdiv(act ? std::max<u32>(nact, 1u) : m, 256)), dim3(256), 0, st, d_sa_slice, d_grp_slice, m, act, nact, R.sb,
                        c->pool_rec[0].as<u64>(), c->pool_hdr[0].as<u64>(), (u32)C_POOL0, R.cap32(),
                        R.make_lists(0), c->large_round[0].as<Desc>(), c->large_cap, (u32)(C_LIST0 + 3), (u32)C_LTILES0, counters);
     DBG("k_import_groups");
@@ -843,7 +858,7 @@ int double_pass(msufsort_hip_ctx* c, u64 n, typename Wd<W>::sa_t* d_sa_slice, u3
     ks.depth = h; ks.sigma = 256; ks.cpk = W ? 3u : 4u; ks.zlow = 0; ks.dig_shift = dig_shift; ks.dig_mask = dig_mask;
     if (actP) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[0].as<u64>(), counters, (u32)C_POOL0,
                                  (const u8*)nullptr, d_isa, n, (u32)MODE_DEFER, (const u8*)nullptr, ks);
-    if (nseg) hipLaunchKernelGGL(k_refill_rows<W>, dim3(std::min<u32>(cdiv(m, 1024), 65536u)), dim3(256), 0, st, d_sa_slice, d_grp_slice, m, R.bufs.p[R.sb], d_isa, n, ks);
+    if (nseg) hipLaunchKernelGGL(k_refill_rows<W>, dim3(std::min<u32>(cdiv(act ? std::max<u32>(nact, 1u) : m, 1024), 65536u)), dim3(256), 0, st, d_sa_slice, d_grp_slice, m, act, nact, R.bufs.p[R.sb], d_isa, n, ks);
     DBG("doubling refill");
     TRY(R.levels_and_sorts());
     if (verbose)
@@ -852,41 +867,72 @@ int double_pass(msufsort_hip_ctx* c, u64 n, typename Wd<W>::sa_t* d_sa_slice, u3
     return MSUFSORT_HIP_OK;
 }
 
-// One doubling step for one slice: remember the groups (grp_prev), then one or two sort passes.
+// One doubling step for one slice: remember the groups, then one or two sort passes.  *items = work items the emit
+// pass must look at afterwards (entries of the active list, or rows).
 template <bool W>
-int double_sort(msufsort_hip_ctx* c, u64 n, typename Wd<W>::sa_t* d_sa_slice, u32* d_grp_slice, u32* d_grp_prev_slice, u64 rows,
-                const typename Wd<W>::sa_t* d_isa, u64 h, int verbose, u64* tied_in)
+int double_sort(msufsort_hip_ctx* c, ActiveSet& as, u64 n, typename Wd<W>::sa_t* d_sa_slice, u32* d_grp_slice, u32* d_grp_prev_slice, u64 rows,
+                const typename Wd<W>::sa_t* d_isa, u64 h, int verbose, u64* tied_in, u64* items)
 {
     const Digits dg = plan_digits<W>(n);
-    HIP_TRY(hipMemcpyAsync(d_grp_prev_slice, d_grp_slice, (size_t)rows * 4, hipMemcpyDeviceToDevice, c->stream));
+    hipStream_t st = c->stream;
+    if (as.key_sa != (const void*)d_sa_slice || as.key_rows != rows) { as.valid = false; as.key_sa = d_sa_slice; as.key_rows = rows; }
+    if (!as.cap) {
+        as.cap = std::max<u64>(rows / 4, 1024);
+        for (auto& b : as.act) TRY(b.ensure(as.cap * 4));
+        TRY(as.prev.ensure(as.cap * 4));
+        TRY(as.cnt.ensure(32));
+    }
+    HIP_TRY(hipMemsetAsync(as.cnt.p, 0, 32, st));
+    const bool list = as.valid;
+    const u32* act = list ? as.act[as.cur].template as<u32>() : nullptr;
+    const u32 nact = list ? (u32)as.count : 0u;
+    *items = list ? as.count : rows;
+    *tied_in = 0;
+    if (list && as.count == 0) return MSUFSORT_HIP_OK;
+    if (list) hipLaunchKernelGGL(k_gather_prev, dim3(grid_for(as.count)), dim3(256), 0, st, d_grp_slice, act, as.count, as.prev.template as<u32>());
+    else HIP_TRY(hipMemcpyAsync(d_grp_prev_slice, d_grp_slice, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
     u64 t0 = 0;
     for (u32 p = 0; p < dg.npass; ++p) {
         u64 t = 0;
-        TRY((double_pass<W>(c, n, d_sa_slice, d_grp_slice, rows, d_isa, h, dg.shift[p], dg.mask[p], verbose, &t)));
+        TRY((double_pass<W>(c, n, d_sa_slice, d_grp_slice, rows, act, nact, d_isa, h, dg.shift[p], dg.mask[p], verbose, &t)));
         if (p == 0) t0 = t;
         if (t == 0) break;
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
     *tied_in = t0;
     return MSUFSORT_HIP_OK;
 }
 
-// rank updates of the rows [r0, r1) of a slice -> d_out (capacity `cap` updates); *count = updates, *tied = rows still tied
+// rank updates of the work items [i0, i1) of a slice -> d_out (capacity `cap` updates); *count = updates, *tied = rows of
+// the window that are still tied.  The window that ends at `items_total` closes the step: the next active list is adopted.
 template <bool W>
-int emit_updates(msufsort_hip_ctx* c, const typename Wd<W>::sa_t* d_sa_slice, const u32* d_grp_slice, const u32* d_grp_prev_slice, u64 rows, u64 slice_lo,
-                 u64 r0, u64 r1, u64* d_out, u64 cap, u64* count, u64* tied)
+int emit_updates(msufsort_hip_ctx* c, ActiveSet& as, const typename Wd<W>::sa_t* d_sa_slice, const u32* d_grp_slice, const u32* d_grp_prev_slice, u64 rows, u64 slice_lo,
+                 u64 i0, u64 i1, u64 items_total, u64* d_out, u64 cap, u64* count, u64* tied)
 {
-    TRY(c->upd_cnt.ensure(16));
-    HIP_TRY(hipMemsetAsync(c->upd_cnt.p, 0, 16, c->stream));
-    if (r1 > r0)
-        hipLaunchKernelGGL(k_emit_updates<W>, dim3(grid_for(r1 - r0, 256, 16384u)), dim3(256), 0, c->stream, d_sa_slice, d_grp_slice, d_grp_prev_slice, rows, r0, r1, slice_lo,
-                           d_out, cap, c->upd_cnt.as<unsigned long long>());
-    HIP_TRY(hipMemcpyAsync(c->h_upd, c->upd_cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipStream_t st = c->stream;
+    if (!as.cap || as.key_sa != (const void*)d_sa_slice) { set_error("emit_updates without a preceding double_sort on this slice"); return MSUFSORT_HIP_ERR_BAD_ARG; }
+    const bool list = as.valid;
+    unsigned long long* cnt = as.cnt.template as<unsigned long long>();
+    HIP_TRY(hipMemcpyAsync(c->h_upd, cnt, 16, hipMemcpyDeviceToHost, st));     // (cnt[0..1] accumulate over the windows of a step)
+    HIP_TRY(hipStreamSynchronize(st));
+    const u64 c0 = c->h_upd[0], t0 = c->h_upd[1];
+    if (i1 > i0) {
+        // updates are written from index 0 of d_out in every window: pass the buffer shifted back by what earlier windows counted
+        hipLaunchKernelGGL(k_emit_updates<W>, dim3(grid_for(i1 - i0, 256, 16384u)), dim3(256), 0, st, d_sa_slice, d_grp_slice,
+                           list ? as.prev.template as<u32>() : d_grp_prev_slice, list ? as.act[as.cur].template as<u32>() : (const u32*)nullptr,
+                           rows, i0, i1, slice_lo, d_out - (W ? 2 : 1) * c0, cap + c0, as.act[as.cur ^ 1].template as<u32>(), as.cap, cnt);
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_upd, cnt, 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
-    if (c->h_upd[0] > cap) { set_error("rank-update window overflow (%llu > %llu)", c->h_upd[0], (unsigned long long)cap); return MSUFSORT_HIP_ERR_INTERNAL; }
-    *count = c->h_upd[0]; *tied = c->h_upd[1];
+    if (c->h_upd[0] - c0 > cap) { set_error("rank-update window overflow (%llu > %llu)", c->h_upd[0] - c0, (unsigned long long)cap); return MSUFSORT_HIP_ERR_INTERNAL; }
+    *count = c->h_upd[0] - c0; *tied = c->h_upd[1] - t0;
+    if (i1 >= items_total) {          // step complete: adopt the list of still-tied rows (if it fitted)
+        as.valid = c->h_upd[3] == 0;
+        as.count = as.valid ? c->h_upd[2] : 0;
+        as.cur ^= 1;
+    }
     return MSUFSORT_HIP_OK;
 }
 
@@ -953,23 +999,26 @@ int build_logical(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* 
         const u64 win = std::min<u64>(n + 1, 1ull << 27);          // rows per rank-update window
         TRY(c->upd.ensure((size_t)win * (W ? 16 : 8)));
         std::vector<char> live(G, 1);
+        std::vector<u64> items(G, 0);
+        for (auto& a : c->active) a.release();
+        c->active.assign(G, ActiveSet());
         for (u64 h = depth;; h *= 2, ++steps) {
             u64 tied_total = 0;
             for (int g = 0; g < G; ++g) {
                 const u64 lo = sc.rows[g], hi = sc.rows[g + 1];
                 if (hi == lo || !live[g]) continue;
                 u64 t = 0;
-                TRY((double_sort<W>(c, n, d_sa + lo, grp + lo, grp_prev + lo, hi - lo, isa, h, verbose, &t)));
-                if (t == 0) live[g] = 0;           // (grp_prev == grp for this slice: no updates either)
+                TRY((double_sort<W>(c, c->active[g], n, d_sa + lo, grp + lo, grp_prev + lo, hi - lo, isa, h, verbose, &t, &items[g])));
+                if (t == 0) live[g] = 0;           // (nothing tied: no updates either)
             }
             // the ranks are read-only while ANY shard still sorts with them: the updates of all shards are applied afterwards
             for (int g = 0; g < G; ++g) {
                 const u64 lo = sc.rows[g], hi = sc.rows[g + 1];
                 if (hi == lo || !live[g]) continue;
-                for (u64 r0 = 0; r0 < hi - lo; r0 += win) {
-                    const u64 r1 = std::min(hi - lo, r0 + win);
+                for (u64 i0 = 0; i0 < items[g]; i0 += win) {
+                    const u64 i1 = std::min(items[g], i0 + win);
                     u64 cnt = 0, tied = 0;
-                    TRY((emit_updates<W>(c, d_sa + lo, grp + lo, grp_prev + lo, hi - lo, lo, r0, r1, c->upd.as<u64>(), win, &cnt, &tied)));
+                    TRY((emit_updates<W>(c, c->active[g], d_sa + lo, grp + lo, grp_prev + lo, hi - lo, lo, i0, i1, items[g], c->upd.as<u64>(), win, &cnt, &tied)));
                     TRY((apply_updates<W>(c, c->upd.as<u64>(), cnt, isa)));
                     tied_total += tied;
                 }
@@ -979,6 +1028,8 @@ int build_logical(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* 
             if (h > 2 * n + 2) { set_error("prefix doubling did not converge"); return MSUFSORT_HIP_ERR_INTERNAL; }
         }
         HIP_TRY(hipStreamSynchronize(st));
+        for (auto& a : c->active) a.release();
+        c->active.clear();
         dbl_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d).count();
     }
     HIP_TRY(hipStreamSynchronize(st));
@@ -1074,7 +1125,7 @@ int msufsort_hip_ctx_create(msufsort_hip_ctx** out, int32_t device, int64_t max_
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     (void)hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), C_NCOUNTERS * 4, hipHostMallocDefault);
     (void)hipHostMalloc(reinterpret_cast<void**>(&c->h_hist), 65536 * 8, hipHostMallocDefault);
-    (void)hipHostMalloc(reinterpret_cast<void**>(&c->h_upd), 16, hipHostMallocDefault);
+    (void)hipHostMalloc(reinterpret_cast<void**>(&c->h_upd), 64, hipHostMallocDefault);
     if (!c->h_counters || !c->h_hist || !c->h_upd) { msufsort_hip_ctx_destroy(c); set_error("hipHostMalloc failed"); return MSUFSORT_HIP_ERR_NOMEM; }
     if (max_n > 0) {
         int r = c->ensure_workspace((u64)max_n);
@@ -1242,32 +1293,34 @@ int msufsort_hip_isa_from_slice_dev(msufsort_hip_ctx* c, const void* d_sa_slice,
 
 int msufsort_hip_double_sort_dev(msufsort_hip_ctx* c, int64_t n, void* d_sa_slice, uint32_t* d_grp_slice, uint32_t* d_grp_prev_slice,
                                  int64_t lo, int64_t hi, const void* d_isa, int64_t h, int32_t index_bytes, const msufsort_hip_opts* opts,
-                                 int64_t* tied_before)
+                                 int64_t* tied_before, int64_t* emit_items)
 {
     if (!c || !d_sa_slice || !d_grp_slice || !d_grp_prev_slice || !d_isa || n <= 0 || lo < 0 || hi < lo || h <= 0 || (index_bytes != 4 && index_bytes != 8)) return MSUFSORT_HIP_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(c->device));
-    u64 t = 0;
+    u64 t = 0, items = 0;
     const int verbose = opts ? opts->verbose : 0;
     const auto t0 = std::chrono::steady_clock::now();
+    if (c->active.empty()) c->active.resize(1);
     if (hi > lo) {
-        if (index_bytes == 8) TRY((double_sort<true>(c, (u64)n, static_cast<u64*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), static_cast<const u64*>(d_isa), (u64)h, verbose, &t)));
-        else TRY((double_sort<false>(c, (u64)n, static_cast<u32*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), static_cast<const u32*>(d_isa), (u64)h, verbose, &t)));
+        if (index_bytes == 8) TRY((double_sort<true>(c, c->active[0], (u64)n, static_cast<u64*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), static_cast<const u64*>(d_isa), (u64)h, verbose, &t, &items)));
+        else TRY((double_sort<false>(c, c->active[0], (u64)n, static_cast<u32*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), static_cast<const u32*>(d_isa), (u64)h, verbose, &t, &items)));
     }
     c->tm.refine_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();     // this shard's sort work of the step
     if (tied_before) *tied_before = (int64_t)t;
+    if (emit_items) *emit_items = (int64_t)items;
     return MSUFSORT_HIP_OK;
 }
 
 int msufsort_hip_emit_updates_dev(msufsort_hip_ctx* c, const void* d_sa_slice, const uint32_t* d_grp_slice, const uint32_t* d_grp_prev_slice,
-                                  int64_t lo, int64_t hi, int64_t r0, int64_t r1, void* d_updates, int64_t capacity, int32_t index_bytes,
+                                  int64_t lo, int64_t hi, int64_t i0, int64_t i1, int64_t items_total, void* d_updates, int64_t capacity, int32_t index_bytes,
                                   int64_t* count, int64_t* tied_rows)
 {
-    if (!c || !d_sa_slice || !d_grp_slice || !d_grp_prev_slice || !d_updates || lo < 0 || hi < lo || r0 < 0 || r1 < r0 || r1 > hi - lo || capacity < 0 ||
-        (index_bytes != 4 && index_bytes != 8)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    if (!c || !d_sa_slice || !d_grp_slice || !d_grp_prev_slice || !d_updates || lo < 0 || hi < lo || i0 < 0 || i1 < i0 || i1 > items_total || items_total > hi - lo || capacity < 0 ||
+        (index_bytes != 4 && index_bytes != 8) || c->active.empty()) return MSUFSORT_HIP_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(c->device));
     u64 cnt = 0, tied = 0;
-    if (index_bytes == 8) TRY((emit_updates<true>(c, static_cast<const u64*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), (u64)lo, (u64)r0, (u64)r1, static_cast<u64*>(d_updates), (u64)capacity, &cnt, &tied)));
-    else TRY((emit_updates<false>(c, static_cast<const u32*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), (u64)lo, (u64)r0, (u64)r1, static_cast<u64*>(d_updates), (u64)capacity, &cnt, &tied)));
+    if (index_bytes == 8) TRY((emit_updates<true>(c, c->active[0], static_cast<const u64*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), (u64)lo, (u64)i0, (u64)i1, (u64)items_total, static_cast<u64*>(d_updates), (u64)capacity, &cnt, &tied)));
+    else TRY((emit_updates<false>(c, c->active[0], static_cast<const u32*>(d_sa_slice), d_grp_slice, d_grp_prev_slice, (u64)(hi - lo), (u64)lo, (u64)i0, (u64)i1, (u64)items_total, static_cast<u64*>(d_updates), (u64)capacity, &cnt, &tied)));
     if (count) *count = (int64_t)cnt;
     if (tied_rows) *tied_rows = (int64_t)tied;
     return MSUFSORT_HIP_OK;

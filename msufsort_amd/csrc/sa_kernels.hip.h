@@ -982,19 +982,25 @@ __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32
 // Stateless doubling step (MODE_DEFER): the segment records of a shard are rebuilt from its suffix-array rows with
 // identity placement - the record of (local) row r lives at rec[r] - and only for rows of groups larger than TINY_MAX
 // (grp[head + TINY_MAX] == head); rows of smaller groups travel through the tiny pool (k_import_groups + k_refill).
+// `act` (optional): the tied rows of the slice, in any order (ActiveSet in engine.hip); nullptr = all m rows.
 template <bool W>
 __global__ __launch_bounds__(256) void k_refill_rows(const typename Wd<W>::sa_t* __restrict__ sa_rows, const u32* __restrict__ grp, u32 m,
+                                                     const u32* __restrict__ act, u32 nact,
                                                      u64* __restrict__ rec, const typename Wd<W>::sa_t* __restrict__ isa, u64 n, KeySpec ks)
 {
     constexpr int U = 4;
-    for (u64 base = (u64)blockIdx.x * 256u * U + threadIdx.x; base < m; base += (u64)gridDim.x * 256u * U) {
+    const u32 cnt = act ? nact : m;
+    for (u64 base = (u64)blockIdx.x * 256u * U + threadIdx.x; base < cnt; base += (u64)gridDim.x * 256u * U) {
         typename Wd<W>::sa_t idx[U];
+        u32 row[U];
         bool v[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const u64 r = base + (u64)k * 256u;
-            v[k] = false; idx[k] = 0;
-            if (r < m) {
+            const u64 i = base + (u64)k * 256u;
+            v[k] = false; idx[k] = 0; row[k] = 0;
+            if (i < cnt) {
+                const u32 r = act ? act[i] : (u32)i;
+                row[k] = r;
                 const u32 g = grp[r];
                 v[k] = (u64)g + TINY_MAX < m && grp[g + TINY_MAX] == g;
                 if (v[k]) idx[k] = sa_rows[r];
@@ -1004,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_refill_rows(const typename Wd<W>::sa_t*
 #pragma unroll
         for (int k = 0; k < U; ++k) key[k] = v[k] ? rank_key<W>(isa, (u64)idx[k] + ks.depth, n, ks) : 0u;
 #pragma unroll
-        for (int k = 0; k < U; ++k) if (v[k]) rec[base + (u64)k * 256u] = make_rec<W>(key[k], idx[k]);
+        for (int k = 0; k < U; ++k) if (v[k]) rec[row[k]] = make_rec<W>(key[k], idx[k]);
     }
 }
 
@@ -1931,14 +1937,14 @@ __global__ __launch_bounds__(256) void k_isa_from_slice(const typename Wd<W>::sa
 // identity placement (record of row r at rec[r]) and are written, with their keys, by k_refill_rows.
 template <bool W>
 __global__ __launch_bounds__(256) void k_import_groups(const typename Wd<W>::sa_t* __restrict__ sa_local, const u32* __restrict__ grp_local, u32 m,
-                                                       u32 seg_buf,
+                                                       const u32* __restrict__ act, u32 nact, u32 seg_buf,
                                                        u64* __restrict__ pool_rec, u64* __restrict__ pool_hdr, u32 pool_cnt_idx, u32 pool_cap,
                                                        Lists lists, Desc* __restrict__ large, u32 large_cap, u32 large_cnt_idx, u32 large_tiles_idx,
                                                        u32* __restrict__ counters)
 {
-    const u64 lp64 = (u64)blockIdx.x * 256u + threadIdx.x;
-    const bool live = lp64 < m;
-    const u32 lp = live ? (u32)lp64 : 0u;
+    const u64 i64 = (u64)blockIdx.x * 256u + threadIdx.x;
+    const bool live = i64 < (act ? nact : m);
+    const u32 lp = live ? (act ? act[i64] : (u32)i64) : 0u;        // (the tail test below reads grp[lp + 1] itself: any order of `act` will do)
     u32 g = 0, len = 0;
     if (live) {
         g = grp_local[lp];
@@ -1977,37 +1983,41 @@ __global__ __launch_bounds__(256) void k_import_groups(const typename Wd<W>::sa_
     if (cls == 3) atomicAdd(&counters[large_tiles_idx], (len + P1_TILE - 1) / P1_TILE);
 }
 
-// Rank updates of one step for the rows [r0, r1) of a slice: every row whose group head differs from the one it had when
-// the step began (grp_prev) names a suffix whose rank changed.  An update is {suffix, new global head row}: one u64
-// (row << 32 | suffix) in narrow builds, two u64 in wide builds.  out_count[0] = pairs written (stops at cap: the caller
-// sizes the row window so that it cannot overflow), out_count[1] += rows of the window that are still tied.
+// Rank updates of one step for a window [i0, i1) of a slice's work items - rows (act == nullptr, compared with the full
+// copy grp_prev[row]) or entries of the active list (compared with prev[i], k_gather_prev): every row whose group head
+// differs from the one it had when the step began names a suffix whose rank changed.  An update is {suffix, new global
+// head row}: one u64 (row << 32 | suffix) in narrow builds, two u64 in wide builds.
+// cnt[0] = updates written (the caller sizes the window so that it cannot overflow), cnt[1] += rows still tied,
+// cnt[2] = length of next step's active list act_next (tied rows, unordered), cnt[3] = 1 if it did not fit act_cap.
 template <bool W>
-__global__ __launch_bounds__(256) void k_emit_updates(const typename Wd<W>::sa_t* __restrict__ sa_rows, const u32* __restrict__ grp, const u32* __restrict__ grp_prev,
-                                                      u64 rows, u64 r0, u64 r1, u64 slice_lo, u64* __restrict__ out, u64 cap,
-                                                      unsigned long long* __restrict__ out_count)
+__global__ __launch_bounds__(256) void k_emit_updates(const typename Wd<W>::sa_t* __restrict__ sa_rows, const u32* __restrict__ grp, const u32* __restrict__ prev,
+                                                      const u32* __restrict__ act, u64 rows, u64 i0, u64 i1, u64 slice_lo, u64* __restrict__ out, u64 cap,
+                                                      u32* __restrict__ act_next, u64 act_cap, unsigned long long* __restrict__ cnt)
 {
     __shared__ u32 s_cnt, s_tied;
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_base, s_abase;
     const u64 lt_mask = lane_id() ? (~0ull >> (64 - lane_id())) : 0ull;
-    for (u64 b = r0 + (u64)blockIdx.x * 256u; b < r1; b += (u64)gridDim.x * 256u) {
+    for (u64 b = i0 + (u64)blockIdx.x * 256u; b < i1; b += (u64)gridDim.x * 256u) {
         if (threadIdx.x == 0) { s_cnt = 0; s_tied = 0; }
         __syncthreads();
-        const u64 r = b + threadIdx.x;
+        const u64 i = b + threadIdx.x;
         bool chg = false, tied = false;
-        u32 g = 0;
-        if (r < r1) {
+        u32 g = 0, r = 0;
+        if (i < i1) {
+            r = act ? act[i] : (u32)i;
             g = grp[r];
-            chg = g != grp_prev[r];
-            tied = g != (u32)r || (r + 1 < rows && grp[r + 1] == (u32)r);
+            chg = g != prev[i];
+            tied = g != r || ((u64)r + 1 < rows && grp[r + 1] == r);
         }
         const u64 mc = __ballot(chg), mt = __ballot(tied);
-        u32 wbase = 0;
-        if (lane_id() == 0) { if (mc) wbase = atomicAdd(&s_cnt, (u32)__popcll(mc)); if (mt) atomicAdd(&s_tied, (u32)__popcll(mt)); }
-        wbase = __shfl(wbase, 0, 64);
+        u32 wbase = 0, tbase = 0;
+        if (lane_id() == 0) { if (mc) wbase = atomicAdd(&s_cnt, (u32)__popcll(mc)); if (mt) tbase = atomicAdd(&s_tied, (u32)__popcll(mt)); }
+        wbase = __shfl(wbase, 0, 64); tbase = __shfl(tbase, 0, 64);
         __syncthreads();
         if (threadIdx.x == 0) {
-            s_base = s_cnt ? atomicAdd(&out_count[0], (unsigned long long)s_cnt) : 0ull;
-            if (s_tied) atomicAdd(&out_count[1], (unsigned long long)s_tied);
+            s_base = s_cnt ? atomicAdd(&cnt[0], (unsigned long long)s_cnt) : 0ull;
+            s_abase = 0;
+            if (s_tied) { atomicAdd(&cnt[1], (unsigned long long)s_tied); if (act_next) s_abase = atomicAdd(&cnt[2], (unsigned long long)s_tied); }
         }
         __syncthreads();
         if (chg) {
@@ -2017,8 +2027,18 @@ __global__ __launch_bounds__(256) void k_emit_updates(const typename Wd<W>::sa_t
                 else out[o] = ((slice_lo + g) << 32) | (u64)sa_rows[r];
             }
         }
+        if (tied && act_next) {
+            const u64 o = s_abase + tbase + (u32)__popcll(mt & lt_mask);
+            if (o < act_cap) act_next[o] = r; else cnt[3] = 1ull;
+        }
         __syncthreads();
     }
+}
+
+// prev[i] = group head of active row act[i] when the step begins
+__global__ __launch_bounds__(256) void k_gather_prev(const u32* __restrict__ grp, const u32* __restrict__ act, u64 nact, u32* __restrict__ prev)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < nact; i += (u64)gridDim.x * 256u) prev[i] = grp[act[i]];
 }
 
 template <bool W>

@@ -139,20 +139,25 @@ def _distributed_doubling(ctx, n, d_sa_full, d_grp_full, bounds, rank, world, di
             ctx.isa_from_slice(d_sa_full[bounds[g]:bounds[g + 1]], d_grp_full[bounds[g]:bounds[g + 1]], bounds[g], bounds[g + 1], isa, index_bytes)
     st = {"doubling_steps": 0, "sort_ms": 0.0, "exchange_ms": 0.0, "updates": 0, "depth": depth}
     win = state.win
-    nwin = (rows_max + win - 1) // win
     h = depth
     live = hi > lo
     while True:
+        items = 0
         if live:
-            live = ctx.double_sort(n, sl, gl, gp, lo, hi, isa, h, index_bytes, verbose) > 0
+            tied_before, items = ctx.double_sort(n, sl, gl, gp, lo, hi, isa, h, index_bytes, verbose)
+            live = tied_before > 0
             st["sort_ms"] += ctx.timings().refine_ms
+        nw = torch.tensor([(items + win - 1) // win if live else 0], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(nw, op=dist.ReduceOp.MAX)        # every rank walks the same number of exchange windows
+        nwin = int(nw.item())
         tied_local = 0
         for w in range(nwin):
             cnt = tied = 0
-            if live:
-                r0 = min(w * win, hi - lo)
-                r1 = min(r0 + win, hi - lo)
-                cnt, tied = ctx.emit_updates(sl, gl, gp, lo, hi, r0, r1, state.upd_local, win, index_bytes)
+            if live and w * win < items:
+                i0 = w * win
+                i1 = min(i0 + win, items)
+                cnt, tied = ctx.emit_updates(sl, gl, gp, lo, hi, i0, i1, items, state.upd_local, win, index_bytes)
             tied_local += tied
             t0 = time.perf_counter()
             counts = torch.zeros(world, dtype=torch.int64, device=dev)

@@ -264,13 +264,22 @@ def test_sharded_doubling_pieces(M, oracle_mod, shards):
             ctxs[g].isa_from_slice(full[bounds[g]:bounds[g + 1]], grp[bounds[g]:bounds[g + 1]], bounds[g], bounds[g + 1], isa)
         h, steps = depth, 0
         while True:
+            items = [0] * shards
             for g in range(shards):
                 lo, hi = bounds[g], bounds[g + 1]
-                ctxs[g].double_sort(n, full[lo:hi], grp[lo:hi], prev[lo:hi], lo, hi, isa, h)
+                items[g] = ctxs[g].double_sort(n, full[lo:hi], grp[lo:hi], prev[lo:hi], lo, hi, isa, h)[1]
             tied = 0
             for g in range(shards):      # the rank array is read-only until every shard has sorted
                 lo, hi = bounds[g], bounds[g + 1]
-                cnt, td = ctxs[g].emit_updates(full[lo:hi], grp[lo:hi], prev[lo:hi], lo, hi, 0, hi - lo, upd, n + 1)
+                if items[g] == 0:
+                    continue
+                half = (items[g] + 1) // 2           # two windows per shard: the window mechanics of a bounded exchange buffer
+                cnt, td = ctxs[g].emit_updates(full[lo:hi], grp[lo:hi], prev[lo:hi], lo, hi, 0, half, items[g], upd, n + 1)
+                ctxs[g].apply_updates(upd, cnt, isa)
+                tied += td
+                if half == items[g]:
+                    continue
+                cnt, td = ctxs[g].emit_updates(full[lo:hi], grp[lo:hi], prev[lo:hi], lo, hi, half, items[g], items[g], upd, n + 1)
                 ctxs[g].apply_updates(upd, cnt, isa)
                 tied += td
             steps += 1
