@@ -72,7 +72,10 @@ typedef struct msufsort_hip_timings {
     int32_t rounds;            /* rounds after round 0 */
     int32_t doubling_rounds;
     int64_t unresolved_after_round0;
-    int64_t reserved[8];       /* [0] depth at which a sharded build stopped its key rounds, [1] logical shards of the last build */
+    int64_t reserved[8];       /* [0] depth at which a sharded build stopped its key rounds, [1] logical shards of the last build,
+                                  [2] records whose key was gathered, summed over the rounds after round 0 (each: 4 B index read,
+                                  one 64 B sector of text or ranks, 8 B record written, 4 B row written by the sorts),
+                                  [3] inverse BWT: microseconds of the chain walk (k_ibwt_walk), [4] of the whole inverse */
 } msufsort_hip_timings;
 
 int msufsort_hip_device_count(void);

@@ -784,6 +784,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         DBG("k_refill");
         if (R.mode == MODE_TEXT) depth += ks.cpk; else { depth *= 2; tm.doubling_rounds++; }
         tm.rounds++;
+        tm.reserved[2] += (int64_t)(actP + actS);          // records whose next key was gathered (roofline of the key rounds)
     }
     finish_groups();
     HIP_TRY(hipEventRecord(c->ev[5], st));
