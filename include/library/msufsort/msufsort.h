@@ -44,7 +44,12 @@ namespace maniscalco
         {
             auto n = static_cast<std::int64_t>(inputEnd - inputBegin);
             suffix_array sa(static_cast<std::size_t>(n) + 1);
-            check(::msufsort_hip_make_sa_i32_ctx(ctx(), inputBegin, n, sa.data(), nullptr), "make_suffix_array");
+            // large inputs: every visible GPU (or MSUFSORT_DEVICES) sorts a range of buckets, finished slices stream to the
+            // host while the rest is sorted; small ones: this instance's context (lowest latency)
+            if (n >= (std::int64_t(32) << 20))
+                check(::msufsort_hip_make_sa_multi(nullptr, 0, inputBegin, n, sa.data(), 4, nullptr, nullptr), "make_suffix_array");
+            else
+                check(::msufsort_hip_make_sa_i32_ctx(ctx(), inputBegin, n, sa.data(), nullptr), "make_suffix_array");
             return sa;
         }
 

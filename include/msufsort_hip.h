@@ -88,6 +88,10 @@ void msufsort_hip_ctx_destroy(msufsort_hip_ctx* ctx);
 void* msufsort_hip_ctx_stream(msufsort_hip_ctx* ctx);  /* hipStream_t, for hipEvent timing */
 int msufsort_hip_ctx_sync(msufsort_hip_ctx* ctx);
 int msufsort_hip_ctx_trim(msufsort_hip_ctx* ctx);      /* frees the workspace (it is rebuilt on demand) */
+/* The host-pointer entry points without a context argument (and msufsort_hip_make_sa_multi) keep their contexts - stream
+ * and workspace - for the life of the process, as the reference keeps its worker pool per instance (msufsort.h:311-388);
+ * this frees the idle ones. */
+void msufsort_hip_release_cached(void);
 int msufsort_hip_last_timings(msufsort_hip_ctx* ctx, msufsort_hip_timings* out);
 
 /* ---- suffix array: replaces msufsort::make_suffix_array (reference msufsort.cpp:1730-1767,
@@ -171,6 +175,17 @@ int msufsort_hip_make_sa_i64_ctx(msufsort_hip_ctx* ctx, const uint8_t* text, int
                                  const msufsort_hip_opts* opts);
 int msufsort_hip_make_sa_i64_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
                                  int64_t* d_sa_out /* n+1 */, const msufsort_hip_opts* opts);
+
+/* ---- one process, several GPUs (SURVEY 8(b) "device list / count ... defaulting to all visible GPUs", 8(e)) ----
+ * Host text in, host suffix array out (n + 1 entries of index_bytes = 4, or 8 for inputs beyond 2^31 - 2 bytes / force_wide).
+ * devices == NULL or n_dev == 0: the list in the environment variable MSUFSORT_DEVICES ("0,1,..."), else all visible GPUs.
+ * One host thread per device; every device sorts its key ranges and each
+ * finished slice leaves for the host while the next one is sorted (with ONE device this is the streaming host path: the
+ * D2H of 4(n+1) bytes overlaps the remaining sorts).  Deep ties: distributed prefix doubling, rank updates exchanged with
+ * peer-to-peer copies over xGMI.  opts->n_shards: total number of key-range shards (default: 8 per device from 64 MiB on).
+ * Replaces the cost the reference pays at msufsort.cpp:1754-1758 (allocation + first touch of the result). */
+int msufsort_hip_make_sa_multi(const int32_t* devices, int32_t n_dev, const uint8_t* text, int64_t n, void* sa_out,
+                               int32_t index_bytes, const msufsort_hip_opts* opts, msufsort_hip_timings* timings_out);
 
 /* Host-only helper used by the two calls above (no device work): balanced key-range cuts from the
  * exclusive prefix bstart[65537] of the 16-bit histogram; cuts/rows have n_shards+1 entries. */

@@ -37,7 +37,7 @@ SYMBOLS = [
     "msufsort_hip_make_sa_shard_dev", "msufsort_hip_shard_bounds_dev", "msufsort_hip_plan_cuts",
     "msufsort_hip_make_sa_shard_groups_dev", "msufsort_hip_make_sa_shard_groups_i64_dev", "msufsort_hip_isa_from_slice_dev",
     "msufsort_hip_double_sort_dev", "msufsort_hip_emit_updates_dev", "msufsort_hip_apply_updates_dev", "msufsort_hip_ctx_trim",
-    "msufsort_hip_validate_sa_i64_dev", "msufsort_hip_bwt_from_sa_i64_dev", "msufsort_hip_forward_bwt",
+    "msufsort_hip_validate_sa_i64_dev", "msufsort_hip_bwt_from_sa_i64_dev", "msufsort_hip_make_sa_multi", "msufsort_hip_release_cached", "msufsort_hip_forward_bwt",
     "msufsort_hip_forward_bwt_dev", "msufsort_hip_bwt_from_sa_dev", "msufsort_hip_inverse_bwt",
     "msufsort_hip_inverse_bwt_dev", "msufsort_hip_lcp_i32", "msufsort_hip_lcp_i32_dev",
     "msufsort_hip_validate_sa_dev", "msufsort_hip_debug_hist16_dev",
@@ -91,6 +91,8 @@ def lib():
     L.msufsort_hip_emit_updates_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, vp, i64, i32, C.POINTER(i64), C.POINTER(i64)]
     L.msufsort_hip_apply_updates_dev.argtypes = [vp, vp, i64, vp, i32]
     L.msufsort_hip_ctx_trim.argtypes = [vp]
+    L.msufsort_hip_release_cached.restype = None
+    L.msufsort_hip_make_sa_multi.argtypes = [vp, i32, vp, i64, vp, i32, C.POINTER(Opts), C.POINTER(Timings)]
     L.msufsort_hip_validate_sa_i64_dev.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
     L.msufsort_hip_bwt_from_sa_i64_dev.argtypes = [vp, vp, i64, vp, vp, C.POINTER(i64)]
     L.msufsort_hip_shard_bounds_dev.argtypes = [vp, vp, i64, i32, C.POINTER(i64)]

@@ -8,7 +8,13 @@
 #include "../../include/msufsort_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -1077,10 +1083,46 @@ int check_n64(int64_t n)
     return MSUFSORT_HIP_OK;
 }
 
-// temporary context for the host-pointer entry points
+// Contexts of the host-pointer entry points (the one-shot functions and msufsort_hip_make_sa_multi): kept for the life of
+// the process and handed out exclusively - creating one costs a stream and, on first use, the hipMalloc of the workspace
+// (seconds for a 1 GiB input), which the reference pays once per msufsort instance for its worker pool (msufsort.h:311-388)
+// and a one-shot call here must not pay every time.  msufsort_hip_release_cached() frees them.
+struct CtxPool {
+    struct Slot { int device; msufsort_hip_ctx* c; bool busy; };
+    std::mutex mu;
+    std::vector<Slot> slots;
+    int acquire(int device, msufsort_hip_ctx** out)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto& s : slots) if (s.device == device && !s.busy) { s.busy = true; *out = s.c; return MSUFSORT_HIP_OK; }
+        }
+        msufsort_hip_ctx* c = nullptr;
+        TRY(msufsort_hip_ctx_create(&c, device, 0));
+        std::lock_guard<std::mutex> lk(mu);
+        slots.push_back({device, c, true});
+        *out = c;
+        return MSUFSORT_HIP_OK;
+    }
+    void release(msufsort_hip_ctx* c)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& s : slots) if (s.c == c) s.busy = false;
+    }
+    void clear()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        std::vector<Slot> keep;
+        for (auto& s : slots) { if (s.busy) keep.push_back(s); else msufsort_hip_ctx_destroy(s.c); }
+        slots.swap(keep);
+    }
+};
+CtxPool g_pool;
+
 struct TmpCtx {
     msufsort_hip_ctx* c = nullptr;
-    ~TmpCtx() { if (c) msufsort_hip_ctx_destroy(c); }
+    int acquire(int device) { return g_pool.acquire(device, &c); }
+    ~TmpCtx() { if (c) g_pool.release(c); }
 };
 
 }  // namespace
@@ -1158,6 +1200,8 @@ int msufsort_hip_ctx_sync(msufsort_hip_ctx* c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MSUFSORT_HIP_OK;
 }
+
+void msufsort_hip_release_cached(void) { g_pool.clear(); }
 
 int msufsort_hip_ctx_trim(msufsort_hip_ctx* c)
 {
@@ -1358,7 +1402,7 @@ int msufsort_hip_make_sa_i32(const uint8_t* text, int64_t n, int32_t* sa_out, co
     TRY(check_n(n));
     if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
     TmpCtx t;
-    TRY(msufsort_hip_ctx_create(&t.c, opts ? opts->device : 0, 0));
+    TRY(t.acquire(opts ? opts->device : 0));
     return msufsort_hip_make_sa_i32_ctx(t.c, text, n, sa_out, opts);
 }
 
@@ -1406,7 +1450,7 @@ int msufsort_hip_make_sa_i64(const uint8_t* text, int64_t n, int64_t* sa_out, co
     TRY(check_n64(n));
     if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
     TmpCtx t;
-    TRY(msufsort_hip_ctx_create(&t.c, opts ? opts->device : 0, 0));
+    TRY(t.acquire(opts ? opts->device : 0));
     return msufsort_hip_make_sa_i64_ctx(t.c, text, n, sa_out, opts);
 }
 
@@ -1435,3 +1479,5 @@ int msufsort_hip_debug_hist16_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t 
 #include "bwt_host.inc"
 
 }  // extern "C"
+
+#include "multi_host.inc"

@@ -459,3 +459,19 @@ def test_forced_retry_keeps_carried_segments(M, oracle_mod, monkeypatch, kind):
     monkeypatch.setenv("MSUFSORT_HIP_FORCE_RETRY", "1")
     assert (M.make_suffix_array(t) == want).all()
     assert (M.make_suffix_array(t, text_rounds=2) == want).all()
+
+
+@pytest.mark.parametrize("devices,shards", [([0], 0), ([0, 0], 0), ([0, 0, 0], 6), ([0, 0], 8)])
+def test_single_process_multi_gpu_entry(M, oracle_mod, devices, shards):
+    """msufsort_hip_make_sa_multi (host text in, host rows out): one host thread per listed device (the one GPU of the box,
+    listed several times), key-range shards per device, finished slices streamed to the host, distributed doubling with
+    peer copies for deep ties - bit-exact against the reference, narrow and wide."""
+    cases = [gen.random_bytes((1 << 21) + 77, 8), gen.text_bytes(1 << 20, 12)] + _deep_inputs()
+    for t in cases:
+        sa, tm = M.make_suffix_array_multi(t, devices, n_shards=shards, text_rounds=1, timings=True)
+        assert (sa == _want(oracle_mod, t)).all(), (t.size, devices, shards)
+        assert tm.reserved[1] == (shards if shards else len(devices) * (8 if t.size >= (64 << 20) else 1))
+    t = gen.dna_tandem_bytes(500000, 3)
+    sa = M.make_suffix_array_multi(t, devices, n_shards=shards, index_bytes=8, force_wide=True)
+    assert sa.dtype == np.int64 and (sa == _want(oracle_mod, t)).all()
+    assert M.make_suffix_array_multi(np.zeros(0, np.uint8), devices).tolist() == [0]
