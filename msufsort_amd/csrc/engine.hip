@@ -93,6 +93,8 @@ struct msufsort_hip_ctx {
     DevBuf alpha, seg0_base, stripe_sums, hist_partial, hist, hist_clip, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
     DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, aux3, doneB, doneC;
     std::vector<ActiveSet> active;                // per logical shard (index 0: the per-shard C-ABI pieces)
+    DevBuf sub_partial, sub_hist, sub_saved;      // deeper histogram of ONE two-byte key (shard boundaries inside heavy keys)
+    int64_t sub_key = -1;                         // which key sub_partial describes (-1: none); valid for the current text only
     DevBuf grp_full, grp_prev, upd, upd_cnt;      // single-process sharded builds: tie-group heads (all rows), their copy at the
                                                   // start of a doubling step, rank updates of one row window
     u32* h_counters = nullptr;   // pinned
@@ -122,7 +124,8 @@ struct msufsort_hip_ctx {
     int set_attrs()
     {
         if (attrs_set) return MSUFSORT_HIP_OK;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan16), hipFuncAttributeMaxDynamicSharedMemorySize, SCAN16_LDS_BYTES));
         TRY(set_mid_attrs<false>());
         TRY(set_mid_attrs<true>());
@@ -196,6 +199,7 @@ struct msufsort_hip_ctx {
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
         grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release();
+        sub_partial.release(); sub_hist.release(); sub_saved.release(); sub_key = -1;
         for (auto& a : active) a.release();
         active.clear();
         cap_m = 0; cap_for_m = 0;
@@ -303,19 +307,55 @@ int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
     TRY(c->set_attrs());          // (k_hist16 takes 136 KiB of dynamic LDS; shard planning reaches this before any build)
     TRY(c->ensure_fixed(hchunks));
     c->nchunks = nchunks; c->chunk_len = (u32)chunk_len; c->hist_per = per;
-    hipLaunchKernelGGL(k_hist16, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>());
+    c->sub_key = -1;
+    hipLaunchKernelGGL(k_hist16<false>, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>(), 0u);
     hipLaunchKernelGGL(k_reduce16<W>, dim3(256), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), hchunks, c->hist.as<typename Wd<W>::hist_t>());
     HIP_TRY(hipGetLastError());
     return MSUFSORT_HIP_OK;
 }
 
+// deeper histogram (next two bytes) of the suffixes that start with the two-byte key `key`; per-chunk partials stay in
+// c->sub_partial, the totals (big-endian sub-key order) go to c->sub_hist
 template <bool W>
-void run_scan(msufsort_hip_ctx* c, u32 klo, u32 khi, u64 z)
+int run_subhist(msufsort_hip_ctx* c, const u8* d_text, u64 m, u32 key)
 {
-    const u32* h32 = c->hist.as<u32>();
-    if (W) {   // 64-bit global counts -> the shard's own 32-bit counts (everything outside [klo, khi) reads as 0)
-        hipLaunchKernelGGL(k_hist_clip, dim3(256), dim3(256), 0, c->stream, c->hist.as<u64>(), klo, khi, c->hist_clip.as<u32>(), c->counters.as<u32>());
-        h32 = c->hist_clip.as<u32>();
+    if (c->sub_key == (int64_t)key) return MSUFSORT_HIP_OK;
+    const u32 hchunks = c->nchunks * c->hist_per;
+    TRY(c->sub_partial.ensure((size_t)hchunks * 65536 * 4));
+    TRY(c->sub_hist.ensure(65536 * 8));
+    hipLaunchKernelGGL(k_hist16<true>, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, c->chunk_len / c->hist_per, hchunks, c->sub_partial.as<u32>(),
+                       (key >> 8) | ((key & 255u) << 8));
+    hipLaunchKernelGGL(k_reduce16<W>, dim3(256), dim3(256), 0, c->stream, c->sub_partial.as<u32>(), hchunks, c->sub_hist.as<typename Wd<W>::hist_t>());
+    HIP_TRY(hipGetLastError());
+    c->sub_key = (int64_t)key;
+    return MSUFSORT_HIP_OK;
+}
+
+// offsets and scatter set-up for the shard that owns the 4-byte prefixes [lo32, hi32)
+template <bool W>
+int run_scan(msufsort_hip_ctx* c, const u8* d_text, u64 m, u64 lo32, u64 hi32, u64 z)
+{
+    const u32 klo = (u32)(lo32 >> 16), khi = (u32)((hi32 + 0xffffull) >> 16);
+    const u32 hchunks = c->nchunks * c->hist_per;
+    hipLaunchKernelGGL(k_hist_clip<W>, dim3(256), dim3(256), 0, c->stream, c->hist.as<typename Wd<W>::hist_t>(), klo, khi, c->hist_clip.as<u32>(), c->counters.as<u32>());
+    const u32* h32 = c->hist_clip.as<u32>();
+    // boundary keys owned in part (a shard boundary inside a heavy two-byte key): in-range counts, globally and per chunk
+    u32 fix_key[2]; u32 nfix = 0;
+    if (khi > klo) {
+        const bool flo = (lo32 & 0xffffull) != 0, fhi = (hi32 & 0xffffull) != 0;
+        if (flo) fix_key[nfix++] = klo;
+        if (fhi && !(flo && khi - 1 == klo)) fix_key[nfix++] = khi - 1;
+        if (nfix) TRY(c->sub_saved.ensure((size_t)2 * hchunks * 4));
+        for (u32 f = 0; f < nfix; ++f) {
+            const u32 bk = fix_key[f];
+            const u32 sublo = (bk == klo && flo) ? (u32)(lo32 & 0xffffull) : 0u;
+            const u32 subhi = (bk == khi - 1 && fhi) ? (u32)(hi32 & 0xffffull) : 65536u;
+            TRY(run_subhist<W>(c, d_text, m, bk));
+            HIP_TRY(hipMemsetAsync(c->hist_clip.as<u32>() + bk, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_sub_fix, dim3(hchunks), dim3(256), 0, c->stream, c->sub_partial.as<u32>(), sublo, subhi, bk, c->hist_partial.as<u32>(),
+                               c->sub_saved.as<u32>() + (size_t)f * hchunks, c->hist_clip.as<u32>() + bk);
+            // (a second boundary key reuses the one sub-histogram buffer: stream order keeps this k_sub_fix ahead of its refill)
+        }
     }
     hipLaunchKernelGGL(k_scan16, dim3(1), dim3(1024), SCAN16_LDS_BYTES, c->stream, h32, c->bstart.as<u32>(), klo, khi,
                        c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->seg0_base.as<u32>(),
@@ -327,6 +367,10 @@ void run_scan(msufsort_hip_ctx* c, u32 klo, u32 khi, u64 z)
     hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks * 4), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), c->hist_per, klo, khi, c->stripe_sums.as<u32>());
     hipLaunchKernelGGL(k_stripes, dim3(256), dim3(128), 0, c->stream, c->stripe_sums.as<u32>(), c->nchunks,
                        c->seg0_base.as<u32>(), c->cursor0.as<u32>());
+    for (u32 f = 0; f < nfix; ++f)      // the per-chunk partials serve every shard of this text: put the full counts back
+        hipLaunchKernelGGL(k_sub_restore, dim3(cdiv(hchunks, 256)), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), c->sub_saved.as<u32>() + (size_t)f * hchunks, hchunks, fix_key[f]);
+    HIP_TRY(hipGetLastError());
+    return MSUFSORT_HIP_OK;
 }
 
 // Host-only: split the 16-bit key space into n_shards count-balanced contiguous ranges.
@@ -346,27 +390,58 @@ void plan_cuts64(const u64* bstart, u64 n, u64 z, int n_shards, u32* cuts, u64* 
 }
 
 struct ShardCuts {
-    std::vector<u32> cuts;       // first 16-bit key of every shard (n_shards + 1)
+    std::vector<u64> cuts;       // first 4-byte prefix (big-endian, as a number) of every shard; 2^32 closes the last one
     std::vector<u64> rows;       // first suffix-array row of every shard
     std::vector<u64> rank0;      // global rank (row - 1) of every shard's first radix-sorted suffix
 };
 
 // Runs the histogram, brings it to the host and plans the shards.  Leaves the histogram on the device (hist_done).
+// A cut that the two-byte keys can only place far behind its balanced target (a key heavier than 1/16 of a shard straddles
+// it: DNA has 16 such keys, text has "e ", " t", ...) is refined with the deeper histogram of that key (next two bytes,
+// one more pass over the text): the shard boundary then lies inside the key (the reference's analogue is
+// largest-partition-first scheduling, cpp:1657-1678).
 template <bool W>
 int plan_shards(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64 z, int n_shards, ShardCuts& sc)
 {
     const u64 m = n - z;
     sc.cuts.assign(n_shards + 1, 0); sc.rows.assign(n_shards + 1, 0); sc.rank0.assign(n_shards + 1, z);
-    sc.cuts[n_shards] = 65536; sc.rows[n_shards] = n + 1;
-    if (m == 0) { for (int g = 1; g < n_shards; ++g) { sc.cuts[g] = 65536; sc.rows[g] = n + 1; } return MSUFSORT_HIP_OK; }
+    sc.cuts[n_shards] = 1ull << 32; sc.rows[n_shards] = n + 1;
+    if (m == 0) { for (int g = 1; g < n_shards; ++g) { sc.cuts[g] = 1ull << 32; sc.rows[g] = n + 1; } return MSUFSORT_HIP_OK; }
     TRY(run_hist<W>(c, d_text, m));
     HIP_TRY(hipMemcpyAsync(c->h_hist, c->hist.p, 65536 * sizeof(typename Wd<W>::hist_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<u64> bs(65537);
     bs[0] = 0;
     for (u32 k = 0; k < 65536; ++k) bs[k + 1] = bs[k] + (W ? c->h_hist[k] : (u64)reinterpret_cast<const u32*>(c->h_hist)[k]);
-    plan_cuts64(bs.data(), n, z, n_shards, sc.cuts.data(), sc.rows.data());
-    for (int g = 0; g <= n_shards; ++g) sc.rank0[g] = z + bs[sc.cuts[g]];
+    const bool refine = getenv("MSUFSORT_HIP_NO_REFINE") == nullptr;
+    const u64 tol = std::max<u64>(m / ((u64)n_shards * 16), 1);
+    std::vector<u64> sp;             // prefix of the deeper histogram of key `sp_key`
+    int64_t sp_key = -1;
+    for (int g = 1; g < n_shards; ++g) {
+        const u64 target = (u64)((unsigned __int128)m * (u64)g / (u64)n_shards);
+        u32 k = (u32)(std::lower_bound(bs.begin(), bs.begin() + 65536, target) - bs.begin());      // first key boundary at or behind the target
+        u64 cut = (u64)k << 16, before = bs[k];
+        if (refine && k > 0 && bs[k] - target > tol) {
+            const u32 kk = k - 1;                                 // the key that straddles the target
+            if (sp_key != (int64_t)kk) {
+                TRY(run_subhist<W>(c, d_text, m, kk));
+                HIP_TRY(hipMemcpyAsync(c->h_hist, c->sub_hist.p, 65536 * sizeof(typename Wd<W>::hist_t), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                sp.assign(65537, 0);
+                for (u32 q = 0; q < 65536; ++q) sp[q + 1] = sp[q] + (W ? c->h_hist[q] : (u64)reinterpret_cast<const u32*>(c->h_hist)[q]);
+                sp_key = kk;
+                if (sp[65536] != bs[kk + 1] - bs[kk]) { set_error("deeper histogram of key %u disagrees with the 16-bit histogram", kk); return MSUFSORT_HIP_ERR_INTERNAL; }
+            }
+            const u64 want = target - bs[kk];
+            const u32 q = (u32)(std::lower_bound(sp.begin(), sp.begin() + 65536, want) - sp.begin());
+            cut = ((u64)kk << 16) + q; before = bs[kk] + sp[q];
+        }
+        if (cut < sc.cuts[g - 1]) { cut = sc.cuts[g - 1]; before = sc.rank0[g - 1] - z; }
+        sc.cuts[g] = cut;
+        sc.rows[g] = 1 + z + before;
+        sc.rank0[g] = z + before;
+    }
+    sc.rank0[n_shards] = z + m;
     return MSUFSORT_HIP_OK;
 }
 
@@ -391,7 +466,7 @@ struct Rounds {
     u32 mode = MODE_TEXT;
     int round = 0;
     u32 discard = 0;
-    u32 klo = 0, khi = 65536;
+    u32 klo = 0, khi = 65536;        // two-byte keys the shard touches (skew forecast only)
     u32 cpk = W ? 3u : 4u;
     int verbose = 0;
     bool exact_sticky = false, fast_gave_up = false, force_retry = false, no_pack = false;
@@ -641,9 +716,10 @@ struct Rounds {
 #define MSUFSORT_HIP_UNRESOLVED 1
 template <bool W>
 int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_rows /* row 0 of this shard's slice */, u64 slice_row_lo,
-             u64 z, u32 klo, u32 khi, u64 rank0, bool with_head, const msufsort_hip_opts* opts, bool hist_done,
+             u64 z, u64 lo32, u64 hi32, u64 rank0, bool with_head, const msufsort_hip_opts* opts, bool hist_done,
              u32* d_grp_rows = nullptr, u64 slice_rows = 0)
 {
+    const u32 klo = (u32)(lo32 >> 16), khi = (u32)((hi32 + 0xffffull) >> 16);
     typedef typename Wd<W>::sa_t sa_t;
     const int verbose = opts ? opts->verbose : 0;
     const bool sharded = W || (opts && opts->n_shards > 1);
@@ -657,6 +733,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     memset(&tm, 0, sizeof tm);
     tm.n = (int64_t)n; tm.m = (int64_t)m;
     TRY(c->set_attrs());
+    for (auto& a : c->active) a.valid = false;      // lists of still-tied rows belong to the previous build's doubling steps
     HIP_TRY(hipEventRecord(c->ev[0], st));
     if (with_head) hipLaunchKernelGGL(k_sa_head<W>, dim3(grid_for(std::max<u64>(z, 1))), dim3(256), 0, st, d_sa_rows, n, z);
     auto finish_groups = [&]() { if (d_grp_rows && slice_rows) hipLaunchKernelGGL(k_grp_iota, dim3(grid_for(slice_rows)), dim3(256), 0, st, d_grp_rows, slice_rows, 0u); };
@@ -677,12 +754,12 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     if (!hist_done) TRY(run_hist<W>(c, d_text, m));
     HIP_TRY(hipMemsetAsync(counters, 0, C_NCOUNTERS * 4, st));
     HIP_TRY(hipEventRecord(c->ev[1], st));
-    run_scan<W>(c, klo, khi, z);
+    TRY(run_scan<W>(c, d_text, m, lo32, hi32, z));
     R.bufs = RecBufs{{c->rec[0].as<u64>(), c->rec[1].as<u64>(), c->rec[2].as<u64>()}};
     RecBufs& bufs = R.bufs;
     sa_t* sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
     R.sa_local = sa_local;
-    hipLaunchKernelGGL(k_scatter0<W>, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, m, klo, khi, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0], c->alpha.as<u8>(), counters, R.no_pack ? 0u : 1u);
+    hipLaunchKernelGGL(k_scatter0<W>, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, m, lo32, hi32, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0], c->alpha.as<u8>(), counters, R.no_pack ? 0u : 1u);
     HIP_TRY(hipEventRecord(c->ev[2], st));
     DBG("k_scatter0");
     hipLaunchKernelGGL(k_partition, dim3(cdiv(cdiv(ms, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
@@ -1233,7 +1310,7 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     msufsort_hip_opts o{};
     if (opts) o = *opts;
     o.n_shards = 1; o.shard = 0;
-    return build_sa<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 65536, z, true, &o, false);
+    return build_sa<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 1ull << 32, z, true, &o, false);
 }
 
 int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t n_shards, int64_t* bounds)

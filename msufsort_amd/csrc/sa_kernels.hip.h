@@ -232,19 +232,34 @@ __device__ __forceinline__ void push_desc(const Lists& L, u32* counters, u32 cls
 #define H16_OVF_CAP 1024u    // >= max chunk_len / H16_FLUSH (chunk_len <= 16 MiB)
 #define H16_LDS_BYTES (131072u + H16_OVF_CAP * 8u + 64u)
 
-__device__ __forceinline__ void h16_add(u32* h_lds, u32 lo, u32 hi, int j)
+// two bytes at byte offset o of the little-endian word stream w[]
+__device__ __forceinline__ u32 h16_key(const u32* w, int o)
 {
-    const int s = j & 3;                                     // key' = bytes j, j+1 of the stream lo | hi << 32
-    const u32 k = s == 3 ? __builtin_amdgcn_alignbyte(hi, lo, 3) : (lo >> (8 * s));
-    atomicAdd(&h_lds[k & 0x7fffu], ((k >> 15) & 1u) * 0xffffu + 1u);      // + 1 or + 0x10000
+    const int s = o & 3;
+    const u32 k = s == 3 ? __builtin_amdgcn_alignbyte(w[(o >> 2) + 1], w[o >> 2], 3) : (w[o >> 2] >> (8 * s));
+    return k & 0xffffu;
 }
 
+__device__ __forceinline__ void h16_add(u32* h_lds, u32 k, u32 c)
+{
+    atomicAdd(&h_lds[k & 0x7fffu], c << ((k >> 15) * 16u));             // + c or + c << 16
+}
+
+// SUB = false: counts key' = bytes (j, j+1) of every position of the chunk.
+// SUB = true:  counts key' = bytes (j+2, j+3) of the positions whose bytes (j, j+1) equal `sel` (memory order) - the
+//              deeper histogram that lets a shard boundary fall INSIDE a heavy two-byte key ("if one key
+//              exceeds n/G, refine that key with a deeper histogram"; the reference balances by handing out the largest
+//              partitions first, cpp:1657-1678).
+// Skewed chunks (pass 1, entered when a 16-bit counter wrapped in pass 0): a lane first merges runs of equal consecutive keys
+// among its 16 positions into one add, and a wave whose lanes all add the same key and count issues ONE add for all of them -
+// on a run of one repeated byte every LDS atomic of pass 0 is a 64-way same-address conflict (all-'A': 4.4 ms per GiB).
+template <bool SUB>
 __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u64 m, u32 chunk_len, u32 nchunks,
-                                                 u32* __restrict__ partial)
+                                                 u32* __restrict__ partial, u32 sel)
 {
     extern __shared__ u32 h_lds[];
     u64* ovf = reinterpret_cast<u64*>(h_lds + 32768);
-    u32* ovf_n = h_lds + 32768 + H16_OVF_CAP * 2;            // [0] list length, [1] checksum
+    u32* ovf_n = h_lds + 32768 + H16_OVF_CAP * 2;            // [0] list length, [1] checksum, [2] keys counted (SUB), [3] largest counter
     const u32 chunk = blockIdx.x, t = threadIdx.x;
     if (chunk >= nchunks) return;
     uint4* h4 = reinterpret_cast<uint4*>(h_lds);
@@ -252,15 +267,21 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
     u64 cend = cbeg + chunk_len;
     if (cend > m) cend = m;
     if (cend < cbeg) cend = cbeg;
+    const u32 nsub = (u32)((cend - cbeg + H16_SUB - 1) / H16_SUB);
+    // Optimistic counting (no sweeps, one plain add per key) is right for chunks whose keys are spread out.  Whether this is
+    // such a chunk shows after the first sub-chunk, where no counter can have wrapped yet: if its largest counter, scaled to
+    // the whole chunk, would pass 16 bits the chunk continues in SAFE mode right away instead of counting everything twice.
+    bool safe = false;
 #pragma unroll 1
     for (u32 pass = 0; pass < 2; ++pass) {
         for (u32 i = t; i < 8192u; i += 1024u) h4[i] = make_uint4(0, 0, 0, 0);
-        if (t < 2) ovf_n[t] = 0;
+        if (t < 4) ovf_n[t] = 0;
         __syncthreads();
         u64 base = cbeg + (u64)t * 16u;
         uint4 v = make_uint4(0, 0, 0, 0);
         u32 nx = 0;
-        if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = text[base + 16]; }
+        u32 counted = 0;
+        if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = *reinterpret_cast<const u32*>(text + base + 16); }   // (the text is padded)
 #pragma unroll 1
         for (u64 sub = cbeg; sub < cend; sub += H16_SUB) {
 #pragma unroll 1
@@ -270,22 +291,52 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
                 const u32 cn = nx;
                 const u64 cb = base;
                 base += 16384u;
-                if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = text[base + 16]; }   // prefetch
-                const u32 w[5] = {cv.x, cv.y, cv.z, cv.w, cn};
-                if (cend - cb >= 16) {
+                if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = *reinterpret_cast<const u32*>(text + base + 16); }   // prefetch
+                const u32 w[6] = {cv.x, cv.y, cv.z, cv.w, cn, 0u};
+                const u32 lim = cend - cb >= 16 ? 16u : (u32)(cend - cb);
+                if (!safe && !SUB && lim == 16u) {                 // the common case: 16 plain adds, nothing predicated
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) h16_add(h_lds, w[j >> 2], w[(j >> 2) + 1], j);
+                    for (int j = 0; j < 16; ++j) h16_add(h_lds, h16_key(w, j), 1u);
+                } else if (!safe) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        bool on = (u32)j < lim;
+                        if (SUB) on = on && h16_key(w, j) == sel;
+                        if (on) { h16_add(h_lds, h16_key(w, SUB ? j + 2 : j), 1u); if (SUB) ++counted; }
+                    }
                 } else {
-                    const u32 lim = (u32)(cend - cb);
+                    u32 run = 0, prev = 0;
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) if ((u32)j < lim) h16_add(h_lds, w[j >> 2], w[(j >> 2) + 1], j);
+                    for (int j = 0; j <= 16; ++j) {
+                        bool on = (u32)j < lim && j < 16;
+                        if (SUB && on) on = h16_key(w, j) == sel;
+                        const u32 k = on ? h16_key(w, SUB ? j + 2 : j) : 0u;
+                        const bool flush = run != 0 && (!on || k != prev);
+                        const u32 fk = prev, fc = run;
+                        if (flush) run = 0;
+                        if (on) { prev = k; ++run; }
+                        const u64 fm = __ballot(flush);
+                        if (fm) {
+                            const u32 k0 = __builtin_amdgcn_readfirstlane(fk), c0 = __builtin_amdgcn_readfirstlane(fc);
+                            if (__ballot(flush && (fk != k0 || fc != c0)) == 0) {          // the whole wave adds the same thing
+                                if (flush && (int)lane_id() == __ffsll((long long)fm) - 1) h16_add(h_lds, k0, c0 * (u32)__popcll(fm));
+                            } else if (flush) h16_add(h_lds, fk, fc);
+                        }
+                    }
                 }
             }
-            if (pass == 0 || sub + H16_SUB >= cend) continue;      // the last sub-chunk needs no sweep
+            if (sub + H16_SUB >= cend) continue;                    // the last sub-chunk needs no sweep
+            if (!safe && sub != cbeg) continue;                     // optimistic: only the look after the first sub-chunk
             __syncthreads();
+            u32 cmax = 0;
 #pragma unroll 1
             for (u32 i = t; i < 8192u; i += 1024u) {
                 uint4 q = h4[i];
+                if (!safe) {
+                    const u32 a = max(max(q.x & 0xffffu, q.x >> 16), max(q.y & 0xffffu, q.y >> 16));
+                    const u32 b = max(max(q.z & 0xffffu, q.z >> 16), max(q.w & 0xffffu, q.w >> 16));
+                    cmax = max(cmax, max(a, b));
+                }
                 if (((q.x | q.y | q.z | q.w) & 0xC000C000u) == 0) continue;
                 u32 ww[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -302,22 +353,33 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
                 }
                 h4[i] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
             }
+            if (!safe) {
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) cmax = max(cmax, (u32)__shfl_xor(cmax, sft, 64));
+                if (lane_id() == 0) atomicMax(&ovf_n[3], cmax);
+            }
             __syncthreads();
+            // (counters >= H16_FLUSH were moved to the overflow list above in either mode, so switching is seamless)
+            if (!safe && (u64)ovf_n[3] * nsub >= 65535ull) safe = true;
         }
         __syncthreads();
-        if (pass == 1) break;
-        // pass 0: did any counter wrap?
+        if (safe) break;
+        // optimistic to the end: did any counter wrap after all?
         u32 sum = 0;
         for (u32 i = t; i < 8192u; i += 1024u) {
             const uint4 q = h4[i];
             sum += (q.x & 0xffffu) + (q.x >> 16) + (q.y & 0xffffu) + (q.y >> 16) + (q.z & 0xffffu) + (q.z >> 16) + (q.w & 0xffffu) + (q.w >> 16);
         }
-        sum = wave_sum(sum);
-        if (lane_id() == 0) atomicAdd(&ovf_n[1], sum);
+        u32 listed = 0;                                             // what the look after the first sub-chunk moved to the list
+        for (u32 i = t; i < min(ovf_n[0], H16_OVF_CAP); i += 1024u) listed += (u32)ovf[i];
+        sum = wave_sum(sum + listed);
+        if (SUB) counted = wave_sum(counted);
+        if (lane_id() == 0) { atomicAdd(&ovf_n[1], sum); if (SUB) atomicAdd(&ovf_n[2], counted); }
         __syncthreads();
-        const bool clean = ovf_n[1] == (u32)(cend - cbeg);
+        const bool clean = ovf_n[1] == (SUB ? ovf_n[2] : (u32)(cend - cbeg));
         __syncthreads();
         if (clean) break;
+        safe = true;                                                // recount everything with sweeps
     }
     u32* out = partial + (u64)chunk * 65536u;
     for (u32 i = t; i < 32768u; i += 1024u) {
@@ -349,13 +411,46 @@ __global__ __launch_bounds__(256) void k_reduce16(const u32* __restrict__ partia
     hist[((kle & 255u) << 8) | (kle >> 8)] = s0 + s1 + s2 + s3;
 }
 
-// wide builds: the global counts are 64-bit; a shard works on its own key range, whose counts and offsets fit 32 bits
-__global__ __launch_bounds__(256) void k_hist_clip(const u64* __restrict__ hist64, u32 klo, u32 khi, u32* __restrict__ hist32, u32* __restrict__ counters)
+// A shard works on its own key range: everything outside [klo, khi) reads as 0 (wide builds: the global counts are 64-bit,
+// a shard's own counts and offsets fit 32 bits).  Boundary keys that the shard owns only in part are corrected by k_sub_fix.
+template <bool W>
+__global__ __launch_bounds__(256) void k_hist_clip(const typename Wd<W>::hist_t* __restrict__ hist, u32 klo, u32 khi, u32* __restrict__ hist32, u32* __restrict__ counters)
 {
     const u32 k = blockIdx.x * 256u + threadIdx.x;
-    const u64 v = (k >= klo && k < khi) ? hist64[k] : 0ull;
+    const u64 v = (k >= klo && k < khi) ? (u64)hist[k] : 0ull;
     if (v > 0xffffffffull) atomicOr(&counters[C_ERR], 0x100u);
     hist32[k] = (u32)v;
+}
+
+// Shard boundary inside the two-byte key `key` (big-endian): the shard owns only the suffixes whose NEXT two bytes lie in
+// [sublo, subhi).  sub_partial[chunk][.] is the deeper histogram of that key (k_hist16<true>, memory byte order).  Per text
+// chunk: the in-range count replaces hist_partial[chunk][key] (saved for k_sub_restore; the scatter's stripe cursors are made
+// from these), and the total goes to hist_clip[key] (zeroed by the caller).
+__global__ __launch_bounds__(256) void k_sub_fix(const u32* __restrict__ sub_partial, u32 sublo, u32 subhi, u32 key,
+                                                 u32* __restrict__ hist_partial, u32* __restrict__ saved, u32* __restrict__ hist_clip_key)
+{
+    __shared__ u32 s_sum;
+    const u32 chunk = blockIdx.x;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    const u32* p = sub_partial + (u64)chunk * 65536u;
+    u32 sum = 0;
+    for (u32 sk = sublo + threadIdx.x; sk < subhi; sk += 256u) sum += p[(sk >> 8) | ((sk & 255u) << 8)];
+    sum = wave_sum(sum);
+    if (lane_id() == 0 && sum) atomicAdd(&s_sum, sum);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 at = (u64)chunk * 65536u + ((key >> 8) | ((key & 255u) << 8));
+        saved[chunk] = hist_partial[at];
+        hist_partial[at] = s_sum;
+        if (s_sum) atomicAdd(hist_clip_key, s_sum);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sub_restore(u32* __restrict__ hist_partial, const u32* __restrict__ saved, u32 nchunks, u32 key)
+{
+    const u32 chunk = blockIdx.x * 256u + threadIdx.x;
+    if (chunk < nchunks) hist_partial[(u64)chunk * 65536u + ((key >> 8) | ((key & 255u) << 8))] = saved[chunk];
 }
 
 #define SCAN16_LDS_BYTES ((32768u + 1024u + 32u) * 4u)
@@ -526,7 +621,7 @@ template <bool W> __host__ __device__ inline u32 s0_digit_bits(u32 sigma)      /
 }
 
 template <bool W>
-__global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ text, u64 m, u32 klo, u32 khi, u32 chunk_len,
+__global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ text, u64 m, u64 lo32, u64 hi32, u32 chunk_len,
                                                          u32* __restrict__ cursor0, u64* __restrict__ out,
                                                          const u8* __restrict__ code, const u32* __restrict__ counters, u32 allow_pack)
 {
@@ -563,8 +658,9 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
     for (int j = 0; j < S0_POS; ++j) {
         const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
         const u32 b1 = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u;
-        const u32 k16 = (b0 << 8) | b1;
-        const bool valid = (base + j < m) && k16 >= klo && k16 < khi;
+        const u32 b2 = (w[(j + 2) >> 2] >> (8 * ((j + 2) & 3))) & 255u, b3 = (w[(j + 3) >> 2] >> (8 * ((j + 3) & 3))) & 255u;
+        const u64 k32 = ((u64)b0 << 24) | (b1 << 16) | (b2 << 8) | b3;                 // shard = range of 4-byte prefixes
+        const bool valid = (base + j < m) && k32 >= lo32 && k32 < hi32;
         rank[j] = 0;
         if (valid) { rank[j] = atomicAdd(&hist[b0], 1u); validmask |= 1u << j; }
     }

@@ -475,3 +475,26 @@ def test_single_process_multi_gpu_entry(M, oracle_mod, devices, shards):
     sa = M.make_suffix_array_multi(t, devices, n_shards=shards, index_bytes=8, force_wide=True)
     assert sa.dtype == np.int64 and (sa == _want(oracle_mod, t)).all()
     assert M.make_suffix_array_multi(np.zeros(0, np.uint8), devices).tolist() == [0]
+
+
+def test_shard_cuts_split_heavy_keys(M, oracle_mod, monkeypatch):
+    """a two-byte key heavier than a shard must not end up on one rank - the cut is refined with the deeper
+    histogram of that key (next two bytes).  DNA has 16 two-byte keys in all; 8 shards must still come out balanced, and the
+    shards (whose boundary keys are now owned in part) must still reassemble to the reference's array."""
+    import torch
+    r = gen.random_bytes(1 << 22, 9)
+    noisy_a = np.where(r < 128, 65, r).astype(np.uint8)              # half 'A', half noise
+    for name, t, tol in (("dna", gen.dna_bytes(1 << 22, 3), 0.07), ("text", gen.text_bytes(1 << 22, 5), 0.25), ("A+noise", noisy_a, 0.25)):
+        n = t.size
+        d = _dev(M, t)
+        ctx = M.DeviceContext(0)
+        b = ctx.shard_bounds(d, n, 8)
+        sizes = np.diff(b)
+        assert sizes.sum() == n + 1 and sizes.max() <= (1 + tol) * (n + 1) / 8 + 2, (name, sizes.tolist())
+        monkeypatch.setenv("MSUFSORT_HIP_NO_REFINE", "1")
+        coarse = np.diff(ctx.shard_bounds(d, n, 8))
+        monkeypatch.delenv("MSUFSORT_HIP_NO_REFINE")
+        assert coarse.max() >= sizes.max()
+        sa = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        ctx.make_sa(d, n, sa, logical_shards=8)
+        assert (sa.cpu().numpy() == _want(oracle_mod, t)).all(), name
