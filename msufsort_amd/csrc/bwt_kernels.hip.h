@@ -277,14 +277,6 @@ __global__ __launch_bounds__(256) void k_ibwt_scatter(const u8* __restrict__ bwt
     }
 }
 
-__global__ __launch_bounds__(256) void k_ibwt_pack(const u8* __restrict__ bwt, u32 rows, u32 sent, const u32* __restrict__ link, u64* __restrict__ packed)
-{
-    for (u64 k = (u64)blockIdx.x * 256u + threadIdx.x; k < rows; k += (u64)gridDim.x * 256u) {
-        const u32 sym = (k == sent) ? 0u : ibwt_sym(bwt, (u32)k, sent);
-        packed[k] = (u64)link[k] | ((u64)sym << 32);
-    }
-}
-
 __device__ __forceinline__ bool ibwt_marked(u32 row, u32 sent) { return (row & (IBWT_S - 1)) == 0 || row == sent; }
 __device__ __forceinline__ u32 ibwt_id(u32 row, u32 sent, u32 kreg) { return (row == sent && (sent & (IBWT_S - 1))) ? kreg : row / IBWT_S; }
 __device__ __forceinline__ u32 ibwt_start(u32 id, u32 sent, u32 kreg) { return id == kreg ? sent : id * IBWT_S; }
@@ -295,49 +287,91 @@ __device__ __forceinline__ u32 ibwt_start(u32 id, u32 sent, u32 kreg) { return i
 // Afterwards nxt/dist describe a linked list of segments of at most IBWT_CW bytes each; list ranking gives every
 // segment its text position and k_ibwt_assemble copies the buffers out with coalesced stores - n dependent
 // random reads in total instead of the 2n of a count-then-write scheme.
+//
+// A hop is ONE 4-byte load from the link table (4(n+1) bytes; the reference packs link + symbol in 5, cpp:1826-1836):
+// the symbol of text position p is F[row(p)], and F is the sorted column - a search in the cumulative symbol counts C[],
+// which live in LDS (a 4096-entry coarse table gives the first candidate, then a step or two), computed while the load
+// of the next row is in flight.  Every lane runs IBWT_NCH independent chains (the reference interleaves many chains per
+// thread the same way, cpp:1922,1976-2018): the walk is bound by dependent random sector reads, and the loads in
+// flight per lane are what one lane can add to the memory-level parallelism.
 #define IBWT_CW 512u
-__global__ __launch_bounds__(256) void k_ibwt_walk(const u64* __restrict__ packed, u32 sent, u32 kreg, u32 K, u32 kt_cap,
-                                                   u32* __restrict__ queue /* [0] static head, [1] dynamic count */,
+#ifndef IBWT_NCH
+#define IBWT_NCH 2
+#endif
+__global__ __launch_bounds__(256) void k_ibwt_walk(const u32* __restrict__ link, const u32* __restrict__ offs /* [256][ntiles]: C[c] = offs[c * ntiles] */,
+                                                   u32 ntiles, u32 rows, u32 sent, u32 kreg, u32 K, u32 kt_cap,
+                                                   u32* __restrict__ queue /* [1] dynamic count, [2] overflow flag */,
                                                    u32* __restrict__ nxt, u32* __restrict__ dist, u8* __restrict__ segbuf)
 {
     // chain ids 1 .. K-1 are dealt to the workgroups in contiguous shares and pulled from an LDS counter: one global
     // counter for all 4 M pulls of a 1 GiB input saturates (~90 returning atomics per us) and was what the walk waited
     // for; chain lengths are i.i.d., so a share of a few thousand chains is balanced to a few per cent
-    __shared__ u32 s_next, s_end;
-    if (threadIdx.x == 0) {
+    __shared__ u32 s_next, s_end, s_shift;
+    __shared__ u32 s_C[258];
+    __shared__ u8 s_T[4096];
+    const u32 t = threadIdx.x;
+    s_C[t] = offs[(u64)t * ntiles];
+    if (t == 0) {
+        s_C[256] = rows; s_C[257] = 0xffffffffu;
         const u32 per = (K - 1u + gridDim.x - 1u) / gridDim.x;
         const u64 b = 1ull + (u64)blockIdx.x * per;
         s_next = b < K ? (u32)b : K;
         s_end = b + per < K ? (u32)(b + per) : K;
+        u32 sh = 0;
+        while (sh < 32 && ((rows - 1) >> sh) >= 4096u) ++sh;
+        s_shift = sh;
     }
     __syncthreads();
+    {   // coarse table: T[b] = the symbol whose rows contain row b << shift (largest c with C[c] <= that row; 0 below C[0])
+        const u32 sh = s_shift;
+        for (u32 b = t; b < 4096u; b += 256u) {
+            const u64 row = (u64)b << sh;
+            u32 lo = 0, hi = 256;                                   // invariant: C[lo] <= row (or lo == 0), C[hi] > row
+            while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if ((u64)s_C[mid] <= row) lo = mid; else hi = mid; }
+            s_T[b] = (u8)lo;
+        }
+    }
+    __syncthreads();
+    const u32 shift = s_shift;
 #define IBWT_PULL() ([&]() { const u32 i_ = atomicAdd(&s_next, 1u); return i_ < s_end ? i_ : K; }())
-    u32 id = IBWT_PULL();
-    u32 cur = 0, len = 0, my = id;
-    u64 acc = 0;                       // the last (len & 7) bytes met: bytes leave as aligned 8-byte stores (one memory
-                                       // transaction per 8 hops and lane instead of one per hop)
-    if (id < K) cur = (u32)packed[ibwt_start(id, sent, kreg)];
-    while (id < K) {
-        const u64 e = packed[cur];
-        acc |= (u64)(u8)(e >> 32) << (8u * (len & 7u));
-        ++len;
-        if ((len & 7u) == 0) { *reinterpret_cast<u64*>(segbuf + (u64)my * IBWT_CW + len - 8u) = acc; acc = 0; }
-        if (ibwt_marked(cur, sent)) {
-            if (len & 7u) *reinterpret_cast<u64*>(segbuf + (u64)my * IBWT_CW + (len & ~7u)) = acc;     // (tail bytes beyond len are never read)
-            acc = 0;
-            nxt[my] = ibwt_id(cur, sent, kreg);
-            dist[my] = len;
-            id = IBWT_PULL();
-            my = id; len = 0;
-            if (id < K) cur = (u32)packed[ibwt_start(id, sent, kreg)];
-        } else {
-            if (len == IBWT_CW) {      // (a multiple of 8: acc has just been stored)
-                const u32 fresh = K + atomicAdd(&queue[1], 1u);
-                if (fresh >= kt_cap) { queue[2] = 1u; return; }          // cannot happen (capacity covers every cut)
-                nxt[my] = fresh; dist[my] = len;
-                my = fresh; len = 0;
+    u32 id[IBWT_NCH], cur[IBWT_NCH], len[IBWT_NCH], my[IBWT_NCH];
+    u64 acc[IBWT_NCH];                 // the last (len & 7) bytes met: bytes leave as aligned 8-byte stores (one memory
+                                       // transaction per 8 hops and chain instead of one per hop)
+#pragma unroll
+    for (int c = 0; c < IBWT_NCH; ++c) { id[c] = IBWT_PULL(); my[c] = id[c]; len[c] = 0; acc[c] = 0; cur[c] = id[c] < K ? ibwt_start(id[c], sent, kreg) : 0u; }
+    for (;;) {
+        bool any = false;
+        u32 nx[IBWT_NCH];
+#pragma unroll
+        for (int c = 0; c < IBWT_NCH; ++c) { nx[c] = 0; if (id[c] < K) { nx[c] = link[cur[c]]; any = true; } }     // the dependent loads, all in flight together
+        if (!any) break;
+#pragma unroll
+        for (int c = 0; c < IBWT_NCH; ++c) {
+            if (id[c] >= K) continue;
+            // symbol of the row I am leaving (independent of the load above)
+            u32 sy = s_T[cur[c] >> shift];
+            while (cur[c] >= s_C[sy + 1]) ++sy;
+            acc[c] |= (u64)sy << (8u * (len[c] & 7u));
+            ++len[c];
+            if ((len[c] & 7u) == 0) { *reinterpret_cast<u64*>(segbuf + (u64)my[c] * IBWT_CW + len[c] - 8u) = acc[c]; acc[c] = 0; }
+            const u32 r = nx[c];
+            if (ibwt_marked(r, sent)) {
+                if (len[c] & 7u) *reinterpret_cast<u64*>(segbuf + (u64)my[c] * IBWT_CW + (len[c] & ~7u)) = acc[c];     // (tail bytes beyond len are never read)
+                acc[c] = 0;
+                nxt[my[c]] = ibwt_id(r, sent, kreg);
+                dist[my[c]] = len[c];
+                id[c] = IBWT_PULL();
+                my[c] = id[c]; len[c] = 0;
+                cur[c] = id[c] < K ? ibwt_start(id[c], sent, kreg) : 0u;
+            } else {
+                if (len[c] == IBWT_CW) {      // (a multiple of 8: acc has just been stored)
+                    const u32 fresh = K + atomicAdd(&queue[1], 1u);
+                    if (fresh >= kt_cap) { queue[2] = 1u; return; }          // cannot happen (capacity covers every cut)
+                    nxt[my[c]] = fresh; dist[my[c]] = len[c];
+                    my[c] = fresh; len[c] = 0;
+                }
+                cur[c] = r;
             }
-            cur = (u32)e;
         }
     }
 #undef IBWT_PULL
