@@ -114,8 +114,8 @@ struct msufsort_hip_ctx {
     {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<MID_B_THREADS, MID_B_ITEMS, W>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<MID_B_THREADS, MID_B_ITEMS>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>()));
         return MSUFSORT_HIP_OK;
@@ -470,7 +470,35 @@ struct Rounds {
     u32 cpk = W ? 3u : 4u;
     int verbose = 0;
     bool exact_sticky = false, fast_gave_up = false, force_retry = false, no_pack = false;
+    bool safe_rank = getenv("MSUFSORT_HIP_SAFE_RANK") != nullptr;
     u32 nA = 0, nB = 0, nC = 0, nP = 0;
+    GatherSpec gather{nullptr, 0, {}};   // text rounds: the sorts (and the first partition level) gather the keys themselves
+    const u8* code = nullptr;            // dense alphabet code (device)
+
+    // k_sort_fast needs spread-out keys.  The 16-bit histogram already tells: if its largest bucket is far
+    // above the mean the input is text-like and every attempt (reading the records, a serialised LDS-atomic
+    // phase, rejection) would be wasted work - go straight to the LSD sort.
+    bool keys_spread() const
+    {
+        const u64 ms_shard = c->h_counters[C_MS];
+        return (u64)c->h_counters[C_HMAX] * (u64)(khi - klo) <= 8ull * std::max<u64>(ms_shard, 1);   // max <= 8 x mean
+    }
+    // Later rounds of a small-alphabet input sort dense base-sigma keys: if the symbols are about evenly used
+    // (largest two-byte bucket <= 2 x the mean of the non-empty ones: random DNA, base64, hex dumps) the children of
+    // the partition levels are as spread out as random bytes.  The attempt is dropped for the rest of the build as
+    // soon as a round hands more than a quarter of its segments back (tandem repeats, text).
+    // (round 0's dense digits give class-B children of a few hundred records: the 2^13-entry table of k_sort_fast2 costs
+    // more than it saves there - measured on 16..80-symbol random texts - so the dense keys only count from round 1 on)
+    // ... and only for alphabets of up to 16 codes (>= 8 symbols per key): measured, a 17-code hex text loses 11 ms to it
+    bool wants_fast() const
+    {
+        const u64 ms_shard = c->h_counters[C_MS];
+        const bool dense_uniform = round >= 1 && cpk >= 8u &&
+                                   (u64)c->h_counters[C_HMAX] * (u64)std::max<u32>(c->h_counters[C_HNZ], 1u) <= 2ull * std::max<u64>(ms_shard, 1);
+        // (k_sort_fast2 exists for narrow records and text keys only)
+        return !W && mode == MODE_TEXT && getenv("MSUFSORT_HIP_NO_FAST") == nullptr &&
+               (keys_spread() || (dense_uniform && !fast_gave_up) || getenv("MSUFSORT_HIP_FORCE_FAST"));
+    }
 
     Lists make_lists(int slot) const
     {
@@ -514,6 +542,7 @@ struct Rounds {
                 shift = 24 - b;
             }
             else { src_list = c->large_round[cur].template as<Desc>(); nl = c->h_counters[(cur ? C_LIST1 : C_LIST0) + 3]; ntiles = c->h_counters[cur ? C_LTILES1 : C_LTILES0]; lp = 0; shift = 24; }
+            bool first_level = true;
             while (nl > 0) {
                 // (small alphabets: k_scatter0 left only the top bits of the key below the bucket byte non-zero; a level that
                 // reaches below them ends round 0's splitting)
@@ -526,7 +555,10 @@ struct Rounds {
                 hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, src_list, nl, c->tile_start.template as<u32>());
                 HIP_TRY(hipMemsetAsync(c->seg_hist.p, 0, (size_t)nl * 256 * 4, st));
                 HIP_TRY(hipMemsetAsync(c->trivial.p, 0, (size_t)nl * 4, st));
-                hipLaunchKernelGGL(k_count, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.template as<u32>(), shift, c->seg_hist.template as<u32>());
+                GatherSpec g0 = gather;
+                if (!first_level) g0.text = nullptr;      // (the first level has stored the keys it gathered)
+                first_level = false;
+                hipLaunchKernelGGL(k_count<W>, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.template as<u32>(), shift, c->seg_hist.template as<u32>(), g0, code);
                 DBG("k_count");
                 hipLaunchKernelGGL(k_segscan, dim3(nl), dim3(256), 0, st, src_list, nl, c->seg_hist.template as<u32>(), c->child_start.template as<u32>(), c->cursor.template as<u32>(), c->trivial.template as<u32>());
                 DBG("k_segscan");
@@ -577,6 +609,7 @@ struct Rounds {
             em.pool_cnt_idx = nxt ? C_POOL1 : C_POOL0; em.seg_cnt_idx = nxt ? C_SEG1 : C_SEG0;
             em.pool_cap = cap32(); em.seg_cap = cap32();
             em.discard = discard; em.grp_out = grp_out;
+            em.safe_rank = (attempt > 0 || safe_rank) ? 1u : 0u;
             {   // chunk = what the persistent workgroups reserve per global atomic; slack <= active/16 per kernel
                 const u64 act = (u64)c->h_counters[cur ? C_POOL1 : C_POOL0] + c->h_counters[cur ? C_SEG1 : C_SEG0] + (round == 0 ? c->h_counters[C_MS] : 0);
                 const u64 ch = std::min<u64>(4096, std::max<u64>(32, act / (16 * 8192)));
@@ -593,23 +626,8 @@ struct Rounds {
             const u32 base = cur ? C_LIST1 : C_LIST0;
             nA = c->h_counters[base + 0]; nB = c->h_counters[base + 1]; nC = c->h_counters[base + 2];
             nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
-            // k_sort_fast needs spread-out keys.  The 16-bit histogram already tells: if its largest bucket is far
-            // above the mean the input is text-like and every attempt (reading the records, a serialised LDS-atomic
-            // phase, rejection) would be wasted work - go straight to the LSD sort.
-            const u64 ms_shard = c->h_counters[C_MS];
-            const bool spread = (u64)c->h_counters[C_HMAX] * (u64)(khi - klo) <= 8ull * std::max<u64>(ms_shard, 1);   // max <= 8 x mean
-            // Later rounds of a small-alphabet input sort dense base-sigma keys: if the symbols are about evenly used
-            // (largest two-byte bucket <= 2 x the mean of the non-empty ones: random DNA, base64, hex dumps) the children of
-            // the partition levels are as spread out as random bytes.  The attempt is dropped for the rest of the build as
-            // soon as a round hands more than a quarter of its segments back (tandem repeats, text).
-            // (round 0's dense digits give class-B children of a few hundred records: the 2^13-entry table of k_sort_fast2 costs
-            // more than it saves there - measured on 16..80-symbol random texts - so the dense keys only count from round 1 on)
-            // ... and only for alphabets of up to 16 codes (>= 8 symbols per key): measured, a 17-code hex text loses 11 ms to it
-            const bool dense_uniform = round >= 1 && cpk >= 8u &&
-                                       (u64)c->h_counters[C_HMAX] * (u64)std::max<u32>(c->h_counters[C_HNZ], 1u) <= 2ull * std::max<u64>(ms_shard, 1);
-            // (k_sort_fast2 exists for narrow records and text keys only)
-            const bool use_fast = !W && mode == MODE_TEXT && getenv("MSUFSORT_HIP_NO_FAST") == nullptr &&
-                                  (spread || (dense_uniform && !fast_gave_up) || getenv("MSUFSORT_HIP_FORCE_FAST"));
+            const bool spread = keys_spread();
+            const bool use_fast = wants_fast();
             if (use_fast && (nB || nC)) hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << C_FBB) | (1u << C_FBC));
             if (nC) {
                 const u32* ids = nullptr;
@@ -634,7 +652,7 @@ struct Rounds {
                     }
                 }
                 k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
-                    bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, emC, counters, ids, (u32)C_FBC);
+                    bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, emC, counters, ids, (u32)C_FBC, gather, code);
                 DBG("k_sort_mid C");
             }
             if (c->sync_debug) {
@@ -662,16 +680,16 @@ struct Rounds {
                         ids = c->doneB.template as<u32>();
                     }
                 }
-                k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
-                    bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, emB, counters, ids, (u32)C_FBB);
+                k_sort_mid<MID_B_THREADS, MID_B_ITEMS, W><<<dim3(std::min<u32>(nB, 1024u)), dim3(MID_B_THREADS), sort_mid_lds_bytes<MID_B_THREADS, MID_B_ITEMS>(), st>>>(
+                    bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, emB, counters, ids, (u32)C_FBB, gather, code);
                 DBG("k_sort_mid B");
             }
             if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
-                        bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, (const u32*)nullptr, 0u);
+                        bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, (const u32*)nullptr, 0u, gather, code);
             DBG("k_sort_mid A");
             if (nP) hipLaunchKernelGGL(k_sort_tiny<W>, dim3(std::min<u32>(cdiv(nP, 256), 8192u)), dim3(256), 0, st, c->pool_rec[cur].template as<u64>(), c->pool_hdr[cur].template as<u64>(),
                                        (u32)(cur ? C_POOL1 : C_POOL0), sa_local, isa32, mode,
-                                       em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32(), em.pool_chunk, counters, grp_out, discard);
+                                       em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32(), em.pool_chunk, counters, grp_out, discard, gather, code);
             DBG("k_sort_tiny");
             if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
             TRY(c->read_counters(attempt == 0));
@@ -856,13 +874,19 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
                 R.isa32 = isa;
             }
         }
-        // refill keys of all still-tied suffixes
+        // keys of all still-tied suffixes: gathered by the sorts themselves in text rounds (unless k_sort_fast2 will be tried,
+        // which wants its records complete), by k_refill otherwise
         ks.depth = depth;
         const sa_t* isa_any = nullptr;
         if constexpr (!W) isa_any = R.isa32;
-        if (actP) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
+        R.round = round + 1;              // (wants_fast looks at the round that is about to run)
+        const bool fuse = R.mode == MODE_TEXT && !R.wants_fast() && getenv("MSUFSORT_HIP_NO_FUSE") == nullptr;
+        R.round = round;
+        R.code = c->alpha.as<u8>();
+        R.gather = GatherSpec{fuse ? d_text : nullptr, n, ks};
+        if (!fuse && actP) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
                                      d_text, isa_any, n, R.mode, c->alpha.as<u8>(), ks);
-        if (actS) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actS, 1024), 65536u)), dim3(256), 0, st, bufs.p[R.sb], counters, curS,
+        if (!fuse && actS) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actS, 1024), 65536u)), dim3(256), 0, st, bufs.p[R.sb], counters, curS,
                                      d_text, isa_any, n, R.mode, c->alpha.as<u8>(), ks);
         DBG("k_refill");
         if (R.mode == MODE_TEXT) depth += ks.cpk; else { depth *= 2; tm.doubling_rounds++; }

@@ -104,6 +104,16 @@ enum {
 #define CLS_C_ITEMS 18       // <= 18432
 #define CAP_A (CLS_A_THREADS * CLS_A_ITEMS)
 #define CAP_B (CLS_B_THREADS * CLS_B_ITEMS)
+// shape of the LSD sort (k_sort_mid) that takes class B: any THREADS x ITEMS >= CAP_B
+#ifndef MID_B_THREADS
+#define MID_B_THREADS 256
+#endif
+#ifndef MID_B_ITEMS
+#define MID_B_ITEMS 18
+#endif
+#ifndef MID_B_MINW
+#define MID_B_MINW 4          // __launch_bounds__ second argument: waves per SIMD the register allocation must allow
+#endif
 #define CAP_C (CLS_C_THREADS * CLS_C_ITEMS)
 
 #ifndef P1_THREADS
@@ -143,6 +153,10 @@ struct Emit {             // where still-tied runs go (next round)
     u32 pool_cap, seg_cap;
     u32 pool_chunk, seg_chunk;   // persistent workgroups reserve output room in chunks of this many slots
     u32 discard;                 // 1: the caller rebuilds next round's state itself (stateless doubling step): emit nothing
+    u32 safe_rank;               // 1: LSD ranks from wave ballots (match-any); 0: from returning LDS atomics, which gfx950 serves
+                                 // lowest lane first when lanes of one instruction meet on an address (measured:
+                                 // tools/microbench/exp_lds_order.hip, 0 mismatches in 10^9) - not an architectural promise, so
+                                 // every segment checks that it came out sorted and a violation repeats the round with ballots
     u32* grp_out;                // MODE_DEFER: tie-group head of every row (same indexing as the suffix-array rows)
     Lists lists;
 };
@@ -698,6 +712,65 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
     for (u32 s = t; s < tot; s += S0_THREADS) out[gbase[sbin[s]] + s] = stage[s];
 }
 
+// Prefix-doubling keys.  narrow: the rank itself (32 bits).  wide: ranks have up to 40 bits but a record only 24 key bits,
+// so a doubling step sorts in two passes over the same (read-only) rank array - first on digit A = rank >> dig_shift,
+// then, inside the groups that tie on it, on digit B = rank & dig_mask (the passes are ordinary rounds of the engine).
+struct KeySpec {
+    u64 depth;            // text: characters consumed so far; doubling: h
+    u32 sigma, cpk, zlow; // text, dense code: alphabet size, symbols per key, left shift of the base-sigma number
+    u32 dig_shift;        // doubling, wide: key24 = (rank >> dig_shift) & dig_mask
+    u32 dig_mask;
+};
+
+
+// Text rounds: the sorts fetch the next key of a record THEMSELVES (records arrive with the suffix index only), instead of a
+// separate k_refill pass in front of them.  The gathers are bound by random DRAM accesses (one sector per tied suffix:
+// ~40 G/s chip-wide whatever the kernel), the sorts by LDS work: inside one kernel the waves that wait for their sectors
+// leave the CU to the waves that sort (1 GiB text: k_refill 44 ms + LDS sorts 64 ms one after the other before).
+// get_value of the reference (cpp:129-143): big-endian window at text + index + depth, zero beyond the end.
+struct GatherSpec {
+    const u8* text;       // nullptr: keys are already in the records
+    u64 n;
+    KeySpec ks;
+};
+
+// key of ONE suffix from its window; `code` = dense alphabet code (LDS), used when ks.cpk is not a plain window
+template <bool W>
+__device__ __forceinline__ u32 window_key(const u32* w /* 4 words, zero beyond what was loaded */, const KeySpec& ks, const u8* code)
+{
+    if (ks.cpk == (W ? 3u : 4u)) return __builtin_bswap32(w[0]);
+    u32 acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if ((u32)i < ks.cpk) acc = acc * ks.sigma + (u32)code[(w[i >> 2] >> (8 * (i & 3))) & 255u];
+    return acc << ks.zlow;
+}
+
+// keys of up to N records of one lane, B gathers in flight at a time
+template <bool W, int N, int B>
+__device__ __forceinline__ void gather_keys(const GatherSpec& g, const u8* code, const typename Wd<W>::sa_t (&idx)[N], const bool (&valid)[N], u32 (&key)[N])
+{
+    const u32 wbytes = g.ks.cpk == (W ? 3u : 4u) ? 4u : (g.ks.cpk <= 8u ? 8u : 16u);      // kernel-uniform
+#pragma unroll
+    for (int b0 = 0; b0 < N; b0 += B) {
+        u32 w[B][4];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0;
+            if (b0 + k < N && valid[b0 + k]) {
+                const u64 pos = (u64)idx[b0 + k] + g.ks.depth;
+                if (pos < g.n) {                                   // (the text is padded with >= 64 zero bytes)
+                    if (wbytes == 4u) __builtin_memcpy(w[k], g.text + pos, 4);
+                    else if (wbytes == 8u) __builtin_memcpy(w[k], g.text + pos, 8);
+                    else __builtin_memcpy(w[k], g.text + pos, 16);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) if (b0 + k < N) key[b0 + k] = valid[b0 + k] ? window_key<W>(w[k], g.ks, code) : 0xffffffffu;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Generic multi-tile partition level for LARGE segments (the role multikey_quicksort's partition
 // loop cpp:591-625 plays for big partitions): split every listed segment by one key byte.
@@ -713,26 +786,44 @@ __device__ __forceinline__ u32 find_seg(const u32* __restrict__ tile_start, u32 
     return lo;
 }
 
+// g.text != nullptr (first level of a text round): the records arrive without keys - gather them here and store them back
+// for the levels and sorts that follow.
+template <bool W>
 __global__ __launch_bounds__(P1_THREADS) void k_count(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                       const u32* __restrict__ tile_start, u32 shift,
-                                                      u32* __restrict__ seg_hist)
+                                                      u32* __restrict__ seg_hist, GatherSpec g, const u8* __restrict__ code)
 {
     __shared__ u32 hist[256];
     __shared__ u32 s_seg;
+    __shared__ u8 s_code[256];
     const u32 t = threadIdx.x;
     const u32 tile = xcd_tile(blockIdx.x, 512u);
     if (tile >= tile_start[nseg]) return;
     if (t == 0) s_seg = find_seg(tile_start, nseg, tile);
-    if (t < 256) hist[t] = 0;
+    if (t < 256) { hist[t] = 0; if (g.text) s_code[t] = code[t]; }
     __syncthreads();
     const u32 s = s_seg;
     const Desc d = list[s];
     const u32 off = (tile - tile_start[s]) * P1_TILE;
-    const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
+    u64* src = bufs.p[d.buf & 3u] + d.rec_off;
+    if (g.text) {
+        typename Wd<W>::sa_t idx[P1_ITEMS];
+        bool valid[P1_ITEMS];
+        u32 key[P1_ITEMS];
+#pragma unroll
+        for (int j = 0; j < P1_ITEMS; ++j) { const u32 p = off + j * P1_THREADS + t; valid[j] = p < d.len; idx[j] = valid[j] ? rec_idx<W>(src[p]) : 0; }
+        gather_keys<W, P1_ITEMS, 4>(g, s_code, idx, valid, key);
+#pragma unroll
+        for (int j = 0; j < P1_ITEMS; ++j) {
+            const u32 p = off + j * P1_THREADS + t;
+            if (valid[j]) { const u64 r = make_rec<W>(key[j], idx[j]); src[p] = r; atomicAdd(&hist[(u32)(r >> (32 + shift)) & 255u], 1u); }
+        }
+    } else {
 #pragma unroll 4
     for (int j = 0; j < P1_ITEMS; ++j) {
         const u32 p = off + j * P1_THREADS + t;
         if (p < d.len) atomicAdd(&hist[(u32)(src[p] >> (32 + shift)) & 255u], 1u);
+    }
     }
     __syncthreads();
     if (t < 256 && hist[t]) atomicAdd(&seg_hist[(u64)s * 256u + t], hist[t]);
@@ -1001,16 +1092,6 @@ __global__ __launch_bounds__(256) void k_alphabet(const typename Wd<W>::hist_t* 
 // zero beyond the end - 4 bytes, or (small alphabets) up to 16 symbols of the dense alphabet code read as one number
 // in base sigma; in prefix-doubling rounds key = rank of suffix index + h (0 past n).
 // ------------------------------------------------------------------------------------------------
-// Prefix-doubling keys.  narrow: the rank itself (32 bits).  wide: ranks have up to 40 bits but a record only 24 key bits,
-// so a doubling step sorts in two passes over the same (read-only) rank array - first on digit A = rank >> dig_shift,
-// then, inside the groups that tie on it, on digit B = rank & dig_mask (the passes are ordinary rounds of the engine).
-struct KeySpec {
-    u64 depth;            // text: characters consumed so far; doubling: h
-    u32 sigma, cpk, zlow; // text, dense code: alphabet size, symbols per key, left shift of the base-sigma number
-    u32 dig_shift;        // doubling, wide: key24 = (rank >> dig_shift) & dig_mask
-    u32 dig_mask;
-};
-
 template <bool W>
 __device__ __forceinline__ u32 rank_key(const typename Wd<W>::sa_t* __restrict__ isa, u64 pos, u64 n, const KeySpec& ks)
 {
@@ -1129,7 +1210,7 @@ constexpr size_t sort_mid_lds_bytes()
 template <int THREADS, int ITEMS, bool W>
 __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc d,
                                                  typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
-                                                 const Emit& em, u32* __restrict__ counters)
+                                                 const Emit& em, u32* __restrict__ counters, const GatherSpec& g, const u8* s_code)
 {
     constexpr u32 KL = klow<W>();                   // low bits of the key word that are not key (wide: index bits 32..39)
     // Output room (tiny pool, segment array, descriptor lists) is reserved from the global counters in CHUNKS
@@ -1169,18 +1250,40 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 
     u32 key[ITEMS], idx[ITEMS], pos[ITEMS];
     u32 diff = 0;
-    const u32 key0 = (u32)(src[0] >> 32);
+    if (g.text == nullptr) {
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const u32 p = wbase + j * 64 + lane;
-        key[j] = 0xffffffffu; idx[j] = 0xffffffffu;
-        if ((u32)j < rpw && p < len) { const u64 r = src[p]; key[j] = (u32)(r >> 32); idx[j] = (u32)r; diff |= key[j] ^ key0; }
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 p = wbase + j * 64 + lane;
+            key[j] = 0xffffffffu; idx[j] = 0xffffffffu;
+            if ((u32)j < rpw && p < len) { const u64 r = src[p]; key[j] = (u32)(r >> 32); idx[j] = (u32)r; }
+        }
+    } else {        // text round: the records carry the suffix index only, the key is gathered here
+        typename Wd<W>::sa_t fi[ITEMS];
+        bool valid[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 p = wbase + j * 64 + lane;
+            valid[j] = (u32)j < rpw && p < len;
+            fi[j] = valid[j] ? rec_idx<W>(src[p]) : 0;
+        }
+        gather_keys<W, ITEMS, (ITEMS > 8 ? 6 : 8)>(g, s_code, fi, valid, key);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            idx[j] = valid[j] ? (u32)fi[j] : 0xffffffffu;
+            if constexpr (W) { if (valid[j]) key[j] = (key[j] & 0xffffff00u) | (u32)(fi[j] >> 32); }      // the index byte rides in the key word
+        }
     }
-    // block-wide OR of diff
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) diff |= __shfl_xor(diff, s, 64);
+    // block-wide OR of the key differences (against the segment's first key, which thread 0 holds)
+    if (t == 0) tot[0] = key[0];
     if (t < 8) misc[t] = 0;
     __syncthreads();
+    {
+        const u32 key0 = tot[0];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; if ((u32)j < rpw && p < len) diff |= key[j] ^ key0; }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) diff |= __shfl_xor(diff, s, 64);
     if (lane == 0 && diff) atomicOr(&misc[0], diff);
     __syncthreads();
     diff = misc[0] & (0xffffffffu << KL);           // (wide: the index byte never decides an LSD pass; equal keys keep their order)
@@ -1200,6 +1303,13 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
         if (((diff >> shift) & 255u) == 0) continue;            // byte equal everywhere: pass not needed
         for (u32 i = t; i < (u32)NWV * 256u; i += THREADS) wcnt[i] = 0;
         __syncthreads();
+        if (!em.safe_rank) {
+            // stable rank inside the wave = what a returning LDS atomic hands back: instructions of a wave are served in
+            // order, same-address lanes of one instruction lowest lane first
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) pos[j] = atomicAdd(&wcnt[wv * 256u + ((key[j] >> shift) & 255u)], 1u);
+        } else {
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             if (j < rows) {
@@ -1217,6 +1327,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                 old = __shfl(old, leader, 64);
                 pos[j] = old + (u32)__popcll(mask & lt_mask);
             }
+        }
         }
         __syncthreads();
         for (u32 dg = t; dg < 256u; dg += THREADS) {
@@ -1257,6 +1368,8 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
         if (j < rows) {
             const u32 p = wbase + j * 64 + lane;
             const bool eqn = (p + 1 < len) && ((key[j] >> KL) == (ex[p + 1] >> KL));
+            if ((p + 1 < len) && ((key[j] >> KL) > (ex[p + 1] >> KL))) atomicOr(&counters[C_ERR], 0x200u);      // not sorted: the LDS-atomic ranks
+                                                                                                               // were not stable after all
             const u64 bal = __ballot(eqn);
             if (lane == 0) bm_eq[p >> 6] = bal;
             any_eq |= (bal != 0);
@@ -1836,14 +1949,17 @@ constexpr size_t sort_fast_lds_bytes()
 // persistent launch: workgroups stride over the list and skip what k_sort_fast already finished
 // (the class-B instance asks for 4 waves per SIMD = 128 VGPRs: one more resident workgroup per CU)
 template <int THREADS, int ITEMS, bool W>
-__global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+__global__ __launch_bounds__(THREADS, (THREADS == MID_B_THREADS && THREADS != 1024 && THREADS != 64 ? MID_B_MINW : 1)) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                       typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
-                                                      Emit em, u32* __restrict__ counters, const u32* __restrict__ ids, u32 ids_cnt_idx)
+                                                      Emit em, u32* __restrict__ counters, const u32* __restrict__ ids, u32 ids_cnt_idx,
+                                                      GatherSpec g, const u8* __restrict__ code)
 {
     // ids != nullptr: only the segments k_sort_fast left behind (their count lives in the counters block)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_k[];
+    __shared__ u8 s_code[256];
     u32* ach = reinterpret_cast<u32*>(smem_k + sort_mid_lds_bytes<THREADS, ITEMS>()) - 24;
     if (threadIdx.x < 24) ach[threadIdx.x] = 0;
+    if (g.text) for (u32 i = threadIdx.x; i < 256u; i += THREADS) s_code[i] = code[i];
     __syncthreads();
     const u32 total = ids ? counters[ids_cnt_idx] : nseg;
     if (blockIdx.x < total) {
@@ -1852,7 +1968,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(
         for (u32 i = blockIdx.x; i < total; i += gridDim.x) {
             const u32 ni = i + gridDim.x < total ? i + gridDim.x : i;
             const Desc dn = list[ids ? ids[ni] : ni];
-            sort_mid_segment<THREADS, ITEMS, W>(bufs, d, sa_out, isa, mode, em, counters);
+            sort_mid_segment<THREADS, ITEMS, W>(bufs, d, sa_out, isa, mode, em, counters, g, s_code);
             __syncthreads();
             d = dn;
         }
@@ -1875,9 +1991,12 @@ template <bool W>
 __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_rec, const u64* __restrict__ pool_hdr,
                                                    u32 cnt_idx, typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                    u64* __restrict__ next_rec, u64* __restrict__ next_hdr, u32 next_cnt_idx, u32 next_cap,
-                                                   u32 chunk, u32* __restrict__ counters, u32* __restrict__ grp_out, u32 discard)
+                                                   u32 chunk, u32* __restrict__ counters, u32* __restrict__ grp_out, u32 discard,
+                                                   GatherSpec g, const u8* __restrict__ code)
 {
     constexpr u32 KL = klow<W>();
+    __shared__ u8 s_code[256];
+    if (g.text) s_code[threadIdx.x] = code[threadIdx.x];
     constexpr int WIN = 256, HALO = 32, TOT = WIN + HALO;
     __shared__ u32 lkey[TOT], lrun[TOT];
     __shared__ u32 s_total, s_base, s_cb, s_ce, s_fb, s_fe;      // window total / base; chunk [cb, ce); pending fill [fb, fe)
@@ -1893,7 +2012,15 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const u32 e = t + k * WIN;
-            if (e < TOT && b0 + e < count) { rec[k] = pool_rec[b0 + e]; hdr[k] = pool_hdr[b0 + e]; have[k] = true; lkey[e] = (u32)(rec[k] >> (32 + KL)); }
+            if (e < TOT && b0 + e < count) { rec[k] = pool_rec[b0 + e]; hdr[k] = pool_hdr[b0 + e]; have[k] = true; if (!g.text) lkey[e] = (u32)(rec[k] >> (32 + KL)); }
+        }
+        if (g.text) {       // text round: the pool records carry the suffix index only
+            typename Wd<W>::sa_t fi[2] = {rec_idx<W>(rec[0]), rec_idx<W>(rec[1])};
+            const bool valid[2] = {have[0] && ((hdr[0] >> 32) & 255ull) != 0, have[1] && ((hdr[1] >> 32) & 255ull) != 0};      // (len 0 = neutral entry)
+            u32 key[2];
+            gather_keys<W, 2, 2>(g, s_code, fi, valid, key);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) if (have[k]) lkey[t + k * WIN] = key[k] >> KL;
         }
         __syncthreads();
         u32 n_lt[2], n_eq[2], n_eqb[2], lead[2];
