@@ -114,8 +114,8 @@ struct msufsort_hip_ctx {
     {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<MID_B_THREADS, MID_B_ITEMS, W>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<MID_B_THREADS, MID_B_ITEMS>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>()));
         return MSUFSORT_HIP_OK;
@@ -680,7 +680,7 @@ struct Rounds {
                         ids = c->doneB.template as<u32>();
                     }
                 }
-                k_sort_mid<MID_B_THREADS, MID_B_ITEMS, W><<<dim3(std::min<u32>(nB, 1024u)), dim3(MID_B_THREADS), sort_mid_lds_bytes<MID_B_THREADS, MID_B_ITEMS>(), st>>>(
+                k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
                     bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, emB, counters, ids, (u32)C_FBB, gather, code);
                 DBG("k_sort_mid B");
             }

@@ -104,17 +104,6 @@ enum {
 #define CLS_C_ITEMS 18       // <= 18432
 #define CAP_A (CLS_A_THREADS * CLS_A_ITEMS)
 #define CAP_B (CLS_B_THREADS * CLS_B_ITEMS)
-// shape of the LSD sort (k_sort_mid) that takes class B: any THREADS x ITEMS >= CAP_B
-#ifndef MID_B_THREADS
-#define MID_B_THREADS 256
-#endif
-#ifndef MID_B_ITEMS
-#define MID_B_ITEMS 18
-#endif
-#ifndef MID_B_MINW
-#define MID_B_MINW 4          // __launch_bounds__ second argument: waves per SIMD the register allocation must allow
-#endif
-#define CAP_C (CLS_C_THREADS * CLS_C_ITEMS)
 
 #ifndef P1_THREADS
 #define P1_THREADS 1024
@@ -1949,7 +1938,7 @@ constexpr size_t sort_fast_lds_bytes()
 // persistent launch: workgroups stride over the list and skip what k_sort_fast already finished
 // (the class-B instance asks for 4 waves per SIMD = 128 VGPRs: one more resident workgroup per CU)
 template <int THREADS, int ITEMS, bool W>
-__global__ __launch_bounds__(THREADS, (THREADS == MID_B_THREADS && THREADS != 1024 && THREADS != 64 ? MID_B_MINW : 1)) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+__global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                       typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                       Emit em, u32* __restrict__ counters, const u32* __restrict__ ids, u32 ids_cnt_idx,
                                                       GatherSpec g, const u8* __restrict__ code)
