@@ -104,6 +104,7 @@ enum {
 #define CLS_C_ITEMS 18       // <= 18432
 #define CAP_A (CLS_A_THREADS * CLS_A_ITEMS)
 #define CAP_B (CLS_B_THREADS * CLS_B_ITEMS)
+#define CAP_C (CLS_C_THREADS * CLS_C_ITEMS)
 
 #ifndef P1_THREADS
 #define P1_THREADS 1024
