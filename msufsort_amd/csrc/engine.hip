@@ -72,7 +72,7 @@ struct DevBuf {
 }  // namespace
 
 // Tied rows of one slice between doubling steps (unordered list of local rows), so that a step costs time in
-// proportion to what is still tied, not to the slice.  A list holds at most rows / 4 entries; slices with more tied
+// proportion to what is still tied, not to the slice.  A list holds at most rows / 16 entries; slices with more tied
 // rows are scanned completely (act == nullptr in the kernels) and need the caller's full grp_prev copy instead.
 struct ActiveSet {
     DevBuf act[2], prev, cnt;          // cnt: 4 x u64 = {updates, tied rows, next list length, next list overflow}
@@ -985,7 +985,7 @@ int double_sort(msufsort_hip_ctx* c, ActiveSet& as, u64 n, typename Wd<W>::sa_t*
     hipStream_t st = c->stream;
     if (as.key_sa != (const void*)d_sa_slice || as.key_rows != rows) { as.valid = false; as.key_sa = d_sa_slice; as.key_rows = rows; }
     if (!as.cap) {
-        as.cap = std::max<u64>(rows / 4, 1024);
+        as.cap = std::max<u64>(rows / 16, 1024);
         for (auto& b : as.act) TRY(b.ensure(as.cap * 4));
         TRY(as.prev.ensure(as.cap * 4));
         TRY(as.cnt.ensure(32));

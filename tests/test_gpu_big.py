@@ -44,21 +44,25 @@ def test_dna_generator_on_gpu_matches_host():
     assert (d[:n].cpu().numpy() == gen.dna_bytes(n, 7)).all()
 
 
-@pytest.mark.parametrize("n,shards", [((1 << 32) + 12345, 8)])
-def test_beyond_int32_logical_shards(n, shards):
+@pytest.mark.parametrize("n,shards,need_gb", [((1 << 32) + 12345, 8, 200), (1 << 33, 32, 255)])
+def test_beyond_int32_logical_shards(n, shards, need_gb):
+    """n = 2^32 + 12,345, and BASELINE config 5 at its full size (8 GiB of DNA; there the 8 GPUs' shards become 32 logical
+    shards that take turns on the one GPU of the box - ~230 GB of its 288 GB of HBM)."""
     import torch
 
     import msufsort_amd as M
     dev = torch.device("cuda")
     free, total = torch.cuda.mem_get_info()
-    if free < 200 << 30:
-        pytest.skip("needs ~200 GB of HBM")
+    if free < need_gb << 30:
+        pytest.skip(f"needs ~{need_gb} GB of free HBM")
     t0 = time.time()
     d = _dna_gpu(n, 2024, dev)
     # long repeats: 64 MiB of tandem-repeat DNA spliced in, and one 1 MiB block copied 3 GiB further on
     tr = gen.dna_tandem_bytes(1 << 26, 11)
     d[1 << 30: (1 << 30) + (1 << 26)] = torch.from_numpy(tr).to(dev)
     d[(7 << 29): (7 << 29) + (1 << 20)] = d[12345: 12345 + (1 << 20)].clone()
+    if n > (6 << 30):
+        d[(11 << 29): (11 << 29) + (1 << 26)] = torch.from_numpy(gen.dna_tandem_bytes(1 << 26, 12)).to(dev)
     torch.cuda.synchronize()
     t1 = time.time()
     ctx = M.DeviceContext(0)
@@ -78,3 +82,6 @@ def test_beyond_int32_logical_shards(n, shards):
     bad = sa[: 1 << 20].clone()
     sa[5], sa[6] = int(bad[6]), int(bad[5])
     assert ctx.validate_sa(d, n, sa, index_bytes=8) > 0
+    del sa, d, bad
+    ctx.trim()
+    torch.cuda.empty_cache()
