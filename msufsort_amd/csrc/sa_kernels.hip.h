@@ -95,7 +95,9 @@ enum {
 };
 
 // size classes of the LDS sorts
+#ifndef TINY_MAX
 #define TINY_MAX 32
+#endif
 #define CLS_A_THREADS 64
 #define CLS_A_ITEMS 8        // <= 512
 #define CLS_B_THREADS 256
@@ -1654,8 +1656,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
     constexpr int NW = NBIN / 4;
     constexpr int EW = NW / THREADS;
     constexpr u32 TRASH_POS = CAP + 32;
-    constexpr u32 TRASH_W = NW;
-    static_assert(2 * NW + 16 <= CAP + 64, "the sub-bucket table must fit under the composite array");
+    constexpr u32 NWP = NW;
+    constexpr u32 TRASH_W = NWP;
+    static_assert(2 * NWP + 16 <= CAP + 64, "the sub-bucket table must fit under the composite array");
     static_assert((EW & (EW - 1)) == 0 && EW >= 1 && (THREADS & (THREADS - 1)) == 0, "power-of-two shapes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32* ex = reinterpret_cast<u32*>(smem_raw);                 // CAP + 64: sub-bucket table, composites, index exchange
@@ -1675,7 +1678,8 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
     // table entry w lives at tab[FAST_W(w)]: thread t scans the EW consecutive entries t*EW .. t*EW+EW-1, which this map
     // puts at k*THREADS + t - consecutive lanes touch consecutive entries (no bank conflicts in the scan)
 #define FAST_W(w) ((((w) & (u32)(EW - 1)) * (u32)THREADS) | ((w) / (u32)EW))
-#define BYTESUM(x) (((x) * 0x01010101u) >> 24)
+#define FAST_SCAN_AT(k) ((u32)(k) * (u32)THREADS + t)
+#define BYTESUM(x) __builtin_amdgcn_sad_u8((x), 0u, 0u)        // sum of the four bytes: one full-rate instruction (a 32-bit multiply is quarter rate)
     u32 seg = blockIdx.x;
     if (seg >= nseg) return;
     // descriptors are fetched two segments ahead and the record buffer is picked with selects, not with an indexed
@@ -1736,7 +1740,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
             if (t < 16) misc[t] = 0;
             uint4* h4 = reinterpret_cast<uint4*>(ex);
             const uint4 z4 = {0u, 0u, 0u, 0u};
-            for (u32 i = t; i < (2u * NW + 16u) / 4u; i += THREADS) h4[i] = z4;
+            for (u32 i = t; i < (2u * NWP + 16u) / 4u; i += THREADS) h4[i] = z4;
             F2P(11);
             __syncthreads();                                                        // (1)
             F2P(1);
@@ -1763,7 +1767,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
         if (ok) {                                                // ---- phase 3: scan -> base of every table entry
             u32 sum = 0;
 #pragma unroll
-            for (int k = 0; k < EW; ++k) sum += BYTESUM(tab[k * THREADS + t].x);
+            for (int k = 0; k < EW; ++k) sum += BYTESUM(tab[FAST_SCAN_AT(k)].x);
             u32 wt;
             u32 e = wave_excl_scan(sum, wt);
             if (lane == 63) tot[wv] = wt;
@@ -1773,7 +1777,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
             for (int k = 0; k < W; ++k) if (k < (int)wv) wb += tot[k];
             e += wb;
 #pragma unroll
-            for (int k = 0; k < EW; ++k) { tab[k * THREADS + t].y = e; e += BYTESUM(tab[k * THREADS + t].x); }
+            for (int k = 0; k < EW; ++k) { tab[FAST_SCAN_AT(k)].y = e; e += BYTESUM(tab[FAST_SCAN_AT(k)].x); }
             __syncthreads();                                                        // (4)
             F2P(3);
         }
@@ -1919,6 +1923,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_fast2(RecBufs bufs, const Desc
 #endif
 #undef FAST_P
 #undef FAST_W
+#undef FAST_SCAN_AT
 #undef BYTESUM
 #undef FAST_SRC
 #undef F2_LOAD
@@ -1987,7 +1992,7 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
     constexpr u32 KL = klow<W>();
     __shared__ u8 s_code[256];
     if (g.text) s_code[threadIdx.x] = code[threadIdx.x];
-    constexpr int WIN = 256, HALO = 32, TOT = WIN + HALO;
+    constexpr int WIN = 256, HALO = TINY_MAX, TOT = WIN + HALO;
     __shared__ u32 lkey[TOT], lrun[TOT];
     __shared__ u32 s_total, s_base, s_cb, s_ce, s_fb, s_fe;      // window total / base; chunk [cb, ce); pending fill [fb, fe)
     const u32 count = counters[cnt_idx];

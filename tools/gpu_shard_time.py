@@ -24,3 +24,5 @@ for G in (1, 2, 4, 8):
         times.append(best * 1e3)
     ok = ctx.validate_sa(d, n, full) == 0
     print(f"G={G}: per-shard ms {['%.2f' % x for x in times]} max {max(times):.2f} valid {ok}", flush=True)
+    tm = ctx.timings()
+    print(f"      last shard device phases: total {tm.total_ms:.2f} hist {tm.hist16_ms:.2f} scatter0 {tm.scatter0_ms:.2f} partition {tm.scatter1_ms:.2f} sorts {tm.bucket_sort_ms:.2f} refine {tm.refine_ms:.2f}", flush=True)
