@@ -85,3 +85,63 @@ def test_beyond_int32_logical_shards(n, shards, need_gb):
     del sa, d, bad
     ctx.trim()
     torch.cuda.empty_cache()
+
+
+def _random_gpu(n, seed, dev):
+    """gen.random_bytes(n, seed) computed on the GPU (same splitmix64 stream)."""
+    import torch
+    out = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    blk = 1 << 25
+    nd = (n + 7) // 8
+    c1, c2, c3 = (np.int64(np.uint64(x).astype(np.int64)) for x in (0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB))
+    for s in range(0, nd, blk):
+        c = min(blk, nd - s)
+        k = torch.arange(s + 1, s + c + 1, dtype=torch.int64, device=dev)
+        z = k * c1 + np.int64(seed)
+        shr = lambda x, b: (x >> b) & ((1 << (64 - b)) - 1)   # noqa: E731
+        z = (z ^ shr(z, 30)) * c2
+        z = (z ^ shr(z, 27)) * c3
+        z = z ^ shr(z, 31)
+        b = z.view(torch.uint8)
+        take = min(b.numel(), n - s * 8)
+        out[s * 8: s * 8 + take] = b[:take]
+    return out
+
+
+def test_int32_limit_and_first_wide_size():
+    """The two sides of the index-width boundary on random bytes: n = 2^31 - 2 (largest int32 build, narrow engine) and
+    n = 2^31 + 5 through the int64 entry point (smallest input that MUST take the wide engine), both checked on device."""
+    import torch
+
+    import msufsort_amd as M
+    dev = torch.device("cuda")
+    free, _ = torch.cuda.mem_get_info()
+    if free < 230 << 30:
+        pytest.skip("needs ~230 GB of free HBM")
+    n = (1 << 31) - 2
+    d = _random_gpu((1 << 31) + 5, 77, dev)
+    assert (d[:100003].cpu().numpy() == gen.random_bytes(100003, 77)).all()
+    ctx = M.DeviceContext(0)
+    sa = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    keep = d[n:n + 64].clone()
+    d[n:n + 64] = 0                                  # the int32 build sees the first 2^31 - 2 bytes (+ its zero pad)
+    t0 = time.time()
+    ctx.make_sa(d, n, sa)
+    t1 = time.time()
+    assert int(sa[0]) == n and ctx.validate_sa(d, n, sa) == 0
+    print(f"\nn=2^31-2 random, int32 rows: {t1 - t0:.3f}s")
+    del sa
+    ctx.trim(); torch.cuda.empty_cache()
+    d[n:n + 64] = keep
+    n = (1 << 31) + 5
+    sa64 = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    t0 = time.time()
+    ctx.make_sa_i64(d, n, sa64)
+    t1 = time.time()
+    tm = ctx.timings()
+    assert tm.reserved[1] >= 2                       # logical shards: the wide engine ran
+    ctx.trim()
+    assert int(sa64[0]) == n and ctx.validate_sa(d, n, sa64, index_bytes=8) == 0
+    print(f"n=2^31+5 random, int64 rows, wide engine ({tm.reserved[1]} logical shards): {t1 - t0:.3f}s")
+    del sa64, d
+    ctx.trim(); torch.cuda.empty_cache()
