@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256) void k_validate_order(const u8* __restrict__ t
 //   (v)   fragment order by list ranking (pointer jumping) instead of the serial stitch (cpp:2065-2095)
 // ================================================================================================
 #define IBWT_WT 8192u          // rows per wave-tile
-#define IBWT_S 256u            // splitter stride (rows that are multiples of S start a chain)
+#ifndef IBWT_S
+#define IBWT_S 512u            // splitter stride (rows that are multiples of S start a chain)
+#endif
 
 __device__ __forceinline__ u32 ibwt_sym(const u8* __restrict__ bwt, u32 row, u32 sent)
 {
@@ -172,8 +174,13 @@ __global__ __launch_bounds__(256) void k_ibwt_count(const u8* __restrict__ bwt, 
     if (tile < ntiles) {
         const u32 beg = tile * IBWT_WT;
         const u32 end = (rows - beg < IBWT_WT) ? rows : beg + IBWT_WT;
-        for (u32 r = beg + lane; r < end; r += 64)
-            if (r != sent) atomicAdd(&h[w][ibwt_sym(bwt, r, sent)], 1u);
+        for (u32 r0 = beg + lane; r0 < end; r0 += 64u * 8u) {          // eight byte loads in flight per lane
+            u32 sy[8];
+#pragma unroll
+            for (u32 k = 0; k < 8; ++k) { const u32 r = r0 + 64u * k; sy[k] = (r < end && r != sent) ? ibwt_sym(bwt, r, sent) : 256u; }
+#pragma unroll
+            for (u32 k = 0; k < 8; ++k) if (sy[k] < 256u) atomicAdd(&h[w][sy[k]], 1u);
+        }
     }
     __syncthreads();
     if (tile < ntiles)
@@ -256,10 +263,17 @@ __global__ __launch_bounds__(256) void k_ibwt_scatter(const u8* __restrict__ bwt
     const u32 beg = tile * IBWT_WT;
     const u32 end = (rows - beg < IBWT_WT) ? rows : beg + IBWT_WT;
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    for (u32 r0 = beg; r0 < end; r0 += 64) {
+    for (u32 rb = beg; rb < end; rb += 64u * 4u) {               // four byte loads in flight per lane
+        u32 cs[4];
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) { const u32 r = rb + 64u * k + lane; cs[k] = (r < end && r != sent) ? ibwt_sym(bwt, r, sent) : 0u; }
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) {
+        const u32 r0 = rb + 64u * k;
+        if (r0 >= end) break;
         const u32 r = r0 + lane;
         const bool valid = r < end && r != sent;
-        const u32 c = valid ? ibwt_sym(bwt, r, sent) : 0u;
+        const u32 c = cs[k];
         u64 mask = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -273,6 +287,7 @@ __global__ __launch_bounds__(256) void k_ibwt_scatter(const u8* __restrict__ bwt
             if ((int)lane == leader) old = atomicAdd(&cur[w][c], (u32)__popcll(mask));
             old = __shfl(old, leader, 64);
             link[old + (u32)__popcll(mask & lt_mask)] = r;
+        }
         }
     }
 }
@@ -294,7 +309,9 @@ __device__ __forceinline__ u32 ibwt_start(u32 id, u32 sent, u32 kreg) { return i
 // of the next row is in flight.  Every lane runs IBWT_NCH independent chains (the reference interleaves many chains per
 // thread the same way, cpp:1922,1976-2018): the walk is bound by dependent random sector reads, and the loads in
 // flight per lane are what one lane can add to the memory-level parallelism.
-#define IBWT_CW 512u
+#ifndef IBWT_CW
+#define IBWT_CW 1024u
+#endif
 #ifndef IBWT_NCH
 #define IBWT_NCH 2
 #endif
