@@ -78,7 +78,7 @@ struct ActiveSet {
     DevBuf act[2], prev, cnt;          // cnt: 4 x u64 = {updates, tied rows, next list length, next list overflow}
     u64 count = 0, cap = 0;
     int cur = 0;
-    bool valid = false;
+    bool valid = false, tried_list = false;
     const void* key_sa = nullptr; u64 key_rows = 0;     // which slice the list describes
     void release() { act[0].release(); act[1].release(); prev.release(); cnt.release(); valid = false; count = 0; cap = 0; }
 };
@@ -203,6 +203,19 @@ struct msufsort_hip_ctx {
         for (auto& a : active) a.release();
         active.clear();
         cap_m = 0; cap_for_m = 0;
+    }
+
+    size_t held_bytes() const
+    {
+        size_t b = 0;
+        for (auto& x : rec) b += x.bytes;
+        for (auto& x : pool_rec) b += x.bytes;
+        for (auto& x : pool_hdr) b += x.bytes;
+        for (int s = 0; s < 2; ++s) { for (int k = 0; k < 3; ++k) b += lists[s][k].bytes; b += large_round[s].bytes + lvl[s].bytes; }
+        b += isa.bytes + grp_full.bytes + grp_prev.bytes + upd.bytes + sub_partial.bytes + hist_partial.bytes + seg_hist.bytes + child_start.bytes + cursor.bytes;
+        b += doneB.bytes + doneC.bytes + aux0.bytes + aux1.bytes + aux2.bytes + aux3.bytes + sa_own.bytes + text_own.bytes;
+        for (auto& a : active) b += a.act[0].bytes + a.act[1].bytes + a.prev.bytes;
+        return b;
     }
 
     // frees the sort workspace (records, pools, lists) but keeps the small fixed buffers: single-process builds of very
@@ -751,7 +764,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     memset(&tm, 0, sizeof tm);
     tm.n = (int64_t)n; tm.m = (int64_t)m;
     TRY(c->set_attrs());
-    for (auto& a : c->active) a.valid = false;      // lists of still-tied rows belong to the previous build's doubling steps
+    for (auto& a : c->active) { a.valid = false; a.tried_list = false; }      // lists of still-tied rows belong to the previous build's doubling steps
     HIP_TRY(hipEventRecord(c->ev[0], st));
     if (with_head) hipLaunchKernelGGL(k_sa_head<W>, dim3(grid_for(std::max<u64>(z, 1))), dim3(256), 0, st, d_sa_rows, n, z);
     auto finish_groups = [&]() { if (d_grp_rows && slice_rows) hipLaunchKernelGGL(k_grp_iota, dim3(grid_for(slice_rows)), dim3(256), 0, st, d_grp_rows, slice_rows, 0u); };
@@ -983,7 +996,7 @@ int double_sort(msufsort_hip_ctx* c, ActiveSet& as, u64 n, typename Wd<W>::sa_t*
 {
     const Digits dg = plan_digits<W>(n);
     hipStream_t st = c->stream;
-    if (as.key_sa != (const void*)d_sa_slice || as.key_rows != rows) { as.valid = false; as.key_sa = d_sa_slice; as.key_rows = rows; }
+    if (as.key_sa != (const void*)d_sa_slice || as.key_rows != rows) { as.valid = false; as.tried_list = false; as.key_sa = d_sa_slice; as.key_rows = rows; }
     if (!as.cap) {
         as.cap = std::max<u64>(rows / 16, 1024);
         for (auto& b : as.act) TRY(b.ensure(as.cap * 4));
@@ -991,6 +1004,15 @@ int double_sort(msufsort_hip_ctx* c, ActiveSet& as, u64 n, typename Wd<W>::sa_t*
         TRY(as.cnt.ensure(32));
     }
     HIP_TRY(hipMemsetAsync(as.cnt.p, 0, 32, st));
+    if (!as.valid && !as.tried_list) {
+        // first step on this slice: one cheap look at the group heads tells whether the tied rows fit a list
+        as.tried_list = true;
+        hipLaunchKernelGGL(k_list_tied, dim3(grid_for(rows, 256, 16384u)), dim3(256), 0, st, d_grp_slice, rows, as.act[as.cur].template as<u32>(), as.cap, as.cnt.template as<unsigned long long>());
+        HIP_TRY(hipMemcpyAsync(c->h_upd, as.cnt.p, 32, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c->h_upd[3] == 0) { as.valid = true; as.count = c->h_upd[2]; }
+        HIP_TRY(hipMemsetAsync(as.cnt.p, 0, 32, st));
+    }
     const bool list = as.valid;
     const u32* act = list ? as.act[as.cur].template as<u32>() : nullptr;
     const u32 nact = list ? (u32)as.count : 0u;
@@ -1073,6 +1095,11 @@ int build_logical(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* 
     if (opts_in) o = *opts_in;
     o.n_shards = std::max(G, 2);          // (forces the "publish groups" exit; a single wide shard takes it anyway)
     if (o.text_rounds <= 0) o.text_rounds = W ? 3 : 8;
+    {   // size the one workspace for the largest shard (growing it shard by shard would free and reallocate all of it)
+        u64 mx = 0;
+        for (int g = 0; g < G; ++g) mx = std::max(mx, sc.rows[g + 1] - sc.rows[g]);
+        TRY(c->ensure_workspace(mx));
+    }
     bool any = false;
     u64 depth = 0;
     msufsort_hip_timings acc{};
@@ -1153,11 +1180,12 @@ int build_logical(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* 
 }
 
 // number of logical shards a single-process build needs so that one shard's workspace (~70 B per suffix) fits
-int auto_shards(u64 n, bool wide)
+int auto_shards(msufsort_hip_ctx* c, u64 n, bool wide)
 {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
-    const u64 fixed = (n + 1) * (wide ? 8 + 4 + 4 : 4 + 4 + 4);          // rank array + grp + grp_prev
+    free_b += c->held_bytes();                                            // what this context already holds is reused, not needed again
+    const u64 fixed = (n + 1) * (wide ? 8 + 4 + 4 : 4 + 4 + 4) + n + ((u64)4 << 30);          // rank array + grp + grp_prev; lists of tied rows, update window
     const u64 avail = free_b > fixed + ((u64)8 << 30) ? free_b - fixed - ((u64)8 << 30) : ((u64)4 << 30);
     u64 per = std::min<u64>(avail / 80, wide ? (1ull << 30) : (1ull << 31));
     per = std::max<u64>(per, 1u << 20);
@@ -1525,7 +1553,7 @@ int msufsort_hip_make_sa_i64_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
         return MSUFSORT_HIP_OK;
     }
     TRY(zero_pad(c, d_text, (u64)n));
-    int G = auto_shards((u64)n, true);
+    int G = auto_shards(c, (u64)n, true);
     if (opts && opts->n_shards > G) G = opts->n_shards;
     return build_logical<true>(c, d_text, (u64)n, reinterpret_cast<u64*>(d_sa_out), G, opts);
 }

@@ -2253,6 +2253,34 @@ __global__ __launch_bounds__(256) void k_emit_updates(const typename Wd<W>::sa_t
     }
 }
 
+// list of the tied rows of a slice (any order): lets the very first doubling step run on the list instead of on all rows.
+// cnt[2] = entries written, cnt[3] = 1 if they did not fit
+__global__ __launch_bounds__(256) void k_list_tied(const u32* __restrict__ grp, u64 rows, u32* __restrict__ act, u64 act_cap, unsigned long long* __restrict__ cnt)
+{
+    __shared__ u32 s_tied;
+    __shared__ unsigned long long s_base;
+    const u64 lt_mask = lane_id() ? (~0ull >> (64 - lane_id())) : 0ull;
+    for (u64 b = (u64)blockIdx.x * 256u; b < rows; b += (u64)gridDim.x * 256u) {
+        if (threadIdx.x == 0) s_tied = 0;
+        __syncthreads();
+        const u64 r = b + threadIdx.x;
+        bool tied = false;
+        if (r < rows) { const u32 g = grp[r]; tied = g != (u32)r || (r + 1 < rows && grp[r + 1] == (u32)r); }
+        const u64 mt = __ballot(tied);
+        u32 tbase = 0;
+        if (lane_id() == 0 && mt) tbase = atomicAdd(&s_tied, (u32)__popcll(mt));
+        tbase = __shfl(tbase, 0, 64);
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_tied ? atomicAdd(&cnt[2], (unsigned long long)s_tied) : 0ull;
+        __syncthreads();
+        if (tied) {
+            const u64 o = s_base + tbase + (u32)__popcll(mt & lt_mask);
+            if (o < act_cap) act[o] = (u32)r; else cnt[3] = 1ull;
+        }
+        __syncthreads();
+    }
+}
+
 // prev[i] = group head of active row act[i] when the step begins
 __global__ __launch_bounds__(256) void k_gather_prev(const u32* __restrict__ grp, const u32* __restrict__ act, u64 nact, u32* __restrict__ prev)
 {

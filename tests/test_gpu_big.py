@@ -69,14 +69,17 @@ def test_beyond_int32_logical_shards(n, shards, need_gb):
     sa = torch.empty(n + 1, dtype=torch.int64, device=dev)
     ctx.make_sa_i64(d, n, sa, n_shards=shards, verbose=int(os.environ.get("MSUFSORT_TEST_VERBOSE", "0")))
     t2 = time.time()
+    sa.fill_(-1)
+    ctx.make_sa_i64(d, n, sa, n_shards=shards)       # again, with every buffer in place (the first call allocates ~200 GB)
+    t2b = time.time()
     tm = ctx.timings()
     assert tm.reserved[1] >= shards and tm.doubling_rounds >= 1
     assert int(sa[0]) == n
     ctx.trim()
     errs = ctx.validate_sa(d, n, sa, index_bytes=8)
     t3 = time.time()
-    print(f"\nn={n}: generate {t1 - t0:.1f}s, wide SA build {t2 - t1:.2f}s ({tm.reserved[1]} logical shards, depth {tm.reserved[0]}, "
-          f"{tm.doubling_rounds} doubling steps, doubling {tm.other_ms:.0f} ms), check {t3 - t2:.1f}s, errors {errs}")
+    print(f"\nn={n}: generate {t1 - t0:.1f}s, wide SA build {t2 - t1:.2f}s with allocations, {t2b - t2:.2f}s again ({tm.reserved[1]} logical shards, depth {tm.reserved[0]}, "
+          f"{tm.doubling_rounds} doubling steps, doubling {tm.other_ms:.0f} ms), check {t3 - t2b:.1f}s, errors {errs}")
     assert errs == 0
     # the checker sees damage at this size too
     bad = sa[: 1 << 20].clone()
