@@ -62,5 +62,10 @@ def test_demo_cli_modes(tmp_path):
     for mode, must in (("s", "suffix array validated"), ("l", "lcp array validated"), ("b", "BWT validated")):
         r = subprocess.run([exe, mode, str(f), "4"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and must in r.stdout, r.stdout + r.stderr
+    # 40 MiB: the drop-in header takes msufsort_hip_make_sa_multi (all visible GPUs, slices streamed to the host) from 32 MiB on
+    big = tmp_path / "big.bin"
+    gen.random_bytes(40 << 20, 5).tofile(big)
+    r = subprocess.run([exe, "s", str(big), "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "suffix array validated" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([exe, "t"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " 0 errors" in r.stdout, r.stdout + r.stderr
