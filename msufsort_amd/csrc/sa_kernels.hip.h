@@ -4,9 +4,11 @@
 //   count_suffixes              reference msufsort.cpp:1496-1521  -> k_hist16 (+ k_reduce16/k_scan16)
 //   bucket offsets              reference msufsort.cpp:1603-1630  -> k_scan16
 //   initial_two_byte_radix_sort reference msufsort.cpp:1525-1555  -> k_scatter0 + k_partition (2 x 8 bit)
-//   multikey_quicksort          reference msufsort.cpp:488-642    -> k_sort_mid / k_sort_tiny (LDS radix on
+//   multikey_quicksort          reference msufsort.cpp:488-642    -> k_sort_fast2 / k_sort_mid / k_sort_tiny (LDS sorts on
 //                                                                    big-endian key words) + k_partition levels
-//   tandem-repeat shortcut      reference msufsort.cpp:316-484    -> prefix doubling on ranks (k_refill isa mode)
+//   tandem-repeat shortcut      reference msufsort.cpp:316-484    -> prefix doubling on ranks: in place (k_isa_*, k_refill rank
+//                                                                    mode) or distributed over shards (k_import_groups,
+//                                                                    k_refill_rows, k_emit_updates, k_apply_updates)
 // and, because every suffix is sorted here (no A/B/B* reduction), the stage-2 induction sweeps
 // (cpp:646-1057) have no counterpart: the output of the sorts is already the final suffix array.
 //
@@ -1186,10 +1188,13 @@ __global__ __launch_bounds__(256) void k_refill_rows(const typename Wd<W>::sa_t*
 // ------------------------------------------------------------------------------------------------
 // LDS sort of one mid-size segment (33 .. THREADS*ITEMS records) - the GPU counterpart of
 // multikey_quicksort + multikey_insertion_sort (cpp:488-642, 223-312) for one partition.
-// LSD radix on the key bytes that actually differ inside the segment, 8 bits per pass, stable ranks
-// from wave-wide digit matching (ballots) + per-wave digit counters in LDS.  After sorting: rows are
-// written to the suffix array, equal-key runs are detected with ballot bitmaps and the still-tied
-// runs are compacted into next round's tiny pool / segment array.
+// LSD radix on the key bytes that actually differ inside the segment, 8 bits per pass, stable ranks from
+// per-wave digit counters in LDS: a returning LDS atomic per record (lanes of one instruction that meet on an
+// address are served lowest lane first on gfx950; every segment checks that it came out sorted) or, as the safe
+// fallback, wave-wide digit matching with ballots (Emit::safe_rank).  In text rounds the records arrive with
+// the suffix index only and the keys are gathered here (GatherSpec).  After sorting: rows are written to the
+// suffix array, equal-key runs are detected with ballot bitmaps and the still-tied runs are compacted into next
+// round's tiny pool / segment array.
 // ------------------------------------------------------------------------------------------------
 template <int THREADS, int ITEMS>
 constexpr size_t sort_mid_lds_bytes()
