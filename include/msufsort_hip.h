@@ -192,7 +192,8 @@ int msufsort_hip_make_sa_multi(const int32_t* devices, int32_t n_dev, const uint
 int msufsort_hip_plan_cuts(const uint64_t* bstart, int64_t n, int64_t z, int32_t n_shards,
                            uint32_t* cuts, int64_t* rows);
 
-/* ---- forward BWT: replaces msufsort::forward_burrows_wheeler_transform (cpp:1771-1817) ---- */
+/* ---- forward BWT: replaces msufsort::forward_burrows_wheeler_transform (cpp:1771-1817) ----
+ *      (n > 2^31 - 2, or opts->force_wide: through the wide engine and int64 rows) */
 int msufsort_hip_forward_bwt(uint8_t* inout, int64_t n, int64_t* sentinel_row,
                              const msufsort_hip_opts* opts);
 int msufsort_hip_forward_bwt_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,

@@ -146,5 +146,12 @@ def test_int32_limit_and_first_wide_size():
     ctx.trim()
     assert int(sa64[0]) == n and ctx.validate_sa(d, n, sa64, index_bytes=8) == 0
     print(f"n=2^31+5 random, int64 rows, wide engine ({tm.reserved[1]} logical shards): {t1 - t0:.3f}s")
+    # forward BWT beyond the int32 rows (wide engine inside): every byte equal to T[SA[r] - 1], sentinel row where SA[r] == 0
+    bwt = torch.empty(n, dtype=torch.uint8, device=dev)
+    sent = ctx.forward_bwt(d, n, bwt)
+    assert int(sa64[sent]) == 0
+    rows = torch.cat([sa64[:sent], sa64[sent + 1:]])
+    assert torch.equal(bwt, d[rows - 1])
+    del bwt, rows
     del sa64, d
     ctx.trim(); torch.cuda.empty_cache()
