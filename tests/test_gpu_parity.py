@@ -498,3 +498,33 @@ def test_shard_cuts_split_heavy_keys(M, oracle_mod, monkeypatch):
         sa = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
         ctx.make_sa(d, n, sa, logical_shards=8)
         assert (sa.cpu().numpy() == _want(oracle_mod, t)).all(), name
+
+
+@pytest.mark.parametrize("env", ["MSUFSORT_HIP_SAFE_RANK", "MSUFSORT_HIP_NO_FUSE", "MSUFSORT_HIP_NO_FAST"])
+def test_fallback_paths_stay_exact(M, oracle_mod, monkeypatch, env):
+    """The paths the defaults avoid must stay bit-exact: LSD ranks from wave ballots (what a failed sortedness check falls back
+    to), key gathers as separate k_refill passes, and k_sort_mid in place of k_sort_fast2."""
+    monkeypatch.setenv(env, "1")
+    for t in (gen.random_bytes(1 << 21, 4), gen.text_bytes(1 << 20, 6), gen.dna_tandem_bytes(400000, 2), np.tile(gen.dna_bytes(53, 1), 4000)):
+        assert (M.make_suffix_array(t) == _want(oracle_mod, t)).all(), (env, t.size)
+    t = gen.dna_tandem_bytes(300000, 8)
+    assert (M.make_suffix_array_i64(t, force_wide=True, n_shards=2, text_rounds=1) == _want(oracle_mod, t)).all()
+
+
+def test_cached_contexts_and_trim(M, oracle_mod):
+    """One-shot entry points reuse a process-wide context (no workspace allocation per call); releasing the cache and
+    trimming a context must leave both usable."""
+    import torch
+    t = gen.text_bytes(200000, 31)
+    want = _want(oracle_mod, t)
+    assert (M.make_suffix_array(t) == want).all()
+    M._lib.lib().msufsort_hip_release_cached()
+    assert (M.make_suffix_array(t) == want).all()
+    ctx = M.DeviceContext(0)
+    d = _dev(M, t)
+    sa = torch.empty(t.size + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, t.size, sa)
+    ctx.trim()
+    sa.zero_()
+    ctx.make_sa(d, t.size, sa)
+    assert (sa.cpu().numpy() == want).all()
