@@ -96,7 +96,7 @@ def main():
     d_text[:n] = torch.from_numpy(t).to(dev)
     d_sa = torch.empty(n + 1, dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)          # the engine works on its own HIP stream: the upload must have landed
-    ctx = M.DeviceContext(local, n)
+    ctx = M.DeviceContext(local, n if world == 1 else n // world + n // (8 * world) + (1 << 20))     # workspace: my shard's suffixes
 
     bounds = ctx.shard_bounds(d_text, n, world) if world > 1 else None
     exchange = mdist.select_exchange(dist, dev) if world > 1 else None
