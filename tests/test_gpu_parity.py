@@ -475,6 +475,8 @@ def test_single_process_multi_gpu_entry(M, oracle_mod, devices, shards):
     sa = M.make_suffix_array_multi(t, devices, n_shards=shards, index_bytes=8, force_wide=True)
     assert sa.dtype == np.int64 and (sa == _want(oracle_mod, t)).all()
     assert M.make_suffix_array_multi(np.zeros(0, np.uint8), devices).tolist() == [0]
+    sa = M.make_suffix_array_multi(t, devices, n_shards=shards, index_bytes=8)          # int64 rows from the narrow engine
+    assert sa.dtype == np.int64 and (sa == _want(oracle_mod, t)).all()
 
 
 def test_shard_cuts_split_heavy_keys(M, oracle_mod, monkeypatch):
