@@ -166,25 +166,35 @@ __device__ __forceinline__ u32 ibwt_sym(const u8* __restrict__ bwt, u32 row, u32
 
 __global__ __launch_bounds__(256) void k_ibwt_count(const u8* __restrict__ bwt, u32 rows, u32 sent, u32 ntiles, u32* __restrict__ counts)
 {
-    __shared__ u32 h[4][256];
+    // eight copies of every wave's 256 bins (copy = lane & 7): text puts a third of its bytes on a handful of symbols, and
+    // lanes that meet on one LDS address are served one after the other
+    __shared__ u32 h[4][8][256];
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 tile = blockIdx.x * 4 + w;
-    for (u32 i = lane; i < 256; i += 64) h[w][i] = 0;
+    for (u32 i = lane; i < 8u * 256u; i += 64) (&h[w][0][0])[i] = 0;
     __syncthreads();
     if (tile < ntiles) {
         const u32 beg = tile * IBWT_WT;
         const u32 end = (rows - beg < IBWT_WT) ? rows : beg + IBWT_WT;
-        for (u32 r0 = beg + lane; r0 < end; r0 += 64u * 8u) {          // eight byte loads in flight per lane
-            u32 sy[8];
+        // the rows [beg, end) without the sentinel row are the stored bytes [b0, b1): 16 of them per lane and load
+        const u32 b0 = beg - (beg > sent ? 1u : 0u), b1 = end - (end > sent ? 1u : 0u);
+        for (u32 o = b0 + lane * 16u; o < b1; o += 64u * 16u) {
+            u32 v[4] = {0, 0, 0, 0};
+            const u32 lim = b1 - o >= 16u ? 16u : b1 - o;
+            if (lim == 16u) __builtin_memcpy(v, bwt + o, 16);
+            else for (u32 k = 0; k < lim; ++k) v[k >> 2] |= (u32)bwt[o + k] << (8u * (k & 3u));
 #pragma unroll
-            for (u32 k = 0; k < 8; ++k) { const u32 r = r0 + 64u * k; sy[k] = (r < end && r != sent) ? ibwt_sym(bwt, r, sent) : 256u; }
-#pragma unroll
-            for (u32 k = 0; k < 8; ++k) if (sy[k] < 256u) atomicAdd(&h[w][sy[k]], 1u);
+            for (u32 k = 0; k < 16; ++k) if (k < lim) atomicAdd(&h[w][lane & 7u][(v[k >> 2] >> (8u * (k & 3u))) & 255u], 1u);
         }
     }
     __syncthreads();
     if (tile < ntiles)
-        for (u32 i = lane; i < 256; i += 64) counts[(u64)i * ntiles + tile] = h[w][i];
+        for (u32 i = lane; i < 256; i += 64) {
+            u32 sum = 0;
+#pragma unroll
+            for (u32 q = 0; q < 8; ++q) sum += h[w][q][i];
+            counts[(u64)i * ntiles + tile] = sum;
+        }
 }
 
 // generic device-wide exclusive scan of u32[N]: partial -> top -> final
@@ -416,7 +426,14 @@ __global__ __launch_bounds__(256) void k_ibwt_assemble(const u8* __restrict__ se
     const u32 len = len0[seg];
     const u64 pos = (u64)n - dist_to_end[seg];
     const u8* src = segbuf + (u64)seg * IBWT_CW;
-    for (u32 o = lane; o < len; o += 64u) out[pos + o] = src[o];
+    // 16 bytes per lane (the buffer is aligned, the text position is not: unaligned 16-byte stores), bytes for the tail
+    const u32 full = len & ~15u;
+    for (u32 o = lane * 16u; o < full; o += 64u * 16u) {
+        uint4 v;
+        __builtin_memcpy(&v, src + o, 16);
+        __builtin_memcpy(out + pos + o, &v, 16);
+    }
+    if (lane < (len & 15u)) out[pos + full + lane] = src[full + lane];
 }
 
 __global__ __launch_bounds__(256) void k_ibwt_jump(const u32* __restrict__ nxt, const u32* __restrict__ dist, u32 K,
