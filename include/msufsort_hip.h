@@ -54,7 +54,10 @@ typedef struct msufsort_hip_opts {
                                   tied set stops shrinking past the depth the alphabet needs, at the latest after 24) */
     int32_t verbose;           /* 1: per-round statistics on stderr */
     int32_t force_wide;        /* int64 entry points: use the wide (40-bit index) engine also below 2^31 - 1 bytes (parity tests) */
-    int32_t reserved[10];
+    int32_t two_stage;         /* msufsort_hip_make_sa_i32_dev: 0 = sort only the B* suffixes and induce the others when the input
+                                  looks like text (byte alphabet of 16..128 symbols, no very long runs), 1 = whenever possible,
+                                  -1 = never; inputs that do not suit fall back to sorting all suffixes */
+    int32_t reserved[9];
 } msufsort_hip_opts;
 
 /* Per-phase device time of the last build on this context (hipEvent, milliseconds), plus

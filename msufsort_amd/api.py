@@ -35,9 +35,10 @@ def _u8(data) -> np.ndarray:
     return a
 
 
-def _opts(device=0, verbose=0, text_rounds=0, shard=0, n_shards=1, force_wide=0) -> Opts:
+def _opts(device=0, verbose=0, text_rounds=0, shard=0, n_shards=1, force_wide=0, two_stage=0) -> Opts:
     o = Opts()
     o.device, o.verbose, o.text_rounds, o.shard, o.n_shards, o.force_wide = device, verbose, text_rounds, shard, n_shards, int(force_wide)
+    o.two_stage = int(two_stage)
     return o
 
 
@@ -168,10 +169,11 @@ class DeviceContext:
             return int(x.data_ptr())
         return int(x)
 
-    def make_sa(self, d_text, n: int, d_sa, *, verbose=0, text_rounds=0, logical_shards=0):
+    def make_sa(self, d_text, n: int, d_sa, *, verbose=0, text_rounds=0, logical_shards=0, two_stage=0):
         """d_text: >= n+64 bytes in HBM; d_sa: n+1 int32 in HBM.  logical_shards > 1: the shards of a multi-GPU build,
-        one after the other on this GPU (same code path as the distributed build, bounded workspace)."""
-        o = _opts(self.device, verbose, text_rounds, -1 if logical_shards > 1 else 0, max(logical_shards, 1))
+        one after the other on this GPU (same code path as the distributed build, bounded workspace).  two_stage: 0 = B* sort +
+        induction when the input looks like text, 1 = whenever possible, -1 = never (sort all suffixes)."""
+        o = _opts(self.device, verbose, text_rounds, -1 if logical_shards > 1 else 0, max(logical_shards, 1), two_stage=two_stage)
         _lib.check(self._L.msufsort_hip_make_sa_i32_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa), C.byref(o)), "make_sa_dev")
 
     def make_sa_i64(self, d_text, n: int, d_sa64, *, verbose=0, text_rounds=0, force_wide=False, n_shards=1):

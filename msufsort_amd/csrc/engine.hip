@@ -5,6 +5,7 @@
 // There is NO CPU fallback in this library: without a HIP device every entry point fails.
 #include "sa_kernels.hip.h"
 #include "bwt_kernels.hip.h"
+#include "induce_kernels.hip.h"
 #include "../../include/msufsort_hip.h"
 
 #include <algorithm>
@@ -93,6 +94,11 @@ struct msufsort_hip_ctx {
     DevBuf alpha, seg0_base, stripe_sums, hist_partial, hist, hist_clip, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
     DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, aux3, doneB, doneC;
     std::vector<ActiveSet> active;                // per logical shard (index 0: the per-shard C-ABI pieces)
+    // two-stage build (B* sort + induction, induce_host.inc): suffix-type bitmaps, histograms of the B / B* suffixes, sorted
+    // B* suffixes, preceding characters of the rows, per-tile counts and the state of the induction passes
+    DevBuf ind_bbits, ind_sbits, sel_partial, sel_hist, ind_histb, ind_sstar, ind_pc, ind_tiles, ind_state, ind_tables;
+    const u8* sel_bits = nullptr;                 // != nullptr: build_sa sorts only the positions whose bit is set
+    u32* h_ind = nullptr;                         // pinned staging for the induction tables
     DevBuf sub_partial, sub_hist, sub_saved;      // deeper histogram of ONE two-byte key (shard boundaries inside heavy keys)
     int64_t sub_key = -1;                         // which key sub_partial describes (-1: none); valid for the current text only
     DevBuf grp_full, grp_prev, upd, upd_cnt;      // single-process sharded builds: tie-group heads (all rows), their copy at the
@@ -124,8 +130,9 @@ struct msufsort_hip_ctx {
     int set_attrs()
     {
         if (attrs_set) return MSUFSORT_HIP_OK;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16<0>), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan16), hipFuncAttributeMaxDynamicSharedMemorySize, SCAN16_LDS_BYTES));
         TRY(set_mid_attrs<false>());
         TRY(set_mid_attrs<true>());
@@ -200,6 +207,8 @@ struct msufsort_hip_ctx {
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
         grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release();
         sub_partial.release(); sub_hist.release(); sub_saved.release(); sub_key = -1;
+        ind_bbits.release(); ind_sbits.release(); sel_partial.release(); sel_hist.release(); ind_histb.release(); ind_sstar.release();
+        ind_pc.release(); ind_tiles.release(); ind_state.release(); ind_tables.release();
         for (auto& a : active) a.release();
         active.clear();
         cap_m = 0; cap_for_m = 0;
@@ -214,6 +223,7 @@ struct msufsort_hip_ctx {
         for (int s = 0; s < 2; ++s) { for (int k = 0; k < 3; ++k) b += lists[s][k].bytes; b += large_round[s].bytes + lvl[s].bytes; }
         b += isa.bytes + grp_full.bytes + grp_prev.bytes + upd.bytes + sub_partial.bytes + hist_partial.bytes + seg_hist.bytes + child_start.bytes + cursor.bytes;
         b += doneB.bytes + doneC.bytes + aux0.bytes + aux1.bytes + aux2.bytes + aux3.bytes + sa_own.bytes + text_own.bytes;
+        b += ind_bbits.bytes + ind_sbits.bytes + sel_partial.bytes + ind_sstar.bytes + ind_pc.bytes + ind_tiles.bytes;
         for (auto& a : active) b += a.act[0].bytes + a.act[1].bytes + a.prev.bytes;
         return b;
     }
@@ -321,7 +331,7 @@ int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
     TRY(c->ensure_fixed(hchunks));
     c->nchunks = nchunks; c->chunk_len = (u32)chunk_len; c->hist_per = per;
     c->sub_key = -1;
-    hipLaunchKernelGGL(k_hist16<false>, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>(), 0u);
+    hipLaunchKernelGGL(k_hist16<0>, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>(), 0u, (const unsigned short*)nullptr);
     hipLaunchKernelGGL(k_reduce16<W>, dim3(256), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), hchunks, c->hist.as<typename Wd<W>::hist_t>());
     HIP_TRY(hipGetLastError());
     return MSUFSORT_HIP_OK;
@@ -336,8 +346,8 @@ int run_subhist(msufsort_hip_ctx* c, const u8* d_text, u64 m, u32 key)
     const u32 hchunks = c->nchunks * c->hist_per;
     TRY(c->sub_partial.ensure((size_t)hchunks * 65536 * 4));
     TRY(c->sub_hist.ensure(65536 * 8));
-    hipLaunchKernelGGL(k_hist16<true>, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, c->chunk_len / c->hist_per, hchunks, c->sub_partial.as<u32>(),
-                       (key >> 8) | ((key & 255u) << 8));
+    hipLaunchKernelGGL(k_hist16<1>, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, c->chunk_len / c->hist_per, hchunks, c->sub_partial.as<u32>(),
+                       (key >> 8) | ((key & 255u) << 8), (const unsigned short*)nullptr);
     hipLaunchKernelGGL(k_reduce16<W>, dim3(256), dim3(256), 0, c->stream, c->sub_partial.as<u32>(), hchunks, c->sub_hist.as<typename Wd<W>::hist_t>());
     HIP_TRY(hipGetLastError());
     c->sub_key = (int64_t)key;
@@ -350,7 +360,11 @@ int run_scan(msufsort_hip_ctx* c, const u8* d_text, u64 m, u64 lo32, u64 hi32, u
 {
     const u32 klo = (u32)(lo32 >> 16), khi = (u32)((hi32 + 0xffffull) >> 16);
     const u32 hchunks = c->nchunks * c->hist_per;
-    hipLaunchKernelGGL(k_hist_clip<W>, dim3(256), dim3(256), 0, c->stream, c->hist.as<typename Wd<W>::hist_t>(), klo, khi, c->hist_clip.as<u32>(), c->counters.as<u32>());
+    // (two-stage builds sort a SELECTION of the suffixes: counts and stripe cursors come from the histogram of the selected
+    // positions, the alphabet from the histogram of the whole text)
+    const typename Wd<W>::hist_t* hist_counts = c->sel_bits ? c->sel_hist.as<typename Wd<W>::hist_t>() : c->hist.as<typename Wd<W>::hist_t>();
+    const u32* partial_counts = c->sel_bits ? c->sel_partial.as<u32>() : c->hist_partial.as<u32>();
+    hipLaunchKernelGGL(k_hist_clip<W>, dim3(256), dim3(256), 0, c->stream, hist_counts, klo, khi, c->hist_clip.as<u32>(), c->counters.as<u32>());
     const u32* h32 = c->hist_clip.as<u32>();
     // boundary keys owned in part (a shard boundary inside a heavy two-byte key): in-range counts, globally and per chunk
     u32 fix_key[2]; u32 nfix = 0;
@@ -377,7 +391,7 @@ int run_scan(msufsort_hip_ctx* c, const u8* d_text, u64 m, u64 lo32, u64 hi32, u
                        c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->counters.as<u32>());
     hipLaunchKernelGGL(k_alphabet<W>, dim3(1), dim3(256), 0, c->stream, c->hist.as<typename Wd<W>::hist_t>(), c->alpha.as<u8>(), c->counters.as<u32>());
     (void)hipMemsetAsync(c->stripe_sums.p, 0, (size_t)c->nchunks * 256 * 4, c->stream);
-    hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks * 4), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), c->hist_per, klo, khi, c->stripe_sums.as<u32>());
+    hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks * 4), dim3(256), 0, c->stream, partial_counts, c->hist_per, klo, khi, c->stripe_sums.as<u32>());
     hipLaunchKernelGGL(k_stripes, dim3(256), dim3(128), 0, c->stream, c->stripe_sums.as<u32>(), c->nchunks,
                        c->seg0_base.as<u32>(), c->cursor0.as<u32>());
     for (u32 f = 0; f < nfix; ++f)      // the per-chunk partials serve every shard of this text: put the full counts back
@@ -753,7 +767,8 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     const u32 klo = (u32)(lo32 >> 16), khi = (u32)((hi32 + 0xffffull) >> 16);
     typedef typename Wd<W>::sa_t sa_t;
     const int verbose = opts ? opts->verbose : 0;
-    const bool sharded = W || (opts && opts->n_shards > 1);
+    const bool selected = c->sel_bits != nullptr;      // two-stage build: B* suffixes only; deep ties make the caller fall back
+    const bool sharded = W || (opts && opts->n_shards > 1) || selected;
     const bool auto_switch = !(opts && opts->text_rounds > 0) && !getenv("MSUFSORT_HIP_TEXT_ROUNDS");
     int text_rounds = (opts && opts->text_rounds > 0) ? opts->text_rounds : 24;
     u64 prev_active = 0;
@@ -790,7 +805,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     RecBufs& bufs = R.bufs;
     sa_t* sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
     R.sa_local = sa_local;
-    hipLaunchKernelGGL(k_scatter0<W>, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, m, lo32, hi32, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0], c->alpha.as<u8>(), counters, R.no_pack ? 0u : 1u);
+    hipLaunchKernelGGL(k_scatter0<W>, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, m, lo32, hi32, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0], c->alpha.as<u8>(), counters, R.no_pack ? 0u : 1u, c->sel_bits);
     HIP_TRY(hipEventRecord(c->ev[2], st));
     DBG("k_scatter0");
     hipLaunchKernelGGL(k_partition, dim3(cdiv(cdiv(ms, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
@@ -845,11 +860,12 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         // everything tied for the first rounds without any repeats being involved.
         const double sigma2 = std::max<double>(4.0, (double)c->h_counters[C_HNZ]);
         const double need = 2.0 * std::log((double)std::max<u64>(m, 2)) / std::log(sigma2);
-        const bool stalled = auto_switch && !sharded && round >= 2 && (double)depth >= std::max(13.0, 1.3 * need) &&
+        const bool stalled = auto_switch && (!sharded || selected) && round >= 2 && (double)depth >= std::max(13.0, 1.3 * need) &&
                              (actP + actS) * 10 > prev_active * 7;
         prev_active = actP + actS;
         if (R.mode == MODE_TEXT && (round + 1 > text_rounds || stalled)) {
             if (sharded) {
+                if (selected) { HIP_TRY(hipStreamSynchronize(st)); return MSUFSORT_HIP_UNRESOLVED; }
                 if (!d_grp_rows) { set_error("ties deeper than %llu bytes in a sharded build and no group buffer was given", (unsigned long long)depth); return MSUFSORT_HIP_ERR_UNSUPPORTED; }
                 // publish the tie groups of my slice (local rows); the caller continues with the distributed doubling
                 const u32 row0 = (u32)(1 + rank0 - slice_row_lo);
@@ -1256,6 +1272,8 @@ struct TmpCtx {
 
 }  // namespace
 
+#include "induce_host.inc"
+
 // ================================================================================================
 extern "C" {
 
@@ -1317,6 +1335,7 @@ void msufsort_hip_ctx_destroy(msufsort_hip_ctx* c)
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_hist) (void)hipHostFree(c->h_hist);
     if (c->h_upd) (void)hipHostFree(c->h_upd);
+    if (c->h_ind) (void)hipHostFree(c->h_ind);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1362,7 +1381,15 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     msufsort_hip_opts o{};
     if (opts) o = *opts;
     o.n_shards = 1; o.shard = 0;
-    return build_sa<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 1ull << 32, z, true, &o, false);
+    // two-stage build (B* sort + induction) for text-like inputs; everything it declines goes through the sort-all path
+    int two_stage = o.two_stage;
+    if (const char* e = getenv("MSUFSORT_HIP_TWO_STAGE")) two_stage = atoi(e);
+    bool hist_done = false;
+    if (two_stage >= 0) {
+        const int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, two_stage > 0, &hist_done);
+        if (r != MSUFSORT_HIP_UNRESOLVED) return r;
+    }
+    return build_sa<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 1ull << 32, z, true, &o, hist_done);
 }
 
 int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t n_shards, int64_t* bounds)

@@ -1,0 +1,390 @@
+// Two-stage suffix-array build for text-like inputs: sort only the B* suffixes with the
+// engine of sa_kernels.hip.h, then INDUCE the rest.  Counterparts in the reference: suffix typing + B* scatter
+// msufsort.cpp:1496-1555, second stage (right-to-left pass for the B suffixes, left-to-right pass for the A suffixes)
+// cpp:646-791 and cpp:867-1017, driven from cpp:1021-1057.  The reference walks each pass with a few threads that hand
+// batches to each other; here a pass is a sequence of data-parallel STABLE SCATTERS:
+//
+//   suffix i is type B if T[i..] < T[i+1..], else type A (the suffix of the last character is A); B* = B followed by A.
+//   Row layout of first-byte bucket c0:  [ A suffixes | B suffixes by second byte c1 >= c0: (c0,c0) (c0,c0+1) ... ],
+//   inside sub-bucket (c0,c1): [ B* | other B ].
+//
+//   pass B, c1 = 255 .. 0: the B rows of bucket c1, read right to left, put every B-type predecessor j-1 (T[j-1] <= c1) at
+//       the right end of sub-bucket (T[j-1], c1).  All sources of one bucket except those that land in (c1,c1) itself are
+//       known when the bucket starts, so "level 0" = sub-buckets (c1, > c1) is ONE stable scatter by T[j-1]; what it puts
+//       into (c1,c1) is level 1, and so on: as many levels as the longest run of the byte c1 in the text.
+//   pass A, c0 = 0 .. 255: the rows of bucket c0, read left to right, put every A-type predecessor at the left end of the A
+//       area of bucket T[j-1] >= c0: levels over the A area (what lands in A(c0) itself feeds the next level), then the B area.
+//
+// Every row carries up to three characters in front of its suffix (pc[row] = T[j-1] | T[j-2] << 8 | T[j-3] << 16 | count << 24,
+// j = SA[row]), so a source costs no text access to find its target, and the row it induces inherits the remaining
+// characters: text is read (one unaligned 4-byte load) only for B* rows and for every third row of an induction chain.
+// Random text accesses of the whole second stage: about 1.3 per B* suffix (against a sector per tied suffix and key round
+// in the sort-all path).
+#pragma once
+#include "sa_kernels.hip.h"
+
+#define TY_THREADS 256
+#define TY_TILE (TY_THREADS * 32)          // positions per workgroup: every thread owns one 32-bit word of the bitmaps
+#define TY_SCAN_LIMIT (1u << 16)           // give up on runs of one byte longer than this (flag: the caller sorts all suffixes)
+#define IND_MAXRUN_CAP 4096u
+
+#define IND_FLAG_LONGRUN 1u
+#define IND_FLAG_CURSOR 2u           // pass B
+#define IND_FLAG_CURSOR_A 4u
+
+// ---- suffix types: bitmaps of the B and the B* positions ----
+__global__ __launch_bounds__(TY_THREADS) void k_types(const u8* __restrict__ text, u64 n, u32* __restrict__ b_bits, u32* __restrict__ bs_bits,
+                                                      u32* __restrict__ flags)
+{
+    __shared__ u32 s_has[TY_THREADS / 64], s_first[TY_THREADS / 64];
+    __shared__ u32 s_carry;
+    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const u64 tile0 = (u64)blockIdx.x * TY_TILE;
+    const u64 base = tile0 + (u64)t * 32u;
+    u32 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = 0;
+    if (base < n) {                                   // (the text is padded with 64 zero bytes)
+        const uint4 a = *reinterpret_cast<const uint4*>(text + base), b = *reinterpret_cast<const uint4*>(text + base + 16);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        w[8] = *reinterpret_cast<const u32*>(text + base + 32);
+    }
+    // F: the type is decided at this position (next byte differs, or last position); L: ... and it is B
+    u32 F = 0, L = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const u32 a = (w[i >> 2] >> (8 * (i & 3))) & 255u, b = (w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 255u;
+        const u64 pos = base + i;
+        const bool tail = pos + 1 >= n;               // the last suffix is type A; positions behind the text read as A
+        F |= (u32)(tail || a != b) << i;
+        L |= (u32)(!tail && a < b) << i;
+    }
+    const bool has = F != 0;
+    const u32 first = has ? (L >> (__ffs((int)F) - 1)) & 1u : 0u;
+    const u64 has_m = __ballot(has), first_m = __ballot(first != 0);
+    if (lane == 0) { s_has[wv] = has_m != 0; s_first[wv] = has_m ? (u32)((first_m >> (__ffsll((long long)has_m) - 1)) & 1ull) : 0u; }
+    __syncthreads();
+    if (wv == 0) {      // type of the first position behind this tile (decides the last position's B* bit, and the types of a run
+                        // of equal bytes that crosses the boundary)
+        u32 carry = 0;
+        {
+            u64 e = tile0 + TY_TILE;
+            const u64 e0 = e;
+            for (;;) {
+                const u64 pos = e + lane;
+                const u32 a = pos < n ? text[pos] : 0u, b = pos + 1 < n ? text[pos + 1] : 0u;
+                const bool tail = pos + 1 >= n;
+                const u64 f = __ballot(tail || a != b), l = __ballot(!tail && a < b);
+                if (f) { carry = (u32)((l >> (__ffsll((long long)f) - 1)) & 1ull); break; }
+                e += 64;
+                if (e - e0 > TY_SCAN_LIMIT) { if (lane == 0) atomicOr(flags, IND_FLAG_LONGRUN); break; }
+            }
+        }
+        if (lane == 0) s_carry = carry;
+    }
+    __syncthreads();
+    // type of the position behind my 32
+    u32 carry;
+    const u64 above = lane == 63 ? 0ull : (has_m & (~0ull << (lane + 1)));
+    if (above) carry = (u32)((first_m >> (__ffsll((long long)above) - 1)) & 1ull);
+    else {
+        carry = s_carry;
+        for (int w2 = TY_THREADS / 64 - 1; w2 > (int)wv; --w2) if (s_has[w2]) carry = s_first[w2];
+    }
+    u32 tb = 0, cur = carry;
+#pragma unroll
+    for (int i = 31; i >= 0; --i) {
+        cur = ((F >> i) & 1u) ? ((L >> i) & 1u) : cur;
+        tb |= cur << i;
+    }
+    const u32 nxt = (tb >> 1) | (carry << 31);
+    b_bits[base >> 5] = tb;
+    bs_bits[base >> 5] = tb & ~nxt;
+}
+
+// longest run of every byte value (number of levels an induction pass needs inside that byte's bucket)
+__global__ __launch_bounds__(256) void k_maxrun(const u8* __restrict__ text, u64 n, u32* __restrict__ maxrun /* 256, zeroed */, u32* __restrict__ flags)
+{
+    __shared__ u32 s_max[256];
+    const u32 t = threadIdx.x;
+    s_max[t] = 0;
+    __syncthreads();
+    for (u64 base = ((u64)blockIdx.x * 256u + t) * 16u; base < n; base += (u64)gridDim.x * 256u * 16u) {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + base);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+        u32 prev = base ? text[base - 1] : 0x100u;
+        u32 run_c = 0x100u, run_len = 0;             // run that STARTS inside my 16 bytes and is still open
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const u32 ch = (w[i >> 2] >> (8 * (i & 3))) & 255u;
+            const bool in = base + i < n;
+            if (in && ch != prev) {
+                if (run_len > s_max[run_c & 255u] && run_c < 256u) atomicMax(&s_max[run_c], run_len);
+                run_c = ch; run_len = 1;
+            } else if (in && run_c < 256u) ++run_len;
+            if (in) prev = ch;
+        }
+        if (run_c < 256u) {                          // my last run may continue behind my bytes
+            u64 p = base + 16;
+            while (p < n && text[p] == run_c && run_len < IND_MAXRUN_CAP) { ++p; ++run_len; }
+            if (run_len >= IND_MAXRUN_CAP) atomicOr(flags, IND_FLAG_LONGRUN);
+            if (run_len > s_max[run_c]) atomicMax(&s_max[run_c], run_len);
+        }
+    }
+    __syncthreads();
+    if (s_max[t]) atomicMax(&maxrun[t], s_max[t]);
+}
+
+// ---- tables of the row layout (made on the host from the three histograms) ----
+struct IndTables {
+    const u32* bkt;         // [257] first row of every first-byte bucket (row 0 = the empty suffix)
+    const u32* aend;        // [256] first row behind the A area = first row of the B area
+    const u32* sub_start;   // [65536] first row of sub-bucket (c0,c1); B* first
+    const u32* sub_cnt;     // [65536] B suffixes of (c0,c1)
+    const u32* sub_bs;      // [65536] B* suffixes of (c0,c1)
+    const u32* bs_off;      // [65536] where the B* suffixes of (c0,c1) start in the sorted B* array
+};
+
+struct IndState {
+    u32 cur[256];           // pass B: next free row + 1 (right end, exclusive) of sub-bucket (c0, current c1); pass A: next free row of A(c)
+    u32 rng[2][2];          // source rows [lo, hi) of the level being processed / of the next level
+    u32 flags;
+    u32 pad[3];
+};
+
+// sorted B* suffixes -> the left ends of their sub-buckets; one workgroup per non-empty (c0,c1)
+__global__ __launch_bounds__(256) void k_place_bstar(const u32* __restrict__ sstar, const u32* __restrict__ keys, IndTables tb, u32* __restrict__ sa)
+{
+    const u32 key = keys[blockIdx.x];
+    const u32 cnt = tb.sub_bs[key], src = tb.bs_off[key], dst = tb.sub_start[key];
+    for (u32 i = blockIdx.y * 256u + threadIdx.x; i < cnt; i += gridDim.y * 256u) sa[dst + i] = sstar[src + i];
+}
+
+// the (up to) three characters in front of suffix j and how many there are
+__device__ __forceinline__ u32 ind_fetch(const u8* __restrict__ text, u32 j)
+{
+    if (j >= 4u) {
+        u32 w;
+        __builtin_memcpy(&w, text + j - 4u, 4);
+        return (__builtin_bswap32(w) & 0xffffffu) | (3u << 24);
+    }
+    u32 v = 0;
+    for (u32 k = 0; k < j && k < 3u; ++k) v |= (u32)text[j - 1u - k] << (8u * k);
+    return v | ((j < 3u ? j : 3u) << 24);
+}
+
+#define IND_TILE 2048u       // sources per tile: 256 threads x 8, wave-major rows of 64
+#define IND_ITEMS 8
+
+// start of a bucket's work
+//   kind 0 (pass B, bucket c): cursors = right ends of the sub-buckets (c0, c); level 0 = sub-buckets (c, > c)
+//   kind 1 (pass A, bucket c, A levels): level 0 = what earlier buckets put into A(c)
+//   kind 2 (pass A, bucket c, B area)
+//   kind 3 (start of pass A): cursors = left ends of the A areas; the empty suffix (row 0) induces suffix n-1
+__global__ __launch_bounds__(256) void k_ind_setup(IndState* __restrict__ st, IndTables tb, u32 kind, u32 c, const u8* __restrict__ text, u32 n,
+                                                   u32* __restrict__ sa, u32* __restrict__ pc)
+{
+    const u32 t = threadIdx.x;
+    if (kind == 0) {
+        if (t <= c) st->cur[t] = tb.sub_start[t * 256u + c] + tb.sub_cnt[t * 256u + c];
+        if (t == 0) { st->rng[0][0] = tb.sub_start[c * 256u + c] + tb.sub_cnt[c * 256u + c]; st->rng[0][1] = tb.bkt[c + 1]; }
+    } else if (kind == 1) {
+        if (t == 0) { st->rng[0][0] = tb.bkt[c]; st->rng[0][1] = st->cur[c]; }
+    } else if (kind == 2) {
+        if (t == 0) { st->rng[0][0] = tb.aend[c]; st->rng[0][1] = tb.bkt[c + 1]; }
+    } else {
+        u32 v = tb.bkt[t];
+        const u32 last = text[n - 1];
+        if (t == last) { sa[v] = n - 1; pc[v] = ind_fetch(text, n - 1); ++v; }
+        st->cur[t] = v;
+        if (t == 0) sa[0] = n;
+    }
+}
+
+struct IndLevel {
+    u32 pass_b;      // 1: right-to-left pass over B rows; 0: left-to-right pass
+    u32 c;           // bucket being read
+    u32 slot;        // which rng[] holds this level's rows
+    u32 stars;       // pass B level 0: the sources include B* rows, whose pc is not known yet
+    u32 src_a;       // pass A: the sources are A rows (an equal preceding byte is then type A too)
+};
+
+// target bin of one source row, or 256: nothing to induce
+__device__ __forceinline__ u32 ind_bin(const IndLevel& lv, u32 j, u32 pcw)
+{
+    if (j == 0) return 256u;
+    const u32 pcv = pcw & 255u;
+    if (lv.pass_b) return pcv <= lv.c ? pcv : 256u;
+    return (pcv > lv.c || (pcv == lv.c && lv.src_a)) ? pcv : 256u;
+}
+
+// per tile and target bin: number of rows this level writes (also fetches the preceding character of B* sources)
+__global__ __launch_bounds__(256) void k_ind_count(const IndState* __restrict__ st, IndLevel lv, IndTables tb, const u32* __restrict__ sa, u32* __restrict__ pc,
+                                                   const u8* __restrict__ text, u32* __restrict__ tile_hist, u32 max_tiles)
+{
+    __shared__ u32 hist[256];
+    __shared__ u32 s_sub[257];           // pass B level 0: first rows of the sub-buckets of bucket c (binary search: which one holds a row)
+    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const u32 lo = st->rng[lv.slot][0], hi = st->rng[lv.slot][1];
+    const u32 cnt = hi - lo, ntiles = (cnt + IND_TILE - 1) / IND_TILE;
+    if (blockIdx.x >= ntiles) return;
+    if (lv.stars) { s_sub[t] = tb.sub_start[lv.c * 256u + t]; if (t == 0) s_sub[256] = tb.bkt[lv.c + 1]; }
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        hist[t] = 0;
+        __syncthreads();
+        u32 j[IND_ITEMS], pcv[IND_ITEMS], row[IND_ITEMS];
+        bool star[IND_ITEMS];
+#pragma unroll
+        for (int i = 0; i < IND_ITEMS; ++i) {
+            const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
+            row[i] = 0xffffffffu; j[i] = 0; pcv[i] = 0; star[i] = false;
+            if (q < cnt) {
+                const u32 r = lv.pass_b ? hi - 1u - q : lo + q;
+                row[i] = r;
+                j[i] = sa[r];
+                if (lv.stars) {
+                    u32 a = lv.c, b = 256u;              // sub-bucket c2 with s_sub[c2] <= r < s_sub[c2 + 1]
+                    while (b - a > 1u) { const u32 mid = (a + b) >> 1; if (s_sub[mid] <= r) a = mid; else b = mid; }
+                    star[i] = r < s_sub[a] + tb.sub_bs[lv.c * 256u + a];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IND_ITEMS; ++i)
+            if (row[i] != 0xffffffffu) pcv[i] = star[i] ? ind_fetch(text, j[i]) : pc[row[i]];
+#pragma unroll
+        for (int i = 0; i < IND_ITEMS; ++i) {
+            const bool in = row[i] != 0xffffffffu;
+            if (in && star[i]) pc[row[i]] = pcv[i];
+            const u32 b = in ? ind_bin(lv, j[i], pcv[i]) : 256u;
+            // one LDS atomic per distinct bin and row of the wave (few bins: DNA, text)
+            const bool on = b < 256u;
+            u64 peers = __ballot(on);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool bit = (b >> q) & 1u;
+                const u64 bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
+            if (on && (int)lane == __ffsll((long long)peers) - 1) atomicAdd(&hist[b], (u32)__popcll(peers));
+        }
+        __syncthreads();
+        tile_hist[(u64)t * max_tiles + tile] = hist[t];
+    }
+}
+
+// per bin: exclusive prefix over the tiles -> absolute first target row of every tile; moves the cursor; the rows that land in
+// the bucket being read are the next level
+__global__ __launch_bounds__(256) void k_ind_scan(IndState* __restrict__ st, IndLevel lv, u32* __restrict__ tile_hist, u32 max_tiles)
+{
+    __shared__ u32 wsum[4];
+    __shared__ u32 s_run;
+    const u32 bin = blockIdx.x, t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const u32 lo = st->rng[lv.slot][0], hi = st->rng[lv.slot][1];
+    const u32 ntiles = (hi - lo + IND_TILE - 1) / IND_TILE;
+    const u32 base = st->cur[bin];
+    u32* h = tile_hist + (u64)bin * max_tiles;
+    if (t == 0) s_run = 0;
+    __syncthreads();
+    for (u32 t0 = 0; t0 < ntiles; t0 += 256u) {
+        const u32 i = t0 + t;
+        const u32 v = i < ntiles ? h[i] : 0u;
+        u32 wt;
+        u32 e = wave_excl_scan(v, wt);
+        if (lane == 63) wsum[wv] = wt;
+        __syncthreads();
+        u32 before = s_run;
+        for (u32 w2 = 0; w2 < wv; ++w2) before += wsum[w2];
+        if (i < ntiles) h[i] = lv.pass_b ? base - 1u - (before + e) : base + before + e;
+        __syncthreads();
+        if (t == 0) s_run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const u32 total = s_run;
+        const u32 nb = lv.pass_b ? base - total : base + total;
+        st->cur[bin] = nb;
+        if (bin == lv.c) { st->rng[lv.slot ^ 1u][0] = lv.pass_b ? nb : base; st->rng[lv.slot ^ 1u][1] = lv.pass_b ? base : nb; }
+    }
+}
+
+// stable scatter of one level: row of source j's predecessor = first target row of (tile, bin) +- rank inside the tile
+__global__ __launch_bounds__(256) void k_ind_scatter(const IndState* __restrict__ st, IndLevel lv, u32* __restrict__ sa, u32* __restrict__ pc,
+                                                     const u8* __restrict__ text, const u32* __restrict__ tile_hist, u32 max_tiles)
+{
+    __shared__ u32 wcnt[4][256];
+    __shared__ u32 goff[256];
+    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const u32 lo = st->rng[lv.slot][0], hi = st->rng[lv.slot][1];
+    const u32 cnt = hi - lo, ntiles = (cnt + IND_TILE - 1) / IND_TILE;
+    const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) wcnt[w2][t] = 0;
+        goff[t] = tile_hist[(u64)t * max_tiles + tile];
+        __syncthreads();
+        u32 j[IND_ITEMS], bin[IND_ITEMS], npc[IND_ITEMS], posw[IND_ITEMS];
+#pragma unroll
+        for (int i = 0; i < IND_ITEMS; ++i) {
+            const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
+            j[i] = 0; bin[i] = 256u; npc[i] = 0;
+            if (q < cnt) {
+                const u32 r = lv.pass_b ? hi - 1u - q : lo + q;
+                j[i] = sa[r];
+                const u32 w = pc[r];
+                bin[i] = ind_bin(lv, j[i], w);
+                npc[i] = ((w >> 8) & 0xffffu) | (((w >> 24) - 1u) << 24);          // the new row inherits my other characters
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IND_ITEMS; ++i)
+            if (bin[i] < 256u && (npc[i] >> 24) == 0u) npc[i] = ind_fetch(text, j[i] - 1u);                // ... or fetches its own
+#pragma unroll
+        for (int i = 0; i < IND_ITEMS; ++i) {
+            // lanes of this row with my bin (rows of a wave are taken in order: stable)
+            const bool on = bin[i] < 256u;
+            u64 peers = __ballot(on);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (bin[i] >> b) & 1u;
+                const u64 bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
+            posw[i] = 0;
+            if (on) {
+                const int leader = __ffsll((long long)peers) - 1;
+                u32 old = 0;
+                if ((int)lane == leader) old = atomicAdd(&wcnt[wv][bin[i]], (u32)__popcll(peers));
+                old = __shfl(old, leader, 64);
+                posw[i] = old + (u32)__popcll(peers & lt_mask);
+            }
+        }
+        __syncthreads();
+        {
+            u32 o = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) { const u32 v = wcnt[w2][t]; wcnt[w2][t] = o; o += v; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IND_ITEMS; ++i)
+            if (bin[i] < 256u) {
+                const u32 k = wcnt[wv][bin[i]] + posw[i];
+                const u32 dst = lv.pass_b ? goff[bin[i]] - k : goff[bin[i]] + k;
+                sa[dst] = j[i] - 1u;
+                pc[dst] = npc[i];
+            }
+    }
+}
+
+// after a pass: every cursor must have arrived where the histograms said it would
+__global__ __launch_bounds__(256) void k_ind_check(IndState* __restrict__ st, IndTables tb, u32 kind, u32 c)
+{
+    const u32 t = threadIdx.x;
+    bool bad;
+    if (kind == 0) bad = t <= c && st->cur[t] != tb.sub_start[t * 256u + c] + tb.sub_bs[t * 256u + c];      // pass B, after bucket c
+    else bad = st->cur[t] != tb.aend[t];                                                                    // after pass A
+    if (bad) atomicOr(&st->flags, kind == 0 ? IND_FLAG_CURSOR : IND_FLAG_CURSOR_A);
+}

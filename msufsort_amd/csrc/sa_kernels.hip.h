@@ -261,10 +261,13 @@ __device__ __forceinline__ void h16_add(u32* h_lds, u32 k, u32 c)
 // Skewed chunks (pass 1, entered when a 16-bit counter wrapped in pass 0): a lane first merges runs of equal consecutive keys
 // among its 16 positions into one add, and a wave whose lanes all add the same key and count issues ONE add for all of them -
 // on a run of one repeated byte every LDS atomic of pass 0 is a 64-way same-address conflict (all-'A': 4.4 ms per GiB).
-template <bool SUB>
+// MODE 2:      counts key' = bytes (j, j+1) of the positions whose bit is set in `bits` (one bit per text position): the
+//              histograms of the B and B* suffixes for the two-stage build (induce_kernels.hip.h).
+template <int MODE>
 __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u64 m, u32 chunk_len, u32 nchunks,
-                                                 u32* __restrict__ partial, u32 sel)
+                                                 u32* __restrict__ partial, u32 sel, const unsigned short* __restrict__ bits)
 {
+    constexpr bool SUB = MODE == 1, BITS = MODE == 2, FILT = MODE != 0;
     extern __shared__ u32 h_lds[];
     u64* ovf = reinterpret_cast<u64*>(h_lds + 32768);
     u32* ovf_n = h_lds + 32768 + H16_OVF_CAP * 2;            // [0] list length, [1] checksum, [2] keys counted (SUB), [3] largest counter
@@ -302,7 +305,9 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
                 if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = *reinterpret_cast<const u32*>(text + base + 16); }   // prefetch
                 const u32 w[6] = {cv.x, cv.y, cv.z, cv.w, cn, 0u};
                 const u32 lim = cend - cb >= 16 ? 16u : (u32)(cend - cb);
-                if (!safe && !SUB && lim == 16u) {                 // the common case: 16 plain adds, nothing predicated
+                u32 pb = 0xffffu;
+                if (BITS) pb = bits[cb >> 4];
+                if (!safe && !FILT && lim == 16u) {                // the common case: 16 plain adds, nothing predicated
 #pragma unroll
                     for (int j = 0; j < 16; ++j) h16_add(h_lds, h16_key(w, j), 1u);
                 } else if (!safe) {
@@ -310,7 +315,8 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
                     for (int j = 0; j < 16; ++j) {
                         bool on = (u32)j < lim;
                         if (SUB) on = on && h16_key(w, j) == sel;
-                        if (on) { h16_add(h_lds, h16_key(w, SUB ? j + 2 : j), 1u); if (SUB) ++counted; }
+                        if (BITS) on = on && ((pb >> j) & 1u);
+                        if (on) { h16_add(h_lds, h16_key(w, SUB ? j + 2 : j), 1u); if (FILT) ++counted; }
                     }
                 } else {
                     u32 run = 0, prev = 0;
@@ -318,6 +324,8 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
                     for (int j = 0; j <= 16; ++j) {
                         bool on = (u32)j < lim && j < 16;
                         if (SUB && on) on = h16_key(w, j) == sel;
+                        if (BITS && on) on = (pb >> j) & 1u;
+                        if (FILT && on) ++counted;
                         const u32 k = on ? h16_key(w, SUB ? j + 2 : j) : 0u;
                         const bool flush = run != 0 && (!on || k != prev);
                         const u32 fk = prev, fc = run;
@@ -381,10 +389,10 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
         u32 listed = 0;                                             // what the look after the first sub-chunk moved to the list
         for (u32 i = t; i < min(ovf_n[0], H16_OVF_CAP); i += 1024u) listed += (u32)ovf[i];
         sum = wave_sum(sum + listed);
-        if (SUB) counted = wave_sum(counted);
-        if (lane_id() == 0) { atomicAdd(&ovf_n[1], sum); if (SUB) atomicAdd(&ovf_n[2], counted); }
+        if (FILT) counted = wave_sum(counted);
+        if (lane_id() == 0) { atomicAdd(&ovf_n[1], sum); if (FILT) atomicAdd(&ovf_n[2], counted); }
         __syncthreads();
-        const bool clean = ovf_n[1] == (SUB ? ovf_n[2] : (u32)(cend - cbeg));
+        const bool clean = ovf_n[1] == (FILT ? ovf_n[2] : (u32)(cend - cbeg));
         __syncthreads();
         if (clean) break;
         safe = true;                                                // recount everything with sweeps
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(256) void k_hist_clip(const typename Wd<W>::hist_t*
 }
 
 // Shard boundary inside the two-byte key `key` (big-endian): the shard owns only the suffixes whose NEXT two bytes lie in
-// [sublo, subhi).  sub_partial[chunk][.] is the deeper histogram of that key (k_hist16<true>, memory byte order).  Per text
+// [sublo, subhi).  sub_partial[chunk][.] is the deeper histogram of that key (k_hist16<1>, memory byte order).  Per text
 // chunk: the in-range count replaces hist_partial[chunk][key] (saved for k_sub_restore; the scatter's stripe cursors are made
 // from these), and the total goes to hist_clip[key] (zeroed by the caller).
 __global__ __launch_bounds__(256) void k_sub_fix(const u32* __restrict__ sub_partial, u32 sublo, u32 subhi, u32 key,
@@ -631,7 +639,8 @@ template <bool W> __host__ __device__ inline u32 s0_digit_bits(u32 sigma)      /
 template <bool W>
 __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ text, u64 m, u64 lo32, u64 hi32, u32 chunk_len,
                                                          u32* __restrict__ cursor0, u64* __restrict__ out,
-                                                         const u8* __restrict__ code, const u32* __restrict__ counters, u32 allow_pack)
+                                                         const u8* __restrict__ code, const u32* __restrict__ counters, u32 allow_pack,
+                                                         const u8* __restrict__ sel_bits /* one bit per position, or nullptr: all */)
 {
     // Small alphabets (up to 84 codes, k_alphabet): the three key symbols behind the second byte are written as ONE
     // dense base-sigma number, left-aligned in the 24 key bits below the bucket byte.  Same depth (5 characters), but
@@ -662,13 +671,15 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
     }
     u32 rank[S0_POS];
     u32 validmask = 0;
+    u32 selmask = 0xffu;                 // (S0_POS == 8: the positions of one thread are one byte of the bitmap)
+    if (sel_bits) selmask = base < m ? sel_bits[base >> 3] : 0u;
 #pragma unroll
     for (int j = 0; j < S0_POS; ++j) {
         const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
         const u32 b1 = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u;
         const u32 b2 = (w[(j + 2) >> 2] >> (8 * ((j + 2) & 3))) & 255u, b3 = (w[(j + 3) >> 2] >> (8 * ((j + 3) & 3))) & 255u;
         const u64 k32 = ((u64)b0 << 24) | (b1 << 16) | (b2 << 8) | b3;                 // shard = range of 4-byte prefixes
-        const bool valid = (base + j < m) && k32 >= lo32 && k32 < hi32;
+        const bool valid = (base + j < m) && k32 >= lo32 && k32 < hi32 && ((selmask >> j) & 1u);
         rank[j] = 0;
         if (valid) { rank[j] = atomicAdd(&hist[b0], 1u); validmask |= 1u << j; }
     }

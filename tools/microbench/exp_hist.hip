@@ -18,7 +18,7 @@ int main(int argc, char** argv)
     if (kind == 3) for (u64 i = 0; i < n; ++i) h[i] = "abc"[i % 3];
     u8* d; CK(hipMalloc(&d, n + 64)); CK(hipMemcpy(d, h.data(), n + 64, hipMemcpyHostToDevice));
     u32 *p1, *h1; CK(hipMalloc(&p1, 256ull * 65536 * 4)); CK(hipMalloc(&h1, 65536 * 4));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16<0>), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const u32 m = (u32)n;
     u32 nc = (u32)std::min<u64>(128, std::max<u64>(1, (m + 65535ull) / 65536));
@@ -28,7 +28,7 @@ int main(int argc, char** argv)
     for (int rep = 0; rep < 5; ++rep) {
         float ms;
         CK(hipEventRecord(e0));
-        k_hist16<<<nc * per, 1024, H16_LDS_BYTES>>>(d, m, (u32)(cl / per), nc * per, p1);
+        k_hist16<0><<<nc * per, 1024, H16_LDS_BYTES>>>(d, m, (u32)(cl / per), nc * per, p1, 0u, (const unsigned short*)nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
