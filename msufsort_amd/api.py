@@ -46,11 +46,11 @@ def device_count() -> int:
     return int(_lib.lib().msufsort_hip_device_count())
 
 
-def make_suffix_array(data, threads: int = 1, *, device: int = 0, verbose: int = 0, text_rounds: int = 0) -> np.ndarray:
+def make_suffix_array(data, threads: int = 1, *, device: int = 0, verbose: int = 0, text_rounds: int = 0, two_stage: int = 0) -> np.ndarray:
     """maniscalco::make_suffix_array (h:432-445): n+1 int32 entries, SA[0] = n."""
     t = _u8(data)
     sa = np.empty(t.size + 1, dtype=np.int32)
-    o = _opts(device, verbose, text_rounds)
+    o = _opts(device, verbose, text_rounds, two_stage=two_stage)
     _lib.check(_lib.lib().msufsort_hip_make_sa_i32(t.ctypes.data, t.size, sa.ctypes.data, C.byref(o)), "make_suffix_array")
     return sa
 

@@ -96,7 +96,7 @@ struct msufsort_hip_ctx {
     std::vector<ActiveSet> active;                // per logical shard (index 0: the per-shard C-ABI pieces)
     // two-stage build (B* sort + induction, induce_host.inc): suffix-type bitmaps, histograms of the B / B* suffixes, sorted
     // B* suffixes, preceding characters of the rows, per-tile counts and the state of the induction passes
-    DevBuf ind_bbits, ind_sbits, sel_partial, sel_hist, ind_histb, ind_sstar, ind_pc, ind_tiles, ind_state, ind_tables;
+    DevBuf ind_sbits, sel_partial, sel_hist, ind_sstar, ind_pc, ind_tiles, ind_state, ind_tables;
     const u8* sel_bits = nullptr;                 // != nullptr: build_sa sorts only the positions whose bit is set
     u32* h_ind = nullptr;                         // pinned staging for the induction tables
     DevBuf sub_partial, sub_hist, sub_saved;      // deeper histogram of ONE two-byte key (shard boundaries inside heavy keys)
@@ -207,7 +207,7 @@ struct msufsort_hip_ctx {
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
         grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release();
         sub_partial.release(); sub_hist.release(); sub_saved.release(); sub_key = -1;
-        ind_bbits.release(); ind_sbits.release(); sel_partial.release(); sel_hist.release(); ind_histb.release(); ind_sstar.release();
+        ind_sbits.release(); sel_partial.release(); sel_hist.release(); ind_sstar.release();
         ind_pc.release(); ind_tiles.release(); ind_state.release(); ind_tables.release();
         for (auto& a : active) a.release();
         active.clear();
@@ -223,7 +223,7 @@ struct msufsort_hip_ctx {
         for (int s = 0; s < 2; ++s) { for (int k = 0; k < 3; ++k) b += lists[s][k].bytes; b += large_round[s].bytes + lvl[s].bytes; }
         b += isa.bytes + grp_full.bytes + grp_prev.bytes + upd.bytes + sub_partial.bytes + hist_partial.bytes + seg_hist.bytes + child_start.bytes + cursor.bytes;
         b += doneB.bytes + doneC.bytes + aux0.bytes + aux1.bytes + aux2.bytes + aux3.bytes + sa_own.bytes + text_own.bytes;
-        b += ind_bbits.bytes + ind_sbits.bytes + sel_partial.bytes + ind_sstar.bytes + ind_pc.bytes + ind_tiles.bytes;
+        b += ind_sbits.bytes + sel_partial.bytes + ind_sstar.bytes + ind_pc.bytes + ind_tiles.bytes;
         for (auto& a : active) b += a.act[0].bytes + a.act[1].bytes + a.prev.bytes;
         return b;
     }

@@ -32,13 +32,17 @@
 #define IND_FLAG_CURSOR 2u           // pass B
 #define IND_FLAG_CURSOR_A 4u
 
-// ---- suffix types: bitmaps of the B and the B* positions ----
-__global__ __launch_bounds__(TY_THREADS) void k_types(const u8* __restrict__ text, u64 n, u32* __restrict__ b_bits, u32* __restrict__ bs_bits,
-                                                      u32* __restrict__ flags)
+// ---- suffix types: bitmap of the B* positions ----
+// diag[c] += B positions whose next byte is the same byte c.  (With different bytes the pair decides the type: the 16-bit
+// histogram of all suffixes already is the histogram of the B suffixes above the diagonal, and zero below it.)
+__global__ __launch_bounds__(TY_THREADS) void k_types(const u8* __restrict__ text, u64 n, u32* __restrict__ bs_bits,
+                                                      u32* __restrict__ flags, u32* __restrict__ diag /* 256, zeroed */)
 {
     __shared__ u32 s_has[TY_THREADS / 64], s_first[TY_THREADS / 64];
     __shared__ u32 s_carry;
+    __shared__ u32 s_diag[256];
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    s_diag[t] = 0;
     const u64 tile0 = (u64)blockIdx.x * TY_TILE;
     const u64 base = tile0 + (u64)t * 32u;
     u32 w[9];
@@ -98,8 +102,15 @@ __global__ __launch_bounds__(TY_THREADS) void k_types(const u8* __restrict__ tex
         tb |= cur << i;
     }
     const u32 nxt = (tb >> 1) | (carry << 31);
-    b_bits[base >> 5] = tb;
     bs_bits[base >> 5] = tb & ~nxt;
+    u32 eq = tb & ~F;                                 // B positions inside a run of equal bytes
+    while (eq) {
+        const int i = __ffs((int)eq) - 1;
+        eq &= eq - 1u;
+        atomicAdd(&s_diag[(w[i >> 2] >> (8 * (i & 3))) & 255u], 1u);
+    }
+    __syncthreads();
+    if (s_diag[t]) atomicAdd(&diag[t], s_diag[t]);
 }
 
 // longest run of every byte value (number of levels an induction pass needs inside that byte's bucket)
@@ -143,6 +154,9 @@ struct IndTables {
     const u32* sub_cnt;     // [65536] B suffixes of (c0,c1)
     const u32* sub_bs;      // [65536] B* suffixes of (c0,c1)
     const u32* bs_off;      // [65536] where the B* suffixes of (c0,c1) start in the sorted B* array
+    const u8* code;         // [256] dense number of every byte value that occurs in the text (others: 255)
+    const u8* sym;          // [nb] the byte value of every dense number
+    u32 nb;                 // dense numbers, rounded up to a multiple of 8: per-tile counts are kept as [tile][nb]
 };
 
 struct IndState {
@@ -173,8 +187,8 @@ __device__ __forceinline__ u32 ind_fetch(const u8* __restrict__ text, u32 j)
     return v | ((j < 3u ? j : 3u) << 24);
 }
 
-#define IND_TILE 2048u       // sources per tile: 256 threads x 8, wave-major rows of 64
-#define IND_ITEMS 8
+#define IND_ITEMS 16
+#define IND_TILE (256u * IND_ITEMS)      // sources per tile: 256 threads x 16, wave-major rows of 64
 
 // start of a bucket's work
 //   kind 0 (pass B, bucket c): cursors = right ends of the sub-buckets (c0, c); level 0 = sub-buckets (c, > c)
@@ -220,7 +234,7 @@ __device__ __forceinline__ u32 ind_bin(const IndLevel& lv, u32 j, u32 pcw)
 
 // per tile and target bin: number of rows this level writes (also fetches the preceding character of B* sources)
 __global__ __launch_bounds__(256) void k_ind_count(const IndState* __restrict__ st, IndLevel lv, IndTables tb, const u32* __restrict__ sa, u32* __restrict__ pc,
-                                                   const u8* __restrict__ text, u32* __restrict__ tile_hist, u32 max_tiles)
+                                                   const u8* __restrict__ text, u32* __restrict__ tile_hist)
 {
     __shared__ u32 hist[256];
     __shared__ u32 s_sub[257];           // pass B level 0: first rows of the sub-buckets of bucket c (binary search: which one holds a row)
@@ -229,6 +243,7 @@ __global__ __launch_bounds__(256) void k_ind_count(const IndState* __restrict__ 
     const u32 cnt = hi - lo, ntiles = (cnt + IND_TILE - 1) / IND_TILE;
     if (blockIdx.x >= ntiles) return;
     if (lv.stars) { s_sub[t] = tb.sub_start[lv.c * 256u + t]; if (t == 0) s_sub[256] = tb.bkt[lv.c + 1]; }
+    const u32 my_code = tb.code[t];
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
         hist[t] = 0;
@@ -270,48 +285,55 @@ __global__ __launch_bounds__(256) void k_ind_count(const IndState* __restrict__ 
             if (on && (int)lane == __ffsll((long long)peers) - 1) atomicAdd(&hist[b], (u32)__popcll(peers));
         }
         __syncthreads();
-        tile_hist[(u64)t * max_tiles + tile] = hist[t];
+        if (my_code != 255u || tb.nb == 256u) tile_hist[(u64)tile * tb.nb + my_code] = hist[t];      // (255 = byte value that does not occur, unless all do)
     }
 }
 
-// per bin: exclusive prefix over the tiles -> absolute first target row of every tile; moves the cursor; the rows that land in
-// the bucket being read are the next level
-__global__ __launch_bounds__(256) void k_ind_scan(IndState* __restrict__ st, IndLevel lv, u32* __restrict__ tile_hist, u32 max_tiles)
+// per target byte (one workgroup per dense number): exclusive prefix over the tiles -> absolute first target row of every tile;
+// moves the cursor; the rows that land in the bucket being read are the next level
+#define IND_SCAN_PER 8
+__global__ __launch_bounds__(256) void k_ind_scan(IndState* __restrict__ st, IndLevel lv, IndTables tb, u32* __restrict__ tile_hist)
 {
     __shared__ u32 wsum[4];
     __shared__ u32 s_run;
-    const u32 bin = blockIdx.x, t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const u32 code = blockIdx.x, bin = tb.sym[code], nb = tb.nb;
+    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const u32 lo = st->rng[lv.slot][0], hi = st->rng[lv.slot][1];
     const u32 ntiles = (hi - lo + IND_TILE - 1) / IND_TILE;
     const u32 base = st->cur[bin];
-    u32* h = tile_hist + (u64)bin * max_tiles;
     if (t == 0) s_run = 0;
     __syncthreads();
-    for (u32 t0 = 0; t0 < ntiles; t0 += 256u) {
-        const u32 i = t0 + t;
-        const u32 v = i < ntiles ? h[i] : 0u;
+    for (u32 t0 = 0; t0 < ntiles; t0 += 256u * IND_SCAN_PER) {
+        const u32 first = t0 + t * IND_SCAN_PER;
+        u32 v[IND_SCAN_PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < IND_SCAN_PER; ++k) { v[k] = first + k < ntiles ? tile_hist[(u64)(first + k) * nb + code] : 0u; sum += v[k]; }
         u32 wt;
-        u32 e = wave_excl_scan(v, wt);
+        const u32 e = wave_excl_scan(sum, wt);
         if (lane == 63) wsum[wv] = wt;
         __syncthreads();
-        u32 before = s_run;
+        u32 before = s_run + e;
         for (u32 w2 = 0; w2 < wv; ++w2) before += wsum[w2];
-        if (i < ntiles) h[i] = lv.pass_b ? base - 1u - (before + e) : base + before + e;
+#pragma unroll
+        for (int k = 0; k < IND_SCAN_PER; ++k) {
+            if (first + k < ntiles) tile_hist[(u64)(first + k) * nb + code] = lv.pass_b ? base - 1u - before : base + before;
+            before += v[k];
+        }
         __syncthreads();
         if (t == 0) s_run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
     if (t == 0) {
         const u32 total = s_run;
-        const u32 nb = lv.pass_b ? base - total : base + total;
-        st->cur[bin] = nb;
-        if (bin == lv.c) { st->rng[lv.slot ^ 1u][0] = lv.pass_b ? nb : base; st->rng[lv.slot ^ 1u][1] = lv.pass_b ? base : nb; }
+        const u32 nbase = lv.pass_b ? base - total : base + total;
+        st->cur[bin] = nbase;
+        if (bin == lv.c) { st->rng[lv.slot ^ 1u][0] = lv.pass_b ? nbase : base; st->rng[lv.slot ^ 1u][1] = lv.pass_b ? base : nbase; }
     }
 }
 
 // stable scatter of one level: row of source j's predecessor = first target row of (tile, bin) +- rank inside the tile
 __global__ __launch_bounds__(256) void k_ind_scatter(const IndState* __restrict__ st, IndLevel lv, u32* __restrict__ sa, u32* __restrict__ pc,
-                                                     const u8* __restrict__ text, const u32* __restrict__ tile_hist, u32 max_tiles)
+                                                     const u8* __restrict__ text, IndTables tb, const u32* __restrict__ tile_hist)
 {
     __shared__ u32 wcnt[4][256];
     __shared__ u32 goff[256];
@@ -319,11 +341,12 @@ __global__ __launch_bounds__(256) void k_ind_scatter(const IndState* __restrict_
     const u32 lo = st->rng[lv.slot][0], hi = st->rng[lv.slot][1];
     const u32 cnt = hi - lo, ntiles = (cnt + IND_TILE - 1) / IND_TILE;
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const u32 my_code = tb.code[t];
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) wcnt[w2][t] = 0;
-        goff[t] = tile_hist[(u64)t * max_tiles + tile];
+        goff[t] = (my_code != 255u || tb.nb == 256u) ? tile_hist[(u64)tile * tb.nb + my_code] : 0u;
         __syncthreads();
         u32 j[IND_ITEMS], bin[IND_ITEMS], npc[IND_ITEMS], posw[IND_ITEMS];
 #pragma unroll

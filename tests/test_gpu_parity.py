@@ -530,3 +530,53 @@ def test_cached_contexts_and_trim(M, oracle_mod):
     sa.zero_()
     ctx.make_sa(d, t.size, sa)
     assert (sa.cpu().numpy() == want).all()
+
+
+# ---- two-stage build: B* sort + induction (reference cpp:1496-1555, 646-791, 867-1017) ----
+def _two_stage(M, oracle_mod, t, taken=True):
+    import torch
+    n = t.size
+    ctx = M.DeviceContext(0)
+    d = _dev(M, t)
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, n, sa, two_stage=1)
+    assert (ctx.timings().reserved[5] > 0) == taken, "two-stage path %s" % ("declined" if taken else "taken")
+    if n <= (4 << 20):
+        want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+        assert (sa.cpu().numpy() == want).all()
+    all_ = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, n, all_, two_stage=-1)
+    assert ctx.timings().reserved[5] == 0
+    assert torch.equal(sa, all_)
+    assert ctx.validate_sa(d, n, sa) == 0
+
+
+@pytest.mark.parametrize("kind,n,seed", [("text", (3 << 20) + 1, 7), ("random", (1 << 20) + 3, 8), ("dna", 2 << 20, 9), ("text", 4097, 1),
+                                          ("dna_tandem", 300000, 2)])
+def test_two_stage_generators(M, oracle_mod, kind, n, seed):
+    _two_stage(M, oracle_mod, gen.GENERATORS[kind](n, seed), taken=kind != "dna_tandem")
+
+
+def test_two_stage_edges(M, oracle_mod):
+    rng = np.random.default_rng(3)
+    body = gen.text_bytes(200000, 11)
+    # position 0 is a B* suffix; trailing zero bytes (chain of A suffixes behind the empty suffix); every byte value
+    _two_stage(M, oracle_mod, np.concatenate([np.frombuffer(b"acb", np.uint8), body]))
+    _two_stage(M, oracle_mod, np.concatenate([body, np.zeros(5, np.uint8)]))
+    _two_stage(M, oracle_mod, np.concatenate([body, np.zeros(70, np.uint8)]))
+    _two_stage(M, oracle_mod, np.concatenate([np.arange(256, dtype=np.uint8), rng.integers(0, 256, 70000, dtype=np.uint8), np.arange(255, -1, -1, dtype=np.uint8)]))
+    # runs of one byte: hundreds of induction levels inside one bucket (a B run in front of a larger byte, an A run at the end)
+    _two_stage(M, oracle_mod, np.concatenate([body[:50000], np.full(500, ord("e"), np.uint8), np.frombuffer(b"z", np.uint8), body[50000:], np.full(300, ord("z"), np.uint8)]))
+    for sigma in (2, 3, 5):
+        _two_stage(M, oracle_mod, gen.sweep_bytes(sigma, 60000 + sigma))
+
+
+def test_two_stage_declines(M, oracle_mod):
+    """Inputs the two-stage path hands back to the sort-all path: results stay exact."""
+    body = gen.text_bytes(1 << 20, 12)
+    _two_stage(M, oracle_mod, np.full(100000, 65, np.uint8), taken=False)                               # one long run
+    _two_stage(M, oracle_mod, np.concatenate([np.full(3000, 97, np.uint8), body]), taken=False)         # more levels than it is worth
+    _two_stage(M, oracle_mod, np.concatenate([body, body]), taken=False)                                # B* suffixes tie too deep
+    _two_stage(M, oracle_mod, body[:4000], taken=False)                                                 # too short
+    sa = M.make_suffix_array(body, two_stage=1)
+    assert (sa == M.make_suffix_array(body, two_stage=-1)).all()
