@@ -205,12 +205,21 @@ def main():
         avg = lambda f: sum(getattr(p, f) for p in phases) / K   # noqa: E731
         # per-launch device time (HIP events on the engine's stream) and ALGORITHMIC bytes
         refilled = sum(p.reserved[2] for p in phases) / K
+        # two-stage build (text-like inputs): the sort phases below handle the B* suffixes only; the others are induced
+        mstar = phases[-1].reserved[5]
+        two_stage = mstar > 0
+        ms_ = mstar if two_stage else m          # suffixes the sort phases handle
         kern = {
             "k_hist16": (avg("hist16_ms"), n),
-            "k_scatter0": (avg("scatter0_ms"), n + 8 * m),
-            "k_partition(level 1)": (avg("scatter1_ms"), 16 * m),
-            ("k_sort_fast2(bucket sort)" if args.workload == "random" else "round-0 LDS sorts (k_sort_mid/k_sort_tiny/k_sort_fast2)"): (avg("bucket_sort_ms"), 12 * m),
+            "k_scatter0": (avg("scatter0_ms"), n + 8 * ms_),
+            "k_partition(level 1)": (avg("scatter1_ms"), 16 * ms_),
+            ("k_sort_fast2(bucket sort)" if args.workload == "random" else "round-0 LDS sorts (k_sort_mid/k_sort_tiny/k_sort_fast2)"): (avg("bucket_sort_ms"), 12 * ms_),
         }
+        if two_stage:
+            # rows read twice (count + scatter: 4 B index + 4 B characters), every induced row written once (8 B),
+            # one 4-byte text fetch per B* suffix and per third induced suffix
+            rows_read = phases[-1].reserved[7] + n
+            kern["induction (k_ind_count + k_ind_scan + k_ind_scatter)"] = (avg("other_ms"), int(16 * rows_read + 8 * (n - mstar) + 4 * (mstar + (n - mstar) / 3)))
         if refilled > 0.01 * m:
             # per still-tied suffix and key round: index read (4) + key (8) + index written (4)
             kern["key rounds (k_refill + k_partition levels + LDS sorts)"] = (avg("refine_ms"), int(16 * refilled))
@@ -255,6 +264,9 @@ def main():
                         for k, v in kern.items()},
             "phases_ms": {k: round(v[0], 4) for k, v in kern.items()} | {"refine": round(avg("refine_ms"), 4), "device_total": round(avg("total_ms"), 4)},
         }
+        if two_stage:
+            out["two_stage"] = {"bstar_suffixes": int(mstar), "induced_suffixes": int(n - mstar), "induction_ms": round(avg("other_ms"), 3),
+                                "level_launches": int(phases[-1].reserved[6])}
         if len(ops) > 1:
             out["ops_ms"] = {k: round(v / K, 3) for k, v in op_ms.items()}
             if "ibwt" in ops:

@@ -54,9 +54,11 @@ typedef struct msufsort_hip_opts {
                                   tied set stops shrinking past the depth the alphabet needs, at the latest after 24) */
     int32_t verbose;           /* 1: per-round statistics on stderr */
     int32_t force_wide;        /* int64 entry points: use the wide (40-bit index) engine also below 2^31 - 1 bytes (parity tests) */
-    int32_t two_stage;         /* msufsort_hip_make_sa_i32_dev: 0 = sort only the B* suffixes and induce the others when the input
-                                  looks like text (byte alphabet of 16..128 symbols, no very long runs), 1 = whenever possible,
-                                  -1 = never; inputs that do not suit fall back to sorting all suffixes */
+    int32_t two_stage;         /* msufsort_hip_make_sa_i32_dev (and what is built on it: forward BWT, host-pointer entry points):
+                                  0 = sort only the B* suffixes and induce the others (the reference's two stages, cpp:1496-1555 +
+                                  cpp:646-1057) when the input looks like text (16..128 byte values in use, at least 96 MiB, no
+                                  very long runs of one byte), 1 = whenever possible, -1 = never; inputs that do not suit (or
+                                  whose B* suffixes tie too deep) are sorted completely, as before */
     int32_t reserved[9];
 } msufsort_hip_opts;
 
@@ -78,7 +80,9 @@ typedef struct msufsort_hip_timings {
     int64_t reserved[8];       /* [0] depth at which a sharded build stopped its key rounds, [1] logical shards of the last build,
                                   [2] records whose key was gathered, summed over the rounds after round 0 (each: 4 B index read,
                                   one 64 B sector of text or ranks, 8 B record written, 4 B row written by the sorts),
-                                  [3] inverse BWT: microseconds of the chain walk (k_ibwt_walk), [4] of the whole inverse */
+                                  [3] inverse BWT: microseconds of the chain walk (k_ibwt_walk), [4] of the whole inverse,
+                                  two-stage builds (B* sort + induction; the sort phases above then cover the B* suffixes only,
+                                  other_ms is the induction): [5] B* suffixes, [6] level launches, [7] B suffixes */
 } msufsort_hip_timings;
 
 int msufsort_hip_device_count(void);

@@ -103,22 +103,26 @@ __global__ __launch_bounds__(TY_THREADS) void k_types(const u8* __restrict__ tex
     }
     const u32 nxt = (tb >> 1) | (carry << 31);
     bs_bits[base >> 5] = tb & ~nxt;
-    u32 eq = tb & ~F;                                 // B positions inside a run of equal bytes
-    while (eq) {
-        const int i = __ffs((int)eq) - 1;
-        eq &= eq - 1u;
-        atomicAdd(&s_diag[(w[i >> 2] >> (8 * (i & 3))) & 255u], 1u);
+    const u32 eq = tb & ~F;                           // B positions inside a run of equal bytes
+    if (__ballot(eq != 0)) {                          // (static indexing: a loop over the set bits would put w[] into scratch)
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if ((eq >> i) & 1u) atomicAdd(&s_diag[(w[i >> 2] >> (8 * (i & 3))) & 255u], 1u);
     }
     __syncthreads();
     if (s_diag[t]) atomicAdd(&diag[t], s_diag[t]);
 }
 
 // longest run of every byte value (number of levels an induction pass needs inside that byte's bucket)
-__global__ __launch_bounds__(256) void k_maxrun(const u8* __restrict__ text, u64 n, u32* __restrict__ maxrun /* 256, zeroed */, u32* __restrict__ flags)
+// runs[c][k]: number of runs of byte c that are k + 2 long (k = 7: nine or more) - bounds for the sizes of the deeper levels
+__global__ __launch_bounds__(256) void k_maxrun(const u8* __restrict__ text, u64 n, u32* __restrict__ maxrun /* 256, zeroed */, u32* __restrict__ flags,
+                                                u32* __restrict__ runs /* 256 x 8, zeroed */)
 {
     __shared__ u32 s_max[256];
+    __shared__ u32 s_runs[256 * 8];
     const u32 t = threadIdx.x;
     s_max[t] = 0;
+    for (u32 i = t; i < 2048u; i += 256u) s_runs[i] = 0;
     __syncthreads();
     for (u64 base = ((u64)blockIdx.x * 256u + t) * 16u; base < n; base += (u64)gridDim.x * 256u * 16u) {
         const uint4 v = *reinterpret_cast<const uint4*>(text + base);
@@ -130,7 +134,10 @@ __global__ __launch_bounds__(256) void k_maxrun(const u8* __restrict__ text, u64
             const u32 ch = (w[i >> 2] >> (8 * (i & 3))) & 255u;
             const bool in = base + i < n;
             if (in && ch != prev) {
-                if (run_len > s_max[run_c & 255u] && run_c < 256u) atomicMax(&s_max[run_c], run_len);
+                if (run_c < 256u) {
+                    if (run_len > s_max[run_c]) atomicMax(&s_max[run_c], run_len);
+                    if (run_len >= 2u) atomicAdd(&s_runs[run_c * 8u + (run_len > 9u ? 9u : run_len) - 2u], 1u);
+                }
                 run_c = ch; run_len = 1;
             } else if (in && run_c < 256u) ++run_len;
             if (in) prev = ch;
@@ -140,10 +147,12 @@ __global__ __launch_bounds__(256) void k_maxrun(const u8* __restrict__ text, u64
             while (p < n && text[p] == run_c && run_len < IND_MAXRUN_CAP) { ++p; ++run_len; }
             if (run_len >= IND_MAXRUN_CAP) atomicOr(flags, IND_FLAG_LONGRUN);
             if (run_len > s_max[run_c]) atomicMax(&s_max[run_c], run_len);
+            if (run_len >= 2u) atomicAdd(&s_runs[run_c * 8u + (run_len > 9u ? 9u : run_len) - 2u], 1u);
         }
     }
     __syncthreads();
     if (s_max[t]) atomicMax(&maxrun[t], s_max[t]);
+    for (u32 i = t; i < 2048u; i += 256u) if (s_runs[i]) atomicAdd(&runs[i], s_runs[i]);
 }
 
 // ---- tables of the row layout (made on the host from the three histograms) ----
@@ -331,74 +340,129 @@ __global__ __launch_bounds__(256) void k_ind_scan(IndState* __restrict__ st, Ind
     }
 }
 
-// stable scatter of one level: row of source j's predecessor = first target row of (tile, bin) +- rank inside the tile
-__global__ __launch_bounds__(256) void k_ind_scatter(const IndState* __restrict__ st, IndLevel lv, u32* __restrict__ sa, u32* __restrict__ pc,
+// One tile of a level's stable scatter: row of source j's predecessor = first target row of (tile, byte) +- rank inside the tile.
+// SMALL = false: the first target rows come from k_ind_count + k_ind_scan (tile_hist).
+// SMALL = true:  the level is handled by ONE workgroup, tile after tile: the first target rows are the cursors themselves, moved
+//                here; B* sources fetch their characters here too (no k_ind_count ran).
+template <bool SMALL>
+__device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const IndTables& tb, u32* sa, u32* pc, const u8* __restrict__ text,
+                                         const u32* __restrict__ tile_hist, u32 tile, u32 lo, u32 hi, u32 my_code,
+                                         u32 (*wcnt)[256], u32* goff, const u32* s_sub)
+{
+    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const u32 cnt = hi - lo;
+    const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) wcnt[w2][t] = 0;
+    if (!SMALL) goff[t] = (my_code != 255u || tb.nb == 256u) ? tile_hist[(u64)tile * tb.nb + my_code] : 0u;
+    __syncthreads();
+    u32 j[IND_ITEMS], bin[IND_ITEMS], npc[IND_ITEMS], posw[IND_ITEMS];
+#pragma unroll
+    for (int i = 0; i < IND_ITEMS; ++i) {
+        const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
+        j[i] = 0; bin[i] = 256u; npc[i] = 0;
+        if (q < cnt) {
+            const u32 r = lv.pass_b ? hi - 1u - q : lo + q;
+            j[i] = sa[r];
+            u32 w;
+            bool star = false;
+            if (SMALL && lv.stars) {
+                u32 a = lv.c, b = 256u;
+                while (b - a > 1u) { const u32 mid = (a + b) >> 1; if (s_sub[mid] <= r) a = mid; else b = mid; }
+                star = r < s_sub[a] + tb.sub_bs[lv.c * 256u + a];
+            }
+            if (star) { w = ind_fetch(text, j[i]); pc[r] = w; } else w = pc[r];
+            bin[i] = ind_bin(lv, j[i], w);
+            npc[i] = ((w >> 8) & 0xffffu) | (((w >> 24) - 1u) << 24);          // the new row inherits my other characters
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < IND_ITEMS; ++i)
+        if (bin[i] < 256u && (npc[i] >> 24) == 0u) npc[i] = ind_fetch(text, j[i] - 1u);                // ... or fetches its own
+#pragma unroll
+    for (int i = 0; i < IND_ITEMS; ++i) {
+        // lanes of this row with my byte (rows of a wave are taken in order: stable)
+        const bool on = bin[i] < 256u;
+        u64 peers = __ballot(on);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (bin[i] >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        posw[i] = 0;
+        if (on) {
+            const int leader = __ffsll((long long)peers) - 1;
+            u32 old = 0;
+            if ((int)lane == leader) old = atomicAdd(&wcnt[wv][bin[i]], (u32)__popcll(peers));
+            old = __shfl(old, leader, 64);
+            posw[i] = old + (u32)__popcll(peers & lt_mask);
+        }
+    }
+    __syncthreads();
+    {
+        u32 o = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) { const u32 v = wcnt[w2][t]; wcnt[w2][t] = o; o += v; }
+        if (SMALL && o) {                  // claim the rows: the cursor of byte t moves by what this tile writes
+            const u32 base = __atomic_load_n(&st->cur[t], __ATOMIC_RELAXED);
+            goff[t] = lv.pass_b ? base - 1u : base;
+            __atomic_store_n(&st->cur[t], lv.pass_b ? base - o : base + o, __ATOMIC_RELAXED);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IND_ITEMS; ++i)
+        if (bin[i] < 256u) {
+            const u32 k = wcnt[wv][bin[i]] + posw[i];
+            const u32 dst = lv.pass_b ? goff[bin[i]] - k : goff[bin[i]] + k;
+            sa[dst] = j[i] - 1u;
+            pc[dst] = npc[i];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_ind_scatter(IndState* st, IndLevel lv, u32* sa, u32* pc,
                                                      const u8* __restrict__ text, IndTables tb, const u32* __restrict__ tile_hist)
 {
     __shared__ u32 wcnt[4][256];
     __shared__ u32 goff[256];
-    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const u32 lo = st->rng[lv.slot][0], hi = st->rng[lv.slot][1];
-    const u32 cnt = hi - lo, ntiles = (cnt + IND_TILE - 1) / IND_TILE;
-    const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const u32 ntiles = (hi - lo + IND_TILE - 1) / IND_TILE;
+    const u32 my_code = tb.code[threadIdx.x];
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+        ind_tile<false>(st, lv, tb, sa, pc, text, tile_hist, tile, lo, hi, my_code, wcnt, goff, nullptr);
+}
+
+// Levels that are known to be short (at most one tile, from the run-length counts of k_maxrun): ONE workgroup takes all the
+// remaining levels of a bucket, one after the other - most levels of a text are a handful of rows, and a level of three
+// launches costs more than it computes.
+__global__ __launch_bounds__(256) void k_ind_small(IndState* st, IndLevel lv, u32 nlevels, u32* sa, u32* pc, const u8* __restrict__ text, IndTables tb)
+{
+    __shared__ u32 wcnt[4][256];
+    __shared__ u32 goff[256];
+    __shared__ u32 s_sub[257];
+    const u32 t = threadIdx.x;
+    if (lv.stars) { s_sub[t] = tb.sub_start[lv.c * 256u + t]; if (t == 0) s_sub[256] = tb.bkt[lv.c + 1]; }
     const u32 my_code = tb.code[t];
-    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    u32 slot = lv.slot;
+    for (u32 l = 0; l < nlevels; ++l) {
+        IndLevel cur = lv;
+        cur.slot = slot; cur.stars = l == 0 ? lv.stars : 0u;
         __syncthreads();
-#pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) wcnt[w2][t] = 0;
-        goff[t] = (my_code != 255u || tb.nb == 256u) ? tile_hist[(u64)tile * tb.nb + my_code] : 0u;
+        const u32 lo = __atomic_load_n(&st->rng[slot][0], __ATOMIC_RELAXED), hi = __atomic_load_n(&st->rng[slot][1], __ATOMIC_RELAXED);
+        const u32 before = __atomic_load_n(&st->cur[lv.c], __ATOMIC_RELAXED);
+        if (hi == lo) break;
+        const u32 ntiles = (hi - lo + IND_TILE - 1) / IND_TILE;
+        for (u32 tile = 0; tile < ntiles; ++tile) ind_tile<true>(st, cur, tb, sa, pc, text, nullptr, tile, lo, hi, my_code, wcnt, goff, s_sub);
+        __threadfence();
         __syncthreads();
-        u32 j[IND_ITEMS], bin[IND_ITEMS], npc[IND_ITEMS], posw[IND_ITEMS];
-#pragma unroll
-        for (int i = 0; i < IND_ITEMS; ++i) {
-            const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
-            j[i] = 0; bin[i] = 256u; npc[i] = 0;
-            if (q < cnt) {
-                const u32 r = lv.pass_b ? hi - 1u - q : lo + q;
-                j[i] = sa[r];
-                const u32 w = pc[r];
-                bin[i] = ind_bin(lv, j[i], w);
-                npc[i] = ((w >> 8) & 0xffffu) | (((w >> 24) - 1u) << 24);          // the new row inherits my other characters
-            }
+        if (t == 0) {
+            const u32 after = __atomic_load_n(&st->cur[lv.c], __ATOMIC_RELAXED);
+            __atomic_store_n(&st->rng[slot ^ 1u][0], lv.pass_b ? after : before, __ATOMIC_RELAXED);
+            __atomic_store_n(&st->rng[slot ^ 1u][1], lv.pass_b ? before : after, __ATOMIC_RELAXED);
         }
-#pragma unroll
-        for (int i = 0; i < IND_ITEMS; ++i)
-            if (bin[i] < 256u && (npc[i] >> 24) == 0u) npc[i] = ind_fetch(text, j[i] - 1u);                // ... or fetches its own
-#pragma unroll
-        for (int i = 0; i < IND_ITEMS; ++i) {
-            // lanes of this row with my bin (rows of a wave are taken in order: stable)
-            const bool on = bin[i] < 256u;
-            u64 peers = __ballot(on);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (bin[i] >> b) & 1u;
-                const u64 bal = __ballot(bit);
-                peers &= bit ? bal : ~bal;
-            }
-            posw[i] = 0;
-            if (on) {
-                const int leader = __ffsll((long long)peers) - 1;
-                u32 old = 0;
-                if ((int)lane == leader) old = atomicAdd(&wcnt[wv][bin[i]], (u32)__popcll(peers));
-                old = __shfl(old, leader, 64);
-                posw[i] = old + (u32)__popcll(peers & lt_mask);
-            }
-        }
-        __syncthreads();
-        {
-            u32 o = 0;
-#pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2) { const u32 v = wcnt[w2][t]; wcnt[w2][t] = o; o += v; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < IND_ITEMS; ++i)
-            if (bin[i] < 256u) {
-                const u32 k = wcnt[wv][bin[i]] + posw[i];
-                const u32 dst = lv.pass_b ? goff[bin[i]] - k : goff[bin[i]] + k;
-                sa[dst] = j[i] - 1u;
-                pc[dst] = npc[i];
-            }
+        slot ^= 1u;
     }
 }
 
