@@ -108,8 +108,8 @@ def main():
     shard_state = mdist.ShardState() if world > 1 else None
 
     ops = [x for x in args.op.split(",") if x]
-    assert ops and ops[0] == "sa" and set(ops) <= {"sa", "bwt", "ibwt", "lcp"} and (world == 1 or ops == ["sa"]), "--op sa[,bwt][,ibwt][,lcp] (N > 1: sa only)"
-    d_bwt = torch.empty(n, dtype=torch.uint8, device=dev) if ("bwt" in ops or "ibwt" in ops) else None
+    assert ops and ops[0] == "sa" and set(ops) <= {"sa", "bwt", "fbwt", "ibwt", "lcp"} and (world == 1 or ops == ["sa"]), "--op sa[,bwt][,fbwt][,ibwt][,lcp] (N > 1: sa only)"
+    d_bwt = torch.empty(n, dtype=torch.uint8, device=dev) if ("bwt" in ops or "ibwt" in ops or "fbwt" in ops) else None
     d_inv = torch.empty(n, dtype=torch.uint8, device=dev) if "ibwt" in ops else None
     d_lcp = torch.empty(n, dtype=torch.int32, device=dev) if "lcp" in ops else None
     op_ms = {k: 0.0 for k in ops}
@@ -126,7 +126,9 @@ def main():
             timed("sa", lambda: ctx.make_sa(d_text, n, d_sa))
             phases.append(ctx.timings())
             sent = None
-            if d_bwt is not None:
+            if "fbwt" in ops:      # the forward transform as ONE call (own suffix-array build + BWT, reference cpp:1771-1817)
+                sent = timed("fbwt", lambda: ctx.forward_bwt(d_text, n, d_bwt))
+            elif d_bwt is not None:
                 sent = timed("bwt" if "bwt" in ops else "ibwt", lambda: ctx.bwt_from_sa(d_text, n, d_sa, d_bwt))
             if "ibwt" in ops:
                 timed("ibwt", lambda: ctx.inverse_bwt(d_bwt, n, sent, d_inv))

@@ -239,9 +239,9 @@ class DeviceContext:
         _lib.check(f(self._h, self._ptr(d_text), n, self._ptr(d_sa), self._ptr(d_bwt), C.byref(s)), "bwt_from_sa")
         return int(s.value)
 
-    def forward_bwt(self, d_text, n: int, d_bwt) -> int:
+    def forward_bwt(self, d_text, n: int, d_bwt, *, two_stage=0) -> int:
         s = C.c_int64(0)
-        o = _opts(self.device)
+        o = _opts(self.device, two_stage=two_stage)
         _lib.check(self._L.msufsort_hip_forward_bwt_dev(self._h, self._ptr(d_text), n, self._ptr(d_bwt), C.byref(s), C.byref(o)), "forward_bwt_dev")
         return int(s.value)
 

@@ -23,6 +23,19 @@ __global__ __launch_bounds__(256) void k_bwt_gather(const u8* __restrict__ text,
     }
 }
 
+// Two-stage builds (induce_kernels.hip.h) leave the character in front of every suffix next to its row: the BWT is a
+// sequential pass over those instead of n random text reads - how the reference's own forward transform takes its output
+// out of the second stage (cpp:1061-1492) rather than from a finished suffix array.
+__global__ __launch_bounds__(256) void k_bwt_from_pc(const u8* __restrict__ text, const u32* __restrict__ sa, const u32* __restrict__ pc, u64 rows,
+                                                     const unsigned long long* __restrict__ sentp, u8* __restrict__ out)
+{
+    const u64 sent = *sentp;
+    for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r < rows; r += (u64)gridDim.x * 256u) {
+        const u32 v = sa[r];
+        if (v != 0) out[r - (r > sent)] = r == 0 ? text[v - 1] : (u8)pc[r];      // (row 0 is the empty suffix: no characters were kept for it)
+    }
+}
+
 __device__ __forceinline__ u32 dev_match_length(const u8* __restrict__ text, u64 n, u64 a, u64 b)
 {
     if (a > b) { const u64 x = a; a = b; b = x; }

@@ -43,6 +43,9 @@ def test_full_size_golden(oracle_mod, d):
         inv = torch.empty(n, dtype=torch.uint8, device=dev)
         ctx.inverse_bwt(bwt, n, sent, inv)
         assert torch.equal(inv, dt[:n]), "inverse BWT does not restore the text"
+        # the forward transform as one call (two-stage builds take its bytes from the rows' preceding characters)
+        sent2 = ctx.forward_bwt(dt, n, inv)
+        assert sent2 == d["sentinel"] and _fnv(oracle_mod, inv) == d["bwt_fnv"], "forward BWT (one call) differs from the reference"
         del bwt, inv
     if "lcp_fnv" in d:
         lcp = torch.empty(n, dtype=torch.int32, device=dev)

@@ -580,3 +580,25 @@ def test_two_stage_declines(M, oracle_mod):
     _two_stage(M, oracle_mod, body[:4000], taken=False)                                                 # too short
     sa = M.make_suffix_array(body, two_stage=1)
     assert (sa == M.make_suffix_array(body, two_stage=-1)).all()
+
+
+def test_two_stage_forward_bwt(M, oracle_mod):
+    """The forward transform after a two-stage build reads its bytes from the rows' preceding characters (no text gather)."""
+    import torch
+    for t in (gen.text_bytes((2 << 20) + 5, 21), np.concatenate([np.frombuffer(b"acb", np.uint8), gen.text_bytes(70000, 22), np.zeros(3, np.uint8)]),
+              gen.dna_bytes(500001, 23)):
+        n = t.size
+        ctx = M.DeviceContext(0)
+        d = _dev(M, t)
+        b1 = torch.empty(n, dtype=torch.uint8, device="cuda")
+        s1 = ctx.forward_bwt(d, n, b1, two_stage=1)
+        assert ctx.timings().reserved[5] > 0
+        b0 = torch.empty(n, dtype=torch.uint8, device="cuda")
+        s0 = ctx.forward_bwt(d, n, b0, two_stage=-1)
+        assert s0 == s1 and torch.equal(b0, b1)
+        want, sent = oracle_mod.forward_bwt(t) if hasattr(oracle_mod, "forward_bwt") else (None, None)
+        if want is not None:
+            assert sent == s1 and (b1.cpu().numpy() == want).all()
+        back = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ctx.inverse_bwt(b1, n, s1, back)
+        assert torch.equal(back, d[:n])
