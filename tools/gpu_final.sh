@@ -8,10 +8,14 @@ python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?
 python bench.py --steps 10 --warmup 3 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench.json; cut -c1-300 $O/bench.json
 python bench.py --steps 10 --warmup 3 --size 268435456 --no-cpu 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench_256MiB.json
 python bench.py --steps 3 --warmup 1 --workload text --op sa,bwt,ibwt,lcp --no-cpu 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench_text_cfg3_cfg4.json; cut -c1-200 $O/bench_text_cfg3_cfg4.json
+MSUFSORT_HIP_TWO_STAGE=-1 python bench.py --steps 3 --warmup 1 --workload text --op sa,bwt --no-cpu 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench_text_sort_all.json
+python bench.py --steps 5 --warmup 2 --workload text --op sa,fbwt,ibwt --no-cpu 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench_text_forward_bwt.json
+python tools/gpu_two_stage_sweep.py text 4 16 32 64 128 256 1023 > $O/two_stage_sweep.txt 2>&1; python tools/gpu_two_stage_sweep.py dna 64 256 1023 >> $O/two_stage_sweep.txt 2>&1; python tools/gpu_two_stage_sweep.py dna_tandem 256 >> $O/two_stage_sweep.txt 2>&1; grep MiB $O/two_stage_sweep.txt
 python bench.py --steps 3 --warmup 1 --workload dna --no-cpu 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench_dna.json
 python bench.py --steps 3 --warmup 1 --workload dna_tandem --size 268435456 --op sa,bwt,ibwt --no-cpu 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench_dna_tandem_256MiB.json
 tools/gpu_prof_bench.sh kernel_stats_random --steps 3 --warmup 1 > $O/kernel_stats_random.txt 2>&1; cp gpurun_out/prof/kernel_stats_random.csv $O/
 tools/gpu_prof_bench.sh kernel_stats_text --workload text --op sa,bwt,ibwt --steps 2 --warmup 1 > $O/kernel_stats_text.txt 2>&1; cp gpurun_out/prof/kernel_stats_text.csv $O/
+MSUFSORT_HIP_TWO_STAGE=-1 tools/gpu_prof_bench.sh kernel_stats_text_sort_all --workload text --op sa --steps 2 --warmup 1 > $O/kernel_stats_text_sort_all.txt 2>&1; cp gpurun_out/prof/kernel_stats_text_sort_all.csv $O/
 tools/gpu_prof_bench.sh kernel_stats_tandem --workload dna_tandem --size 268435456 --steps 2 --warmup 1 > $O/kernel_stats_tandem.txt 2>&1; cp gpurun_out/prof/kernel_stats_tandem.csv $O/
 bash tools/gpu_pmc_traffic.sh $O/pmc_traffic_random.txt > /dev/null 2>&1; cat $O/pmc_traffic_random.txt
 bash tools/gpu_pmc_traffic.sh $O/pmc_traffic_text_ibwt.txt --workload text --op sa,bwt,ibwt > /dev/null 2>&1
