@@ -80,11 +80,11 @@ def make_suffix_array_multi(data, devices=None, *, index_bytes: int = 4, n_shard
     return (sa, tm) if timings else sa
 
 
-def forward_burrows_wheeler_transform(data, threads: int = 1, *, device: int = 0):
+def forward_burrows_wheeler_transform(data, threads: int = 1, *, device: int = 0, two_stage: int = 0):
     """maniscalco::forward_burrows_wheeler_transform (h:449-462): returns (bwt bytes, sentinel row)."""
     t = _u8(data).copy()
     s = C.c_int64(0)
-    o = _opts(device)
+    o = _opts(device, two_stage=two_stage)
     _lib.check(_lib.lib().msufsort_hip_forward_bwt(t.ctypes.data, t.size, C.byref(s), C.byref(o)), "forward_bwt")
     return t, int(s.value)
 

@@ -282,12 +282,18 @@ inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 inline u32 grid_for(u64 items, u32 per_block = 256, u32 cap = 65536u) { return (u32)std::min<u64>(std::max<u64>((items + per_block - 1) / per_block, 1), cap); }
 
 // number of trailing 0x00 bytes of the device text
-int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out)
+int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out, u32* tail_values = nullptr /* distinct byte values among the last 4 KiB */)
 {
     u8 tail[4096];
     u64 k = std::min<u64>(n, sizeof tail);
     HIP_TRY(hipMemcpyAsync(tail, d_text + (n - k), k, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (tail_values) {
+        bool seen[256] = {false};
+        u32 d = 0;
+        for (u64 i = 0; i < k; ++i) if (!seen[tail[i]]) { seen[tail[i]] = true; ++d; }
+        *tail_values = d;
+    }
     u64 z = 0;
     while (z < k && tail[k - 1 - z] == 0) ++z;
     if (z < k || k == n) { *z_out = z; return MSUFSORT_HIP_OK; }
@@ -1377,15 +1383,18 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     if (opts && opts->n_shards > 1 && opts->shard < 0)      // shard = -1: all n_shards logical shards, one after the other, on this GPU
         return build_logical<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), opts->n_shards, opts);
     u64 z = 0;
-    TRY(trailing_zeros(c, d_text, (u64)n, &z));
+    u32 tail_values = 0;
+    TRY(trailing_zeros(c, d_text, (u64)n, &z, &tail_values));
     msufsort_hip_opts o{};
     if (opts) o = *opts;
     o.n_shards = 1; o.shard = 0;
-    // two-stage build (B* sort + induction) for text-like inputs; everything it declines goes through the sort-all path
+    // two-stage build (B* sort + induction) for text-like inputs; everything it declines goes through the sort-all path.
+    // The default policy first looks at what is on the host anyway (length; the byte values among the last 4 KiB, which
+    // trailing_zeros just fetched): inputs that cannot qualify - short ones, random bytes - do not pay for the typing passes.
     int two_stage = o.two_stage;
     if (const char* e = getenv("MSUFSORT_HIP_TWO_STAGE")) two_stage = atoi(e);
     bool hist_done = false;
-    if (two_stage >= 0) {
+    if (two_stage > 0 || (two_stage == 0 && (u64)n >= (96ull << 20) && tail_values <= 128u)) {
         const int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, two_stage > 0, &hist_done);
         if (r != MSUFSORT_HIP_UNRESOLVED) return r;
     }

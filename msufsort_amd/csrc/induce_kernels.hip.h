@@ -245,7 +245,7 @@ __device__ __forceinline__ u32 ind_bin(const IndLevel& lv, u32 j, u32 pcw)
 __global__ __launch_bounds__(256) void k_ind_count(const IndState* __restrict__ st, IndLevel lv, IndTables tb, const u32* __restrict__ sa, u32* __restrict__ pc,
                                                    const u8* __restrict__ text, u32* __restrict__ tile_hist)
 {
-    __shared__ u32 hist[256];
+    __shared__ u32 hist[8 * 256];
     __shared__ u32 s_sub[257];           // pass B level 0: first rows of the sub-buckets of bucket c (binary search: which one holds a row)
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const u32 lo = st->rng[lv.slot][0], hi = st->rng[lv.slot][1];
@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void k_ind_count(const IndState* __restrict__ 
     const u32 my_code = tb.code[t];
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
-        hist[t] = 0;
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) hist[q * 256u + t] = 0;
         __syncthreads();
         u32 j[IND_ITEMS], pcv[IND_ITEMS], row[IND_ITEMS];
         bool star[IND_ITEMS];
@@ -282,19 +283,17 @@ __global__ __launch_bounds__(256) void k_ind_count(const IndState* __restrict__ 
             const bool in = row[i] != 0xffffffffu;
             if (in && star[i]) pc[row[i]] = pcv[i];
             const u32 b = in ? ind_bin(lv, j[i], pcv[i]) : 256u;
-            // one LDS atomic per distinct bin and row of the wave (few bins: DNA, text)
-            const bool on = b < 256u;
-            u64 peers = __ballot(on);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const bool bit = (b >> q) & 1u;
-                const u64 bal = __ballot(bit);
-                peers &= bit ? bal : ~bal;
-            }
-            if (on && (int)lane == __ffsll((long long)peers) - 1) atomicAdd(&hist[b], (u32)__popcll(peers));
+            // (eight copies of the bins, copy = lane & 7: text and DNA put everything on a handful of bytes, and lanes that
+            // meet on one LDS address are served one after the other)
+            if (b < 256u) atomicAdd(&hist[(lane & 7u) * 256u + b], 1u);
         }
         __syncthreads();
-        if (my_code != 255u || tb.nb == 256u) tile_hist[(u64)tile * tb.nb + my_code] = hist[t];      // (255 = byte value that does not occur, unless all do)
+        if (my_code != 255u || tb.nb == 256u) {      // (255 = byte value that does not occur, unless all do)
+            u32 sum = 0;
+#pragma unroll
+            for (u32 q = 0; q < 8; ++q) sum += hist[q * 256u + t];
+            tile_hist[(u64)tile * tb.nb + my_code] = sum;
+        }
     }
 }
 

@@ -602,3 +602,30 @@ def test_two_stage_forward_bwt(M, oracle_mod):
         back = torch.empty(n, dtype=torch.uint8, device="cuda")
         ctx.inverse_bwt(b1, n, s1, back)
         assert torch.equal(back, d[:n])
+
+
+def test_two_stage_fuzz(M, oracle_mod):
+    """Random alphabets, lengths, inserted runs and repeats through the forced two-stage path against the oracle."""
+    rng = np.random.default_rng(20260)
+    for it in range(48):
+        sigma = int(rng.choice([2, 3, 4, 5, 8, 20, 64, 256]))
+        n = int(rng.integers(4096, 90000))
+        t = rng.integers(0, sigma, n, dtype=np.uint8)
+        if sigma < 256:
+            t = (t + int(rng.integers(0, 256 - sigma))).astype(np.uint8)
+        for _ in range(int(rng.integers(0, 6))):                      # runs of one byte, some at the very start / end
+            L = int(rng.integers(2, 400))
+            at = int(rng.choice([0, n - L, int(rng.integers(0, n - L))]))
+            t[at:at + L] = t[at]
+        if it % 5 == 0:                                               # a repeat (ties a few hundred bytes deep)
+            L = int(rng.integers(50, 300))
+            a, b = int(rng.integers(0, n - L)), int(rng.integers(0, n - L))
+            t[b:b + L] = t[a:a + L]
+        if it % 7 == 0:
+            t[-int(rng.integers(1, 9)):] = 0                           # trailing zero bytes
+        sa = M.make_suffix_array(t, two_stage=1)
+        want = oracle_mod.ref_make_suffix_array(t, 4) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+        assert (sa == want).all(), f"iteration {it}: sigma {sigma}, n {n}"
+        b1, s1 = M.forward_burrows_wheeler_transform(t, two_stage=1)          # (its bytes come from the induction's rows)
+        b0, s0 = oracle_mod.forward_bwt(t)
+        assert s1 == s0 and (b1 == b0).all(), f"iteration {it}: BWT"
