@@ -43,7 +43,12 @@ __global__ __launch_bounds__(TY_THREADS) void k_types(const u8* __restrict__ tex
     __shared__ u32 s_diag[256];
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     s_diag[t] = 0;
-    const u64 tile0 = (u64)blockIdx.x * TY_TILE;
+    // (a workgroup takes many tiles and adds its diagonal counts to the global ones once: every such add is an atomic on one
+    // of a few dozen addresses, which the memory system serves one after the other)
+    const u64 ntiles = (n + TY_TILE - 1) / TY_TILE;
+    for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    const u64 tile0 = tile * TY_TILE;
     const u64 base = tile0 + (u64)t * 32u;
     u32 w[9];
 #pragma unroll
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(TY_THREADS) void k_types(const u8* __restrict__ tex
 #pragma unroll
         for (int i = 0; i < 32; ++i)
             if ((eq >> i) & 1u) atomicAdd(&s_diag[(w[i >> 2] >> (8 * (i & 3))) & 255u], 1u);
+    }
     }
     __syncthreads();
     if (s_diag[t]) atomicAdd(&diag[t], s_diag[t]);
