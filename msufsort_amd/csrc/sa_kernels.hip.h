@@ -1448,14 +1448,15 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
         for (int j = 0; j < 2; ++j) { const u32 p = j * 64 + lane; if (p < len) ex[p] = key[j]; }
         __syncthreads();
         u32 c_lt[2] = {0, 0}, c_eq[2] = {0, 0}, c_eqb[2] = {0, 0};
-        for (u32 q = 0; q < len; ++q) {
-            const u32 kk = ex[q] >> KL;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool e = kk == (key[j] >> KL);
-                c_lt[j] += kk < (key[j] >> KL); c_eq[j] += e; c_eqb[j] += e & (q < (u32)j * 64u + lane);
-            }
+#define SMALL_CMP(kword, qq) do { const u32 kk = (kword) >> KL; _Pragma("unroll") for (int j = 0; j < 2; ++j) { const bool e = kk == (key[j] >> KL); \
+            c_lt[j] += kk < (key[j] >> KL); c_eq[j] += e; c_eqb[j] += e & ((qq) < (u32)j * 64u + lane); } } while (0)
+        const u32 len4 = len & ~3u;
+        for (u32 q = 0; q < len4; q += 4) {              // four keys per LDS round trip (every lane reads the same 16 bytes)
+            const uint4 k4 = *reinterpret_cast<const uint4*>(ex + q);
+            SMALL_CMP(k4.x, q); SMALL_CMP(k4.y, q + 1u); SMALL_CMP(k4.z, q + 2u); SMALL_CMP(k4.w, q + 3u);
         }
+        for (u32 q = len4; q < len; ++q) SMALL_CMP(ex[q], q);
+#undef SMALL_CMP
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -2046,10 +2047,18 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
                     owned[k] = true;
                     const u32 ls = e - off, my = lkey[e];
                     bool found = false;
-                    for (u32 q = 0; q < len; ++q) {
-                        const u32 kk = lkey[ls + q];
-                        n_lt[k] += kk < my;
-                        if (kk == my) { if (!found) { found = true; lead[k] = ls + q; } n_eq[k]++; n_eqb[k] += q < off; }
+                    for (u32 q0 = 0; q0 < len; q0 += 4) {       // four LDS reads in flight (the last ones clamped to the run)
+                        u32 kq[4];
+#pragma unroll
+                        for (u32 i = 0; i < 4; ++i) kq[i] = lkey[ls + (q0 + i < len ? q0 + i : len - 1u)];
+#pragma unroll
+                        for (u32 i = 0; i < 4; ++i) {
+                            const u32 q = q0 + i, kk = kq[i];
+                            if (q < len) {
+                                n_lt[k] += kk < my;
+                                if (kk == my) { if (!found) { found = true; lead[k] = ls + q; } n_eq[k]++; n_eqb[k] += q < off; }
+                            }
+                        }
                     }
                     const u32 row = sa_start + n_lt[k] + n_eqb[k];
                     sa_out[row] = rec_idx<W>(rec[k]);

@@ -155,3 +155,38 @@ def test_int32_limit_and_first_wide_size():
     del bwt, rows
     del sa64, d
     ctx.trim(); torch.cuda.empty_cache()
+
+
+def test_two_stage_at_int32_limit():
+    """The two-stage build (B* sort + induction) on the largest input the int32 rows allow: 2^31 - 2 bytes over a 30-letter
+    alphabet; rows checked on device, forward BWT from the rows' preceding characters against the gathered one."""
+    import torch
+
+    import msufsort_amd as M
+    dev = torch.device("cuda")
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 << 30:
+        pytest.skip("needs ~150 GB of free HBM")
+    n = (1 << 31) - 2
+    d = _random_gpu(n, 99, dev)
+    lut = torch.tensor(list(b"etaoinshrdlucmfwypvbgkjqxz  \n.,e"), dtype=torch.uint8, device=dev)
+    for s in range(0, n, 1 << 28):
+        e = min(n, s + (1 << 28))
+        d[s:e] = lut[(d[s:e] & 31).long()]
+    d[n:] = 0
+    ctx = M.DeviceContext(0)
+    sa = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    t0 = time.time()
+    ctx.make_sa(d, n, sa, two_stage=1)
+    t1 = time.time()
+    tm = ctx.timings()
+    assert tm.reserved[5] > 0, "two-stage path declined"
+    assert int(sa[0]) == n and ctx.validate_sa(d, n, sa) == 0
+    print(f"\nn=2^31-2, 30 letters, two-stage: {t1 - t0:.3f}s (device {tm.total_ms:.1f} ms, {tm.reserved[5]} B* suffixes, induction {tm.other_ms:.1f} ms)")
+    b1 = torch.empty(n, dtype=torch.uint8, device=dev)
+    s1 = ctx.bwt_from_sa(d, n, sa, b1)
+    del sa
+    b2 = torch.empty(n, dtype=torch.uint8, device=dev)
+    s2 = ctx.forward_bwt(d, n, b2, two_stage=1)
+    assert ctx.timings().reserved[5] > 0
+    assert s1 == s2 and torch.equal(b1, b2)
