@@ -36,20 +36,6 @@ __global__ __launch_bounds__(256) void k_bwt_from_pc(const u8* __restrict__ text
     }
 }
 
-__device__ __forceinline__ u32 dev_match_length(const u8* __restrict__ text, u64 n, u64 a, u64 b)
-{
-    if (a > b) { const u64 x = a; a = b; b = x; }
-    u64 m = 0;
-    while (b + m + 8 <= n) {
-        u64 x, y;
-        __builtin_memcpy(&x, text + a + m, 8);
-        __builtin_memcpy(&y, text + b + m, 8);
-        if (x != y) { m += (u64)(__ffsll((long long)(x ^ y)) - 1) >> 3; return (u32)m; }
-        m += 8;
-    }
-    while (b + m < n && text[a + m] == text[b + m]) ++m;
-    return (u32)m;
-}
 
 // demo convention (main.cpp:66-101): out[i] = lcp(SA[i+1], SA[i+2]), i in [0, n-2]; out[n-1] = 0.
 // Direct compare like the demo's match_length, but capped: a pair that is still equal after `cap` bytes raises

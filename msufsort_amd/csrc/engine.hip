@@ -483,6 +483,7 @@ int plan_shards(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64 z, int n_shard
 // rest (with the repeat-with-exact-reservations fallback).  Shared by the suffix-array build (text rounds and, for
 // narrow single-GPU builds, in-place prefix doubling) and by the stateless doubling step of sharded / wide builds.
 // ------------------------------------------------------------------------------------------------
+#define MSUFSORT_HIP_UNRESOLVED 1      // (internal status: the build stopped with unresolved tie groups / declined the input)
 template <bool W>
 struct Rounds {
     typedef typename Wd<W>::sa_t sa_t;
@@ -505,6 +506,7 @@ struct Rounds {
     bool exact_sticky = false, fast_gave_up = false, force_retry = false, no_pack = false;
     bool safe_rank = getenv("MSUFSORT_HIP_SAFE_RANK") != nullptr;
     u32 nA = 0, nB = 0, nC = 0, nP = 0;
+    u32 deep_cap = 0;                    // != 0: k_sort_tiny finishes its runs by comparing the suffixes themselves (two-stage builds)
     GatherSpec gather{nullptr, 0, {}};   // text rounds: the sorts (and the first partition level) gather the keys themselves
     const u8* code = nullptr;            // dense alphabet code (device)
 
@@ -722,10 +724,12 @@ struct Rounds {
             DBG("k_sort_mid A");
             if (nP) hipLaunchKernelGGL(k_sort_tiny<W>, dim3(std::min<u32>(cdiv(nP, 256), 8192u)), dim3(256), 0, st, c->pool_rec[cur].template as<u64>(), c->pool_hdr[cur].template as<u64>(),
                                        (u32)(cur ? C_POOL1 : C_POOL0), sa_local, isa32, mode,
-                                       em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32(), em.pool_chunk, counters, grp_out, discard, gather, code);
+                                       em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32(), em.pool_chunk, counters, grp_out, discard, gather, code,
+                                       (mode == MODE_TEXT && gather.text) ? deep_cap : 0u);
             DBG("k_sort_tiny");
             if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
             TRY(c->read_counters(attempt == 0));
+            if (c->h_counters[C_ERR] & 0x400u) return MSUFSORT_HIP_UNRESOLVED;      // a deep comparison gave up: the caller sorts all suffixes
             if (attempt == 0 && force_retry) c->h_counters[C_ERR] |= 0x8000u;      // test hook: MSUFSORT_HIP_FORCE_RETRY=1
             if (c->h_counters[C_ERR] == 0) {
                 if (use_fast && !spread && (u64)(c->h_counters[C_FBB] + c->h_counters[C_FBC]) * 4 > (u64)nB + nC) fast_gave_up = true;
@@ -764,7 +768,6 @@ struct Rounds {
 // build stops with unresolved groups (return value MSUFSORT_HIP_UNRESOLVED): sharded builds, and every wide build
 // (their prefix doubling is the distributed one further down).
 // ------------------------------------------------------------------------------------------------
-#define MSUFSORT_HIP_UNRESOLVED 1
 template <bool W>
 int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_rows /* row 0 of this shard's slice */, u64 slice_row_lo,
              u64 z, u64 lo32, u64 hi32, u64 rank0, bool with_head, const msufsort_hip_opts* opts, bool hist_done,
@@ -826,8 +829,16 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     TRY(R.children_level1());
     if ((u64)c->h_counters[C_MS] != ms && slice_rows) { set_error("slice bounds disagree with the histogram (%u suffixes on the device, %llu planned)", c->h_counters[C_MS], (unsigned long long)ms); return MSUFSORT_HIP_ERR_INTERNAL; }
 
+    if (selected && auto_switch) text_rounds = 64;       // (late rounds of a two-stage build hold a handful of large tie groups: cheap)
     for (;; ++R.round) {
         const int round = R.round;
+        // two-stage builds: once the tiny pool is small (or the rounds drag on), its runs are finished by exact suffix
+        // comparisons instead of one more key per round - repeated passages agree for thousands of characters
+        R.deep_cap = 0;
+        if (selected && R.mode == MODE_TEXT && round >= 4) {
+            const u64 pool_n = c->h_counters[R.cur ? C_POOL1 : C_POOL0];
+            if (pool_n <= ms / 16 || round >= 12) R.deep_cap = 65536u;
+        }
         TRY(R.levels_and_sorts());
         const int nxt = R.cur ^ 1;
         const u32 nb_base = nxt ? C_LIST1 : C_LIST0;
@@ -866,8 +877,9 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         // everything tied for the first rounds without any repeats being involved.
         const double sigma2 = std::max<double>(4.0, (double)c->h_counters[C_HNZ]);
         const double need = 2.0 * std::log((double)std::max<u64>(m, 2)) / std::log(sigma2);
+        // (two-stage builds: a small set that stays tied - a passage with many copies - is cheap to carry through more rounds)
         const bool stalled = auto_switch && (!sharded || selected) && round >= 2 && (double)depth >= std::max(13.0, 1.3 * need) &&
-                             (actP + actS) * 10 > prev_active * 7;
+                             (actP + actS) * 10 > prev_active * 7 && !(selected && actP + actS <= ms / 256);
         prev_active = actP + actS;
         if (R.mode == MODE_TEXT && (round + 1 > text_rounds || stalled)) {
             if (sharded) {

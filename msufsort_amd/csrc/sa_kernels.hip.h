@@ -1994,6 +1994,49 @@ __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(
 }
 
 
+// length of the common prefix of the suffixes a and b (8 bytes per step)
+__device__ __forceinline__ u32 dev_match_length(const u8* __restrict__ text, u64 n, u64 a, u64 b)
+{
+    if (a > b) { const u64 x = a; a = b; b = x; }
+    u64 m = 0;
+    while (b + m + 8 <= n) {
+        u64 x, y;
+        __builtin_memcpy(&x, text + a + m, 8);
+        __builtin_memcpy(&y, text + b + m, 8);
+        if (x != y) { m += (u64)(__ffsll((long long)(x ^ y)) - 1) >> 3; return (u32)m; }
+        m += 8;
+    }
+    while (b + m < n && text[a + m] == text[b + m]) ++m;
+    return (u32)m;
+}
+
+// Exact order of two suffixes that are known to agree on their first `depth` characters (zero-padded view): true if suffix
+// `other` is smaller than suffix `mine`.  The suffix that ends first is the smaller one (the reference's implicit sentinel).
+// A comparison that would run past `cap` further bytes gives up (flag 0x400: the caller's build is abandoned).
+__device__ __forceinline__ bool deep_other_less(const u8* __restrict__ text, u64 n, u32 mine, u32 other, u64 depth, u32 cap, u32* __restrict__ counters)
+{
+    u64 a = mine, b = other;
+    const bool swapped = a > b;
+    if (swapped) { const u64 x = a; a = b; b = x; }            // a < b: b is the shorter suffix
+    bool b_less;
+    if (b + depth >= n) b_less = true;                          // b ends inside the part already known to agree
+    else {
+        u64 m = depth;
+        bool done = false;
+        while (b + m + 8 <= n) {
+            u64 x, y;
+            __builtin_memcpy(&x, text + a + m, 8);
+            __builtin_memcpy(&y, text + b + m, 8);
+            if (x != y) { m += (u64)(__ffsll((long long)(x ^ y)) - 1) >> 3; done = true; break; }
+            m += 8;
+            if (m - depth > cap) { atomicOr(&counters[C_ERR], 0x400u); done = true; break; }
+        }
+        if (!done) while (b + m < n && text[a + m] == text[b + m]) ++m;
+        b_less = (b + m >= n) || text[b + m] < text[a + m];
+    }
+    return swapped ? !b_less : b_less;       // b is `other` unless swapped
+}
+
 // ------------------------------------------------------------------------------------------------
 // Tiny runs (2..32 records), millions of them on text/DNA inputs: flat pool, one lane per record,
 // rank by counting inside the run (the insertion-sort regime of cpp:223-312).  A workgroup owns the
@@ -2004,9 +2047,13 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
                                                    u32 cnt_idx, typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                    u64* __restrict__ next_rec, u64* __restrict__ next_hdr, u32 next_cnt_idx, u32 next_cap,
                                                    u32 chunk, u32* __restrict__ counters, u32* __restrict__ grp_out, u32 discard,
-                                                   GatherSpec g, const u8* __restrict__ code)
+                                                   GatherSpec g, const u8* __restrict__ code, u32 deep_cap)
 {
+    // deep_cap != 0 (narrow text rounds of a two-stage build, once the pool is small): the runs are finished HERE by comparing
+    // the suffixes themselves, however long they agree (repeated passages: thousands of key rounds otherwise) - nothing goes
+    // to the next round
     constexpr u32 KL = klow<W>();
+    const bool deep = !W && deep_cap != 0u && g.text != nullptr;
     __shared__ u8 s_code[256];
     if (g.text) s_code[threadIdx.x] = code[threadIdx.x];
     constexpr int WIN = 256, HALO = TINY_MAX, TOT = WIN + HALO;
@@ -2026,7 +2073,10 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
             const u32 e = t + k * WIN;
             if (e < TOT && b0 + e < count) { rec[k] = pool_rec[b0 + e]; hdr[k] = pool_hdr[b0 + e]; have[k] = true; if (!g.text) lkey[e] = (u32)(rec[k] >> (32 + KL)); }
         }
-        if (g.text) {       // text round: the pool records carry the suffix index only
+        if (deep) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) if (have[k]) lkey[t + k * WIN] = (u32)rec[k];
+        } else if (g.text) {       // text round: the pool records carry the suffix index only
             typename Wd<W>::sa_t fi[2] = {rec_idx<W>(rec[0]), rec_idx<W>(rec[1])};
             const bool valid[2] = {have[0] && ((hdr[0] >> 32) & 255ull) != 0, have[1] && ((hdr[1] >> 32) & 255ull) != 0};      // (len 0 = neutral entry)
             u32 key[2];
@@ -2046,6 +2096,13 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
                 if (len != 0 && e >= off && e - off < WIN) {      // len 0 = neutral entry (unused chunk tail)
                     owned[k] = true;
                     const u32 ls = e - off, my = lkey[e];
+                    if (deep) {
+                        u32 less = 0;
+                        for (u32 q = 0; q < len; ++q)
+                            if (q != off && deep_other_less(g.text, g.n, my, lkey[ls + q], g.ks.depth, deep_cap, counters)) ++less;
+                        sa_out[sa_start + less] = my;
+                        continue;
+                    }
                     bool found = false;
                     for (u32 q0 = 0; q0 < len; q0 += 4) {       // four LDS reads in flight (the last ones clamped to the run)
                         u32 kq[4];

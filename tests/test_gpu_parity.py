@@ -629,3 +629,20 @@ def test_two_stage_fuzz(M, oracle_mod):
         b1, s1 = M.forward_burrows_wheeler_transform(t, two_stage=1)          # (its bytes come from the induction's rows)
         b0, s0 = oracle_mod.forward_bwt(t)
         assert s1 == s0 and (b1 == b0).all(), f"iteration {it}: BWT"
+
+
+def test_two_stage_repeated_passages(M, oracle_mod):
+    """Duplicated passages (ties hundreds to thousands of characters deep among a few suffixes): the B* sort finishes its small tie
+    groups by exact suffix comparisons, the two-stage path is kept; a passage longer than the comparison cap hands the input back."""
+    rng = np.random.default_rng(77)
+    t = gen.text_bytes(3 << 20, 31).copy()
+    n = t.size
+    for L, copies in ((200, 40), (1500, 6), (20000, 2), (700, 3)):         # 40 copies: a tie group above the tiny limit
+        src = int(rng.integers(0, n - L))
+        for _ in range(copies):
+            at = int(rng.integers(0, n - L))
+            t[at:at + L] = t[src:src + L]
+    _two_stage(M, oracle_mod, t, taken=True)
+    big = gen.text_bytes(2 << 20, 32).copy()
+    big[1000000:1000000 + 300000] = big[100:100 + 300000]                  # 300 kB duplicate: deeper than the cap
+    _two_stage(M, oracle_mod, big, taken=False)
