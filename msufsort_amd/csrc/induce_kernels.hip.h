@@ -172,14 +172,25 @@ struct IndTables {
     const u8* code;         // [256] dense number of every byte value that occurs in the text (others: 255)
     const u8* sym;          // [nb] the byte value of every dense number
     u32 nb;                 // dense numbers, rounded up to a multiple of 8: per-tile counts are kept as [tile][nb]
+    u32 nsym;               // byte values in use
 };
 
+#define IND_MAX_LEVELS 8192u
 struct IndState {
     u32 cur[256];           // pass B: next free row + 1 (right end, exclusive) of sub-bucket (c0, current c1); pass A: next free row of A(c)
     u32 rng[2][2];          // source rows [lo, hi) of the level being processed / of the next level
     u32 flags;
     u32 pad[3];
+    u32 ticket[IND_MAX_LEVELS];   // single-pass levels: next tile to hand out, one counter per level launch (zeroed with the state)
 };
+
+#define IND_FLAG_LOOKBACK 8u      // a look-back waited longer than any kernel runs: the build is reported as failed, not hung
+// tile status of the single-pass levels, one 64-bit word per (tile, byte value in use): [63:62] 1 = this tile's count,
+// 2 = count of all tiles up to and including this one; [61:48] level launch number (stale words of earlier levels read as
+// "nothing yet"); [47:0] the count
+#define IND_ST_AGG 1ull
+#define IND_ST_INC 2ull
+__device__ __forceinline__ u64 ind_status(u64 flag, u32 epoch, u64 value) { return (flag << 62) | ((u64)(epoch & 0x3fffu) << 48) | value; }
 
 // sorted B* suffixes -> the left ends of their sub-buckets; one workgroup per non-empty (c0,c1)
 __global__ __launch_bounds__(256) void k_place_bstar(const u32* __restrict__ sstar, const u32* __restrict__ keys, IndTables tb, u32* __restrict__ sa)
@@ -349,35 +360,55 @@ __global__ __launch_bounds__(256) void k_ind_scan(IndState* __restrict__ st, Ind
 // SMALL = false: the first target rows come from k_ind_count + k_ind_scan (tile_hist).
 // SMALL = true:  the level is handled by ONE workgroup, tile after tile: the first target rows are the cursors themselves, moved
 //                here; B* sources fetch their characters here too (no k_ind_count ran).
-template <bool SMALL>
+// MODE 2 (single pass): no count / scan kernels ran either; the first target rows come from a decoupled look-back over the
+//                tile status words (status, epoch, ntiles, s_base = the cursors as they were when the level started).
+template <int MODE>
 __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const IndTables& tb, u32* sa, u32* pc, const u8* __restrict__ text,
                                          const u32* __restrict__ tile_hist, u32 tile, u32 lo, u32 hi, u32 my_code,
-                                         u32 (*wcnt)[256], u32* goff, const u32* s_sub)
+                                         u32 (*wcnt)[256], u32* goff, const u32* s_sub,
+                                         u64* status = nullptr, u32 epoch = 0, u32 ntiles = 0, const u32* s_base = nullptr)
 {
+    constexpr bool SMALL = MODE == 1, FUSED = MODE == 2, OWN_STARS = MODE != 0;
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const u32 cnt = hi - lo;
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     __syncthreads();
 #pragma unroll
     for (int w2 = 0; w2 < 4; ++w2) wcnt[w2][t] = 0;
-    if (!SMALL) goff[t] = (my_code != 255u || tb.nb == 256u) ? tile_hist[(u64)tile * tb.nb + my_code] : 0u;
+    if (MODE == 0) goff[t] = (my_code != 255u || tb.nb == 256u) ? tile_hist[(u64)tile * tb.nb + my_code] : 0u;
     __syncthreads();
     u32 j[IND_ITEMS], bin[IND_ITEMS], npc[IND_ITEMS], posw[IND_ITEMS];
+    u32 starmask = 0;
+    // (phases, so that all of a thread's loads of one kind are in flight together: rows, then characters)
 #pragma unroll
     for (int i = 0; i < IND_ITEMS; ++i) {
         const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
         j[i] = 0; bin[i] = 256u; npc[i] = 0;
-        if (q < cnt) {
-            const u32 r = lv.pass_b ? hi - 1u - q : lo + q;
-            j[i] = sa[r];
-            u32 w;
-            bool star = false;
-            if (SMALL && lv.stars) {
+        if (q < cnt) j[i] = sa[lv.pass_b ? hi - 1u - q : lo + q];
+    }
+    if (OWN_STARS && lv.stars) {
+#pragma unroll
+        for (int i = 0; i < IND_ITEMS; ++i) {
+            const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
+            if (q < cnt) {
+                const u32 r = hi - 1u - q;                    // (B* rows are sources of pass B only)
                 u32 a = lv.c, b = 256u;
                 while (b - a > 1u) { const u32 mid = (a + b) >> 1; if (s_sub[mid] <= r) a = mid; else b = mid; }
-                star = r < s_sub[a] + tb.sub_bs[lv.c * 256u + a];
+                if (r < s_sub[a] + tb.sub_bs[lv.c * 256u + a]) starmask |= 1u << i;
             }
-            if (star) { w = ind_fetch(text, j[i]); pc[r] = w; } else w = pc[r];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < IND_ITEMS; ++i) {
+        const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
+        if (q < cnt) npc[i] = ((starmask >> i) & 1u) ? ind_fetch(text, j[i]) : pc[lv.pass_b ? hi - 1u - q : lo + q];
+    }
+#pragma unroll
+    for (int i = 0; i < IND_ITEMS; ++i) {
+        const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
+        if (q < cnt) {
+            const u32 w = npc[i];
+            if ((starmask >> i) & 1u) pc[hi - 1u - q] = w;
             bin[i] = ind_bin(lv, j[i], w);
             npc[i] = ((w >> 8) & 0xffffu) | (((w >> 24) - 1u) << 24);          // the new row inherits my other characters
         }
@@ -406,14 +437,67 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
         }
     }
     __syncthreads();
+    u32 tot_t = 0;                         // what this tile writes for byte t
     {
         u32 o = 0;
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) { const u32 v = wcnt[w2][t]; wcnt[w2][t] = o; o += v; }
+        tot_t = o;
         if (SMALL && o) {                  // claim the rows: the cursor of byte t moves by what this tile writes
             const u32 base = __atomic_load_n(&st->cur[t], __ATOMIC_RELAXED);
             goff[t] = lv.pass_b ? base - 1u : base;
             __atomic_store_n(&st->cur[t], lv.pass_b ? base - o : base + o, __ATOMIC_RELAXED);
+        }
+        if (FUSED && (my_code != 255u || tb.nb == 256u))        // publish this tile's counts first: the tiles behind it add them up
+            __hip_atomic_store(status + (u64)tile * tb.nb + my_code, ind_status(tile == 0 ? IND_ST_INC : IND_ST_AGG, epoch, o), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (FUSED) goff[t] = 0;
+    }
+    if (FUSED) {
+        // Decoupled look-back, eight lanes per byte value (32 values at a time): the lanes read the status words of the eight
+        // tiles in front of this one and add up their counts back to the nearest running total (further back if there is
+        // none among them).  Those tiles were handed out earlier, so their workgroups are running and publish without waiting
+        // for anybody.
+        __syncthreads();
+        if (tile != 0) {
+            const u32 sub = t & 7u, grp = lane >> 3;
+            for (u32 cbase = 0; cbase < tb.nsym; cbase += 32u) {
+                const u32 code = cbase + (t >> 3);
+                const bool active = code < tb.nsym;
+                u32 excl = 0, pbase = tile, spins = 0;
+                bool done = !active;
+                for (;;) {
+                    const bool in = !done && sub < pbase;
+                    u64 v = 0;
+                    if (in) v = __hip_atomic_load(status + (u64)(pbase - 1u - sub) * tb.nb + code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ready = !in || ((((v >> 48) & 0x3fffu) == (epoch & 0x3fffu)) && (v >> 62) != 0);
+                    const u64 inc_m = __ballot(in && ready && (v >> 62) == IND_ST_INC), wait_m = __ballot(!ready);
+                    const u32 gi = (u32)(inc_m >> (grp * 8u)) & 255u, gw = (u32)(wait_m >> (grp * 8u)) & 255u;
+                    const int f = gi ? __ffs((int)gi) - 1 : 7;                   // nearest running total, or the whole window
+                    const bool blocked = (gw & ((2u << f) - 1u)) != 0;
+                    u32 part = (!blocked && in && (int)sub <= f) ? (u32)v : 0u;
+                    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+                    if (!done && !blocked) { excl += part; if (gi) done = true; else pbase -= 8u; }
+                    if (!done && blocked && ++spins > (1u << 22)) { atomicOr(&st->flags, IND_FLAG_LOOKBACK); done = true; }
+                    if (__ballot(!done) == 0) break;
+                    if (__ballot(blocked)) __builtin_amdgcn_s_sleep(1);
+                }
+                if (active && sub == 0) goff[tb.sym[code]] = excl;
+            }
+        }
+        __syncthreads();
+        if (my_code != 255u || tb.nb == 256u) {
+            const u32 excl = goff[t];
+            const u32 mine_tot = tot_t;
+            if (tile != 0) __hip_atomic_store(status + (u64)tile * tb.nb + my_code, ind_status(IND_ST_INC, epoch, (u64)excl + mine_tot), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+            const u32 base = s_base[t];
+            goff[t] = lv.pass_b ? base - 1u - excl : base + excl;
+            if (tile == ntiles - 1u) {           // the last tile knows the level's totals: cursors move, the next level's rows are named
+                const u32 nbase = lv.pass_b ? base - (excl + mine_tot) : base + (excl + mine_tot);
+                st->cur[t] = nbase;
+                if (t == lv.c) { st->rng[lv.slot ^ 1u][0] = lv.pass_b ? nbase : base; st->rng[lv.slot ^ 1u][1] = lv.pass_b ? base : nbase; }
+            }
         }
     }
     __syncthreads();
@@ -436,7 +520,38 @@ __global__ __launch_bounds__(256) void k_ind_scatter(IndState* st, IndLevel lv, 
     const u32 ntiles = (hi - lo + IND_TILE - 1) / IND_TILE;
     const u32 my_code = tb.code[threadIdx.x];
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
-        ind_tile<false>(st, lv, tb, sa, pc, text, tile_hist, tile, lo, hi, my_code, wcnt, goff, nullptr);
+        ind_tile<0>(st, lv, tb, sa, pc, text, tile_hist, tile, lo, hi, my_code, wcnt, goff, nullptr);
+}
+
+// One level in ONE pass over its rows (instead of k_ind_count + k_ind_scan + k_ind_scatter): tiles are handed out in order by a
+// ticket counter, every tile ranks its sources, publishes its per-byte counts and learns its first target rows from the tiles in
+// front of it (decoupled look-back), then writes.  The rows are read once, the B* rows fetch their characters here.
+__global__ __launch_bounds__(256) void k_ind_fused(IndState* st, IndLevel lv, u32 epoch, u32* sa, u32* pc, const u8* __restrict__ text, IndTables tb,
+                                                   u64* status)
+{
+    __shared__ u32 wcnt[4][256];
+    __shared__ u32 goff[256];
+    __shared__ u32 s_base[256];
+    __shared__ u32 s_sub[257];
+    __shared__ u32 s_tile;
+    const u32 t = threadIdx.x;
+    s_base[t] = st->cur[t];              // the cursors as the level finds them (the last tile moves them: read before taking a tile)
+    const u32 lo = st->rng[lv.slot][0], hi = st->rng[lv.slot][1];
+    const u32 ntiles = (hi - lo + IND_TILE - 1) / IND_TILE;
+    if (lv.stars) { s_sub[t] = tb.sub_start[lv.c * 256u + t]; if (t == 0) s_sub[256] = tb.bkt[lv.c + 1]; }
+    const u32 my_code = tb.code[t];
+    if (ntiles == 0) {                   // nothing to read: the next level is empty as well
+        if (blockIdx.x == 0 && t == 0) { st->rng[lv.slot ^ 1u][0] = 0; st->rng[lv.slot ^ 1u][1] = 0; }
+        return;
+    }
+    for (;;) {
+        __syncthreads();
+        if (t == 0) s_tile = atomicAdd(&st->ticket[epoch & (IND_MAX_LEVELS - 1u)], 1u);
+        __syncthreads();
+        const u32 tile = s_tile;
+        if (tile >= ntiles) break;
+        ind_tile<2>(st, lv, tb, sa, pc, text, nullptr, tile, lo, hi, my_code, wcnt, goff, s_sub, status, epoch, ntiles, s_base);
+    }
 }
 
 // Levels that are known to be short (at most one tile, from the run-length counts of k_maxrun): ONE workgroup takes all the
@@ -459,7 +574,7 @@ __global__ __launch_bounds__(256) void k_ind_small(IndState* st, IndLevel lv, u3
         const u32 before = __atomic_load_n(&st->cur[lv.c], __ATOMIC_RELAXED);
         if (hi == lo) break;
         const u32 ntiles = (hi - lo + IND_TILE - 1) / IND_TILE;
-        for (u32 tile = 0; tile < ntiles; ++tile) ind_tile<true>(st, cur, tb, sa, pc, text, nullptr, tile, lo, hi, my_code, wcnt, goff, s_sub);
+        for (u32 tile = 0; tile < ntiles; ++tile) ind_tile<1>(st, cur, tb, sa, pc, text, nullptr, tile, lo, hi, my_code, wcnt, goff, s_sub);
         __threadfence();
         __syncthreads();
         if (t == 0) {
