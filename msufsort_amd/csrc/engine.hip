@@ -1406,7 +1406,7 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     int two_stage = o.two_stage;
     if (const char* e = getenv("MSUFSORT_HIP_TWO_STAGE")) two_stage = atoi(e);
     bool hist_done = false;
-    if (two_stage > 0 || (two_stage == 0 && (u64)n >= (96ull << 20) && tail_values <= 128u)) {
+    if (two_stage > 0 || (two_stage == 0 && (u64)n >= (48ull << 20) && tail_values <= 128u)) {
         const int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, two_stage > 0, &hist_done);
         if (r != MSUFSORT_HIP_UNRESOLVED) return r;
     }
