@@ -15,7 +15,9 @@ from msufsort_amd import _lib, gen  # noqa: E402
 from msufsort_amd.api import _opts  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else (1 << 30) - 1
-t = gen.random_bytes(n, 12345)
+workload = sys.argv[2] if len(sys.argv) > 2 else "random"
+t = gen.GENERATORS[workload](n, 12345)
+print("workload:", workload)
 sa = np.zeros(n + 1, dtype=np.int32)
 L = _lib.lib()
 
