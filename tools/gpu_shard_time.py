@@ -6,7 +6,8 @@ import numpy as np, torch
 import msufsort_amd as M
 from msufsort_amd import gen
 n = (1 << 30) - 1
-t = gen.random_bytes(n, 12345)
+workload = sys.argv[1] if len(sys.argv) > 1 else "random"
+t = gen.GENERATORS[workload](n, 12345)
 d = torch.zeros(n + 64, dtype=torch.uint8, device="cuda"); d[:n] = torch.from_numpy(t).cuda()
 full = torch.empty(n + 1, dtype=torch.int32, device="cuda")
 grp = torch.empty(n + 1, dtype=torch.int32, device="cuda")
@@ -19,7 +20,7 @@ for G in (1, 2, 4, 8):
         best = 1e9
         for rep in range(3):
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            ctx.make_sa_shard_groups(d, n, full[lo:hi], grp[lo:hi], hi - lo, g, G, text_rounds=8)
+            ctx.make_sa_shard_groups(d, n, full[lo:hi], grp[lo:hi], hi - lo, g, G, text_rounds=(8 if workload == 'random' else 0))
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
         times.append(best * 1e3)
     ok = ctx.validate_sa(d, n, full) == 0
