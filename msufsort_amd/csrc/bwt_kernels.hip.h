@@ -166,11 +166,12 @@ __device__ __forceinline__ u32 ibwt_sym(const u8* __restrict__ bwt, u32 row, u32
 __global__ __launch_bounds__(256) void k_ibwt_count(const u8* __restrict__ bwt, u32 rows, u32 sent, u32 ntiles, u32* __restrict__ counts)
 {
     // eight copies of every wave's 256 bins (copy = lane & 7): text puts a third of its bytes on a handful of symbols, and
-    // lanes that meet on one LDS address are served one after the other
-    __shared__ u32 h[4][8][256];
+    // lanes that meet on one LDS address are served one after the other.  The copies of one symbol sit next to each other
+    // (bin * 8 + copy): eight different banks - as [copy][bin] they would all share the bank of `bin`.
+    __shared__ u32 h[4][256 * 8];
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 tile = blockIdx.x * 4 + w;
-    for (u32 i = lane; i < 8u * 256u; i += 64) (&h[w][0][0])[i] = 0;
+    for (u32 i = lane; i < 8u * 256u; i += 64) h[w][i] = 0;
     __syncthreads();
     if (tile < ntiles) {
         const u32 beg = tile * IBWT_WT;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void k_ibwt_count(const u8* __restrict__ bwt, 
             if (lim == 16u) __builtin_memcpy(v, bwt + o, 16);
             else for (u32 k = 0; k < lim; ++k) v[k >> 2] |= (u32)bwt[o + k] << (8u * (k & 3u));
 #pragma unroll
-            for (u32 k = 0; k < 16; ++k) if (k < lim) atomicAdd(&h[w][lane & 7u][(v[k >> 2] >> (8u * (k & 3u))) & 255u], 1u);
+            for (u32 k = 0; k < 16; ++k) if (k < lim) atomicAdd(&h[w][(((v[k >> 2] >> (8u * (k & 3u))) & 255u) << 3) | (lane & 7u)], 1u);
         }
     }
     __syncthreads();
@@ -191,113 +192,141 @@ __global__ __launch_bounds__(256) void k_ibwt_count(const u8* __restrict__ bwt, 
         for (u32 i = lane; i < 256; i += 64) {
             u32 sum = 0;
 #pragma unroll
-            for (u32 q = 0; q < 8; ++q) sum += h[w][q][i];
-            counts[(u64)i * ntiles + tile] = sum;
+            for (u32 q = 0; q < 8; ++q) sum += h[w][i * 8u + q];
+            counts[(u64)tile * 256u + i] = sum;
         }
 }
 
-// generic device-wide exclusive scan of u32[N]: partial -> top -> final
-#define SCAN_ITEMS 8
-#define SCAN_BLOCK (1024 * SCAN_ITEMS)
-__device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* wsum /*16*/, u32& block_total)
+// Exclusive scan of the per-tile symbol counts in symbol-major / tile-minor order, base 1 (cpp:1880-1889).  The counts are
+// kept TILE-major, counts[tile][256] (what the count and scatter kernels read and write as whole lines; symbol-major, every
+// tile touched 256 lines), so the scan runs down the 256 columns: column sums per block of IBS_TB tiles, symbol bases from
+// the column totals, then every block walks its tiles with the sum of the blocks in front of it.
+#define IBS_TB 512u
+__global__ __launch_bounds__(256) void k_ibwt_scan_partial(const u32* __restrict__ counts, u32 ntiles, u32* __restrict__ bsum /* [blocks][256] */)
 {
-    u32 wt;
-    const u32 e = wave_excl_scan(v, wt);
-    if (lane_id() == 63) wsum[threadIdx.x >> 6] = wt;
-    __syncthreads();
-    u32 wbase = 0, tot = 0;
-#pragma unroll
-    for (u32 k = 0; k < 16; ++k) { const u32 s = wsum[k]; if (k < (threadIdx.x >> 6)) wbase += s; tot += s; }
-    __syncthreads();
-    block_total = tot;
-    return wbase + e;
-}
-
-__global__ __launch_bounds__(1024) void k_scan_partial(const u32* __restrict__ in, u64 N, u32* __restrict__ block_sums)
-{
-    __shared__ u32 wsum[16];
-    const u64 base = (u64)blockIdx.x * SCAN_BLOCK + (u64)threadIdx.x * SCAN_ITEMS;
-    u32 s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < N) s += in[base + k];
-    u32 tot;
-    (void)block_excl_scan_1024(s, wsum, tot);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(1024) void k_scan_top(u32* __restrict__ sums, u32 nb, u32 init)
-{
-    __shared__ u32 wsum[16];
-    __shared__ u32 s_carry;
-    if (threadIdx.x == 0) s_carry = init;
-    __syncthreads();
-    for (u32 b = 0; b < nb; b += 1024u) {
-        const u32 i = b + threadIdx.x;
-        const u32 v = i < nb ? sums[i] : 0u;
-        u32 tot;
-        const u32 e = block_excl_scan_1024(v, wsum, tot);
-        const u32 carry = s_carry;
-        if (i < nb) sums[i] = carry + e;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = carry + tot;
-        __syncthreads();
+    const u32 b = blockIdx.x, t = threadIdx.x;
+    const u32 t0 = b * IBS_TB, t1 = t0 + IBS_TB < ntiles ? t0 + IBS_TB : ntiles;
+    u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    u32 tile = t0;
+    for (; tile + 4 <= t1; tile += 4) {
+        s0 += counts[(u64)tile * 256u + t]; s1 += counts[(u64)(tile + 1) * 256u + t];
+        s2 += counts[(u64)(tile + 2) * 256u + t]; s3 += counts[(u64)(tile + 3) * 256u + t];
     }
+    for (; tile < t1; ++tile) s0 += counts[(u64)tile * 256u + t];
+    bsum[b * 256u + t] = s0 + s1 + s2 + s3;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_final(u32* __restrict__ data, u64 N, const u32* __restrict__ block_sums)
+__global__ __launch_bounds__(256) void k_ibwt_scan_top(const u32* __restrict__ bsum, u32 nblk, u32* __restrict__ symbase /* 256 */)
 {
-    __shared__ u32 wsum[16];
-    const u64 base = (u64)blockIdx.x * SCAN_BLOCK + (u64)threadIdx.x * SCAN_ITEMS;
-    u32 v[SCAN_ITEMS];
-    u32 s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < N) ? data[base + k] : 0u; s += v[k]; }
-    u32 tot;
-    u32 e = block_excl_scan_1024(s, wsum, tot) + block_sums[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < N) data[base + k] = e; e += v[k]; }
+    __shared__ u32 tot[256], base[256];
+    const u32 t = threadIdx.x;
+    u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    u32 b = 0;
+    for (; b + 4 <= nblk; b += 4) { s0 += bsum[b * 256u + t]; s1 += bsum[(b + 1) * 256u + t]; s2 += bsum[(b + 2) * 256u + t]; s3 += bsum[(b + 3) * 256u + t]; }
+    for (; b < nblk; ++b) s0 += bsum[b * 256u + t];
+    tot[t] = s0 + s1 + s2 + s3;
+    __syncthreads();
+    scan256_first_wave(tot, base);
+    __syncthreads();
+    symbase[t] = base[t] + 1u;            // row 0 is the empty suffix (cpp:1891)
 }
 
-// stable ranked scatter: link[C[c] + rank] = row  (one wave per tile, 64 rows per step)
+__global__ __launch_bounds__(256) void k_ibwt_scan_final(u32* __restrict__ counts, u32 ntiles, const u32* __restrict__ bsum, const u32* __restrict__ symbase)
+{
+    const u32 b = blockIdx.x, t = threadIdx.x;
+    const u32 t0 = b * IBS_TB, t1 = t0 + IBS_TB < ntiles ? t0 + IBS_TB : ntiles;
+    u32 r0 = symbase[t], r1 = 0, r2 = 0, r3 = 0;
+    u32 q = 0;
+    for (; q + 4 <= b; q += 4) { r0 += bsum[q * 256u + t]; r1 += bsum[(q + 1) * 256u + t]; r2 += bsum[(q + 2) * 256u + t]; r3 += bsum[(q + 3) * 256u + t]; }
+    for (; q < b; ++q) r0 += bsum[q * 256u + t];
+    u32 run = r0 + r1 + r2 + r3;
+    u32 tile = t0;
+    for (; tile + 4 <= t1; tile += 4) {          // four loads in flight, then the dependent adds
+        const u32 v0 = counts[(u64)tile * 256u + t], v1 = counts[(u64)(tile + 1) * 256u + t], v2 = counts[(u64)(tile + 2) * 256u + t],
+                  v3 = counts[(u64)(tile + 3) * 256u + t];
+        counts[(u64)tile * 256u + t] = run; run += v0;
+        counts[(u64)(tile + 1) * 256u + t] = run; run += v1;
+        counts[(u64)(tile + 2) * 256u + t] = run; run += v2;
+        counts[(u64)(tile + 3) * 256u + t] = run; run += v3;
+    }
+    for (; tile < t1; ++tile) { const u32 v = counts[(u64)tile * 256u + t]; counts[(u64)tile * 256u + t] = run; run += v; }
+}
+
+// stable ranked scatter: link[C[c] + rank] = row.  One workgroup per tile of IBWT_WT rows, 2048 rows at a time: rank inside the
+// sub-tile from wave ballots + per-wave counters (stable), rows staged in LDS grouped by symbol and written as runs - the
+// link table receives whole lines instead of one 4-byte store per row into a few dozen places.
+#define IBS_SUB 2048u
 __global__ __launch_bounds__(256) void k_ibwt_scatter(const u8* __restrict__ bwt, u32 rows, u32 sent, u32 ntiles,
                                                       const u32* __restrict__ offs, u32* __restrict__ link)
 {
-    __shared__ u32 cur[4][256];
-    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const u32 tile = blockIdx.x * 4 + w;
-    if (blockIdx.x == 0 && threadIdx.x == 0) link[0] = sent;      // cpp:1891
-    if (tile < ntiles) for (u32 i = lane; i < 256; i += 64) cur[w][i] = offs[(u64)i * ntiles + tile];
-    __syncthreads();
-    if (tile >= ntiles) return;
+    __shared__ u32 cur[256];           // next free link slot of every symbol (this tile)
+    __shared__ u32 wcnt[4][256];
+    __shared__ u32 tot[256], lstart[256];
+    __shared__ u32 stage[IBS_SUB];
+    __shared__ u8 sbin[IBS_SUB];
+    const u32 t = threadIdx.x, w = t >> 6, lane = t & 63u;
+    const u32 tile = blockIdx.x;
+    if (tile == 0 && t == 0) link[0] = sent;      // cpp:1891
+    cur[t] = offs[(u64)tile * 256u + t];
     const u32 beg = tile * IBWT_WT;
     const u32 end = (rows - beg < IBWT_WT) ? rows : beg + IBWT_WT;
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    for (u32 rb = beg; rb < end; rb += 64u * 4u) {               // four byte loads in flight per lane
-        u32 cs[4];
+    for (u32 sb = beg; sb < end; sb += IBS_SUB) {
+        __syncthreads();
 #pragma unroll
-        for (u32 k = 0; k < 4; ++k) { const u32 r = rb + 64u * k + lane; cs[k] = (r < end && r != sent) ? ibwt_sym(bwt, r, sent) : 0u; }
+        for (int w2 = 0; w2 < 4; ++w2) wcnt[w2][t] = 0;
+        __syncthreads();
+        u32 cs[8], pos[8];
+        u32 vmask = 0;
 #pragma unroll
-        for (u32 k = 0; k < 4; ++k) {
-        const u32 r0 = rb + 64u * k;
-        if (r0 >= end) break;
-        const u32 r = r0 + lane;
-        const bool valid = r < end && r != sent;
-        const u32 c = cs[k];
-        u64 mask = __ballot(valid);
+        for (u32 k = 0; k < 8; ++k) {
+            const u32 r = sb + w * 512u + k * 64u + lane;
+            const bool valid = r < end && r != sent;
+            cs[k] = valid ? ibwt_sym(bwt, r, sent) : 0u;
+            vmask |= (u32)valid << k;
+        }
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (c >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            mask &= bit ? bal : ~bal;
+        for (u32 k = 0; k < 8; ++k) {
+            const bool valid = (vmask >> k) & 1u;
+            const u32 c = cs[k];
+            u64 mask = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (c >> b) & 1u;
+                const u64 bal = __ballot(bit);
+                mask &= bit ? bal : ~bal;
+            }
+            pos[k] = 0;
+            if (valid) {
+                const int leader = __ffsll((long long)mask) - 1;
+                u32 old = 0;
+                if ((int)lane == leader) old = atomicAdd(&wcnt[w][c], (u32)__popcll(mask));
+                old = __shfl(old, leader, 64);
+                pos[k] = old + (u32)__popcll(mask & lt_mask);
+            }
         }
-        if (valid) {
-            const int leader = __ffsll((long long)mask) - 1;
-            u32 old = 0;
-            if ((int)lane == leader) old = atomicAdd(&cur[w][c], (u32)__popcll(mask));
-            old = __shfl(old, leader, 64);
-            link[old + (u32)__popcll(mask & lt_mask)] = r;
+        __syncthreads();
+        {
+            u32 o = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) { const u32 v = wcnt[w2][t]; wcnt[w2][t] = o; o += v; }
+            tot[t] = o;
         }
-        }
+        __syncthreads();
+        scan256_first_wave(tot, lstart);
+        __syncthreads();
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k)
+            if ((vmask >> k) & 1u) {
+                const u32 c = cs[k], slot = lstart[c] + wcnt[w][c] + pos[k];
+                stage[slot] = sb + w * 512u + k * 64u + lane;
+                sbin[slot] = (u8)c;
+            }
+        __syncthreads();
+        const u32 total = lstart[255] + tot[255];
+        for (u32 s = t; s < total; s += 256u) { const u32 c = sbin[s]; link[cur[c] + (s - lstart[c])] = stage[s]; }
+        __syncthreads();
+        cur[t] += tot[t];
     }
 }
 
@@ -324,7 +353,7 @@ __device__ __forceinline__ u32 ibwt_start(u32 id, u32 sent, u32 kreg) { return i
 #ifndef IBWT_NCH
 #define IBWT_NCH 2
 #endif
-__global__ __launch_bounds__(256) void k_ibwt_walk(const u32* __restrict__ link, const u32* __restrict__ offs /* [256][ntiles]: C[c] = offs[c * ntiles] */,
+__global__ __launch_bounds__(256) void k_ibwt_walk(const u32* __restrict__ link, const u32* __restrict__ offs /* [ntiles][256]: C[c] = offs[c] (tile 0) */,
                                                    u32 ntiles, u32 rows, u32 sent, u32 kreg, u32 K, u32 kt_cap,
                                                    u32* __restrict__ queue /* [1] dynamic count, [2] overflow flag */,
                                                    u32* __restrict__ nxt, u32* __restrict__ dist, u8* __restrict__ segbuf)
@@ -336,7 +365,7 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const u32* __restrict__ link,
     __shared__ u32 s_C[258];
     __shared__ u8 s_T[4096];
     const u32 t = threadIdx.x;
-    s_C[t] = offs[(u64)t * ntiles];
+    s_C[t] = offs[t];
     if (t == 0) {
         s_C[256] = rows; s_C[257] = 0xffffffffu;
         const u32 per = (K - 1u + gridDim.x - 1u) / gridDim.x;

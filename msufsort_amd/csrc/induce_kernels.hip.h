@@ -302,13 +302,13 @@ __global__ __launch_bounds__(256) void k_ind_count(const IndState* __restrict__ 
             const u32 b = in ? ind_bin(lv, j[i], pcv[i]) : 256u;
             // (eight copies of the bins, copy = lane & 7: text and DNA put everything on a handful of bytes, and lanes that
             // meet on one LDS address are served one after the other)
-            if (b < 256u) atomicAdd(&hist[(lane & 7u) * 256u + b], 1u);
+            if (b < 256u) atomicAdd(&hist[b * 8u + (lane & 7u)], 1u);          // (copies of one byte value next to each other: eight banks)
         }
         __syncthreads();
         if (my_code != 255u || tb.nb == 256u) {      // (255 = byte value that does not occur, unless all do)
             u32 sum = 0;
 #pragma unroll
-            for (u32 q = 0; q < 8; ++q) sum += hist[q * 256u + t];
+            for (u32 q = 0; q < 8; ++q) sum += hist[t * 8u + q];
             tile_hist[(u64)tile * tb.nb + my_code] = sum;
         }
     }
