@@ -372,7 +372,9 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const u32 cnt = hi - lo;
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    __shared__ u8 s_codes[256];            // dense number of every byte value (255: not in use; all 256 in use: the identity)
     __syncthreads();
+    s_codes[t] = (u8)my_code;
 #pragma unroll
     for (int w2 = 0; w2 < 4; ++w2) wcnt[w2][t] = 0;
     if (MODE == 0) goff[t] = (my_code != 255u || tb.nb == 256u) ? tile_hist[(u64)tile * tb.nb + my_code] : 0u;
@@ -416,16 +418,20 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
 #pragma unroll
     for (int i = 0; i < IND_ITEMS; ++i)
         if (bin[i] < 256u && (npc[i] >> 24) == 0u) npc[i] = ind_fetch(text, j[i] - 1u);                // ... or fetches its own
+    const u32 nbits = tb.nsym > 1u ? 32u - (u32)__builtin_clz(tb.nsym - 1u) : 1u;     // bits of a dense byte number: 5 for a text, 3 for DNA
 #pragma unroll
     for (int i = 0; i < IND_ITEMS; ++i) {
-        // lanes of this row with my byte (rows of a wave are taken in order: stable)
+        // lanes of this row with my byte (rows of a wave are taken in order: stable): one ballot per bit of its dense number
         const bool on = bin[i] < 256u;
+        const u32 cb = on ? (u32)s_codes[bin[i]] : 0u;
         u64 peers = __ballot(on);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            const bool bit = (bin[i] >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
+            if ((u32)b < nbits) {
+                const bool bit = (cb >> b) & 1u;
+                const u64 bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
         }
         posw[i] = 0;
         if (on) {
