@@ -175,7 +175,7 @@ struct IndTables {
     u32 nsym;               // byte values in use
 };
 
-#define IND_MAX_LEVELS 8192u
+#define IND_MAX_LEVELS 32768u
 struct IndState {
     u32 cur[256];           // pass B: next free row + 1 (right end, exclusive) of sub-bucket (c0, current c1); pass A: next free row of A(c)
     u32 rng[2][2];          // source rows [lo, hi) of the level being processed / of the next level

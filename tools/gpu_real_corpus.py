@@ -43,7 +43,7 @@ ctx = M.DeviceContext(0, 0)
 for mode, out in ((-1, sa0), (1, sa1), (0, sa1)):
     best = 1e9
     for r in range(2):
-        ctx.make_sa(d, n, out, two_stage=mode, verbose=0)
+        ctx.make_sa(d, n, out, two_stage=mode, verbose=(1 if (mode == 1 and r == 0) else 0))
         best = min(best, ctx.timings().total_ms)
     tm = ctx.timings()
     print(f"two_stage={mode:2d}: {best:8.2f} ms  (taken: {tm.reserved[5] > 0}, rounds {tm.rounds}, doubling rounds {tm.doubling_rounds}, induction {tm.other_ms:.2f} ms)", flush=True)
