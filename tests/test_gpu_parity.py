@@ -575,7 +575,8 @@ def test_two_stage_declines(M, oracle_mod):
     """Inputs the two-stage path hands back to the sort-all path: results stay exact."""
     body = gen.text_bytes(1 << 20, 12)
     _two_stage(M, oracle_mod, np.full(100000, 65, np.uint8), taken=False)                               # one long run
-    _two_stage(M, oracle_mod, np.concatenate([np.full(3000, 97, np.uint8), body]), taken=False)         # more levels than it is worth
+    _two_stage(M, oracle_mod, np.concatenate([np.full(3000, 97, np.uint8), body]), taken=True)          # 3000 levels in one bucket, one launch
+    _two_stage(M, oracle_mod, np.concatenate([np.full(3500, 97, np.uint8), body, np.full(3500, 98, np.uint8)]), taken=False)      # more levels than it is worth
     _two_stage(M, oracle_mod, np.concatenate([body, body]), taken=False)                                # B* suffixes tie too deep
     _two_stage(M, oracle_mod, body[:4000], taken=False)                                                 # too short
     sa = M.make_suffix_array(body, two_stage=1)
