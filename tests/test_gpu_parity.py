@@ -647,3 +647,20 @@ def test_two_stage_repeated_passages(M, oracle_mod):
     big = gen.text_bytes(2 << 20, 32).copy()
     big[1000000:1000000 + 300000] = big[100:100 + 300000]                  # 300 kB duplicate: deeper than the cap
     _two_stage(M, oracle_mod, big, taken=False)
+
+
+def test_two_stage_repeatable(M):
+    """The single-pass induction levels chain their tiles through status words in memory (tickets, decoupled look-back): the
+    same input 30 times over must give the sort-all rows every time."""
+    import torch
+    t = gen.text_bytes((16 << 20) + 3, 41)
+    n = t.size
+    d = _dev(M, t)
+    ctx = M.DeviceContext(0)
+    ref = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, n, ref, two_stage=-1)
+    for r in range(30):
+        sa.zero_()
+        ctx.make_sa(d, n, sa, two_stage=1)
+        assert ctx.timings().reserved[5] > 0 and torch.equal(sa, ref), r
