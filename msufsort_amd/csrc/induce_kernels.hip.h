@@ -18,8 +18,8 @@
 // Every row carries up to three characters in front of its suffix (pc[row] = T[j-1] | T[j-2] << 8 | T[j-3] << 16 | count << 24,
 // j = SA[row]), so a source costs no text access to find its target, and the row it induces inherits the remaining
 // characters: text is read (one unaligned 4-byte load) only for B* rows and for every third row of an induction chain.
-// Random text accesses of the whole second stage: about 1.3 per B* suffix (against a sector per tied suffix and key round
-// in the sort-all path).
+// Random text accesses of the whole second stage: about 1.3 per B* suffix, each a 128-byte line of HBM traffic (against a line
+// per tied suffix and key round in the sort-all path).
 #pragma once
 #include "sa_kernels.hip.h"
 
@@ -357,9 +357,9 @@ __global__ __launch_bounds__(256) void k_ind_scan(IndState* __restrict__ st, Ind
 }
 
 // One tile of a level's stable scatter: row of source j's predecessor = first target row of (tile, byte) +- rank inside the tile.
-// SMALL = false: the first target rows come from k_ind_count + k_ind_scan (tile_hist).
-// SMALL = true:  the level is handled by ONE workgroup, tile after tile: the first target rows are the cursors themselves, moved
-//                here; B* sources fetch their characters here too (no k_ind_count ran).
+// MODE 0 (three kernels per level, MSUFSORT_HIP_IND_CLASSIC): the first target rows come from k_ind_count + k_ind_scan (tile_hist).
+// MODE 1 (short levels): the level is handled by ONE workgroup, tile after tile: the first target rows are the cursors themselves,
+//                moved here; B* sources fetch their characters here too (no k_ind_count ran).
 // MODE 2 (single pass): no count / scan kernels ran either; the first target rows come from a decoupled look-back over the
 //                tile status words (status, epoch, ntiles, s_base = the cursors as they were when the level started).
 template <int MODE>
