@@ -282,17 +282,24 @@ inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 inline u32 grid_for(u64 items, u32 per_block = 256, u32 cap = 65536u) { return (u32)std::min<u64>(std::max<u64>((items + per_block - 1) / per_block, 1), cap); }
 
 // number of trailing 0x00 bytes of the device text
-int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out, u32* tail_values = nullptr /* distinct byte values among the last 4 KiB */)
+int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out,
+                   u32* sample_values = nullptr /* distinct byte values among the last 4 KiB and three 1 KiB samples of the body */)
 {
-    u8 tail[4096];
+    u8 tail[4096], body[3][1024];
     u64 k = std::min<u64>(n, sizeof tail);
     HIP_TRY(hipMemcpyAsync(tail, d_text + (n - k), k, hipMemcpyDeviceToHost, c->stream));
+    const bool sample = sample_values && n >= (1u << 20);
+    if (sample)
+        for (int q = 0; q < 3; ++q) HIP_TRY(hipMemcpyAsync(body[q], d_text + (n / 4) * (q + 1) - 512, 1024, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (tail_values) {
+    if (sample_values) {
         bool seen[256] = {false};
         u32 d = 0;
         for (u64 i = 0; i < k; ++i) if (!seen[tail[i]]) { seen[tail[i]] = true; ++d; }
-        *tail_values = d;
+        if (sample)
+            for (int q = 0; q < 3; ++q)
+                for (int i = 0; i < 1024; ++i) if (!seen[body[q][i]]) { seen[body[q][i]] = true; ++d; }
+        *sample_values = d;
     }
     u64 z = 0;
     while (z < k && tail[k - 1 - z] == 0) ++z;
@@ -1402,7 +1409,8 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     o.n_shards = 1; o.shard = 0;
     // two-stage build (B* sort + induction) for text-like inputs; everything it declines goes through the sort-all path.
     // The default policy first looks at what is on the host anyway (length; the byte values among the last 4 KiB, which
-    // trailing_zeros just fetched): inputs that cannot qualify - short ones, random bytes - do not pay for the typing passes.
+    // trailing_zeros fetched, and three 1 KiB samples of the body that came with them): inputs that cannot qualify - short ones,
+    // random bytes - do not pay for the typing passes.
     int two_stage = o.two_stage;
     if (const char* e = getenv("MSUFSORT_HIP_TWO_STAGE")) two_stage = atoi(e);
     bool hist_done = false;
