@@ -664,3 +664,11 @@ def test_two_stage_repeatable(M):
         sa.zero_()
         ctx.make_sa(d, n, sa, two_stage=1)
         assert ctx.timings().reserved[5] > 0 and torch.equal(sa, ref), r
+
+
+def test_two_stage_three_kernel_levels(M, oracle_mod, monkeypatch):
+    """MSUFSORT_HIP_IND_CLASSIC=1: the induction levels as count / scan / scatter launches (the first version, kept as a
+    diagnostic switch) give the same rows as the single-pass levels."""
+    monkeypatch.setenv("MSUFSORT_HIP_IND_CLASSIC", "1")
+    _two_stage(M, oracle_mod, gen.text_bytes((2 << 20) + 9, 51))
+    _two_stage(M, oracle_mod, gen.dna_bytes(1 << 20, 52))
