@@ -10,7 +10,7 @@ for L in "$@"; do
 import csv, glob
 f = glob.glob("$D/*/*kernel_stats.csv")[0]
 for r in csv.reader(open(f)):
-    if r[0].startswith("k_ibwt") or r[0].startswith("k_scan"):
+    if "k_ibwt" in r[0]:
         print("   %-28s calls %3s avg %8.3f ms" % (r[0][:28], r[1], float(r[3]) / 1e6))
 PY
 done
