@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """bench.py - MB/s of input for the suffix-array build on uniform-random bytes (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W [--size BYTES] [--workload random|text|dna|dna_tandem] [--op sa[,bwt][,ibwt][,lcp]]
+  python bench.py --gpus N --steps K --warmup W [--size BYTES] [--workload random|text|dna|dna_tandem] [--op sa[,bwt][,fbwt][,ibwt][,lcp]]
 
-Default (what the driver runs): the headline, SA of 2^30 - 1 uniform random bytes.  `--workload text --op sa,bwt,ibwt`
-is BASELINE config 3 + 4 (a step = SA build, BWT from the SA, inverse BWT; single GPU).
+Default (what the driver runs): the headline, SA of 2^30 - 1 uniform random bytes (splitmix64 seed 12345), checked after the timed
+region against the hash the UNMODIFIED reference produced for the same input (tests/golden/golden_full.json).  With N = 1 and
+no workload flags the same JSON line also carries BASELINE configs 3 and 4 under "configs" (text, 2^30 - 1 bytes: SA, forward
+BWT, inverse BWT, LCP), measured after the headline, each with its own roofline entry, reference hashes and CPU baseline.
 
 A "step" is one complete suffix-array build (16-bit radix histogram, two 8-bit scatter levels, LDS bucket
 sorts, refinement rounds) of one synthetic input that is already resident in HBM.  N = 1: the whole
-array on one MI355X.  N > 1 (launched by torch.distributed.run, one rank per GPU): the 16-bit key space
-is split into N count-balanced ranges, every rank sorts its range into its slice of the full array and
-the slices are exchanged with one all-gatherv (one group of direct sends/receives over RCCL/xGMI); total work
-is fixed, so "scaling" is "strong".  Rank 0 prints ONE JSON line.
+array on one MI355X.  N > 1: the 4-byte-prefix space is split into N count-balanced ranges, every rank sorts its range into
+its slice of the full array and the slices are exchanged with one all-gatherv (one group of direct sends/receives over
+RCCL/xGMI); total work is fixed, so "scaling" is "strong".  `python bench.py --gpus N` starts its N ranks itself (a child
+`torch.distributed.run`, one rank per GPU); started under torch.distributed.run it is one of the ranks.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -23,35 +25,288 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+CPU_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, %(root)r)
+import oracle
+from msufsort_amd import gen
+t = gen.GENERATORS[%(workload)r](%(n)d, %(seed)d)
+out = []
+for threads, what in %(runs)r:
+    t0 = time.perf_counter()
+    if what == "sa":
+        oracle.ref_make_suffix_array(t, threads)
+    else:
+        oracle.ref_forward_bwt(t, threads)
+    dt = time.perf_counter() - t0
+    out.append({"threads": threads, "op": what, "seconds": round(dt, 3), "MB/s": round(t.size / dt / 1e6, 2)})
+    print(json.dumps(out), flush=True)
+"""
 
 
-def cpu_baseline(sample_bytes, seed, workload="random"):
-    """The unmodified reference (oracle/_ref, "reference") or our C restatement ("port") timed on the
-    host cores on a bounded sample of the same stream.  Checker/baseline only - never the product."""
-    import numpy as np  # noqa: F401
+def cpu_reference_runs(workload, seed, n, runs, timeout_s):
+    """The unmodified reference (oracle/_ref) timed on the host cores in a CHILD process (its spin-wait worker pool can stall;
+    a watchdog ends it).  Checker/baseline only - never the product.  Returns the runs that finished."""
+    import subprocess
+    code = CPU_CHILD % {"root": ROOT, "workload": workload, "n": n, "seed": seed, "runs": runs}
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("[")]
+    except subprocess.TimeoutExpired as e:
+        so = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        lines = [ln for ln in so.splitlines() if ln.startswith("[")]
+    return json.loads(lines[-1]) if lines else []
 
+
+def cpu_baseline(sample_bytes, seed, workload="random", op="sa", full_n=None):
+    """cpu_baseline object of the JSON line: the reference ("reference") with 32 threads and with every hardware thread,
+    or - when oracle/_ref is absent - our single-threaded C restatement ("port") on a bounded sample."""
     import oracle
-    from msufsort_amd import gen
-    t = gen.GENERATORS[workload](sample_bytes, seed)
     ncpu = os.cpu_count() or 1
     if oracle.have_reference():
-        cores = max(1, min(32, ncpu))
-        kind = "reference"
-        runs = []
-        for _ in range(3):                      # spin-wait pool: median of 3 runs on the same input (SURVEY 8(d))
-            t0 = time.perf_counter()
-            oracle.ref_make_suffix_array(t, cores)
-            runs.append(time.perf_counter() - t0)
-        med = sorted(runs)[1]
-        note = "median of 3 (runs: " + ", ".join(f"{sample_bytes / r / 1e6:.1f}" for r in runs) + " MB/s)"
-    else:
-        cores, kind = 1, "port"
+        t32 = max(1, min(32, ncpu))
+        runs = [(t32, op)] + ([(ncpu, op)] if ncpu != t32 else [])
+        res = cpu_reference_runs(workload, seed, sample_bytes, runs, timeout_s=240)
+        if not res:
+            return {"error": "the reference did not finish within 240 s", "host_cpus": ncpu}
+        best = max(res, key=lambda r: r["MB/s"])
+        what = "make_suffix_array" if op == "sa" else "forward_burrows_wheeler_transform"
+        part = "the whole input" if full_n == sample_bytes else f"first {sample_bytes} bytes of the same stream"
+        return {"value": best["MB/s"], "unit": "MB/s", "cores": best["threads"], "kind": "reference", "host_cpus": ncpu, "runs": res,
+                "sample": f"{part}, {what} wall time incl. allocation, one run per thread count ({', '.join(str(r['threads']) for r in res)} threads; value = the faster)"}
+    from msufsort_amd import gen
+    t = gen.GENERATORS[workload](min(sample_bytes, 1 << 24), seed)
+    t0 = time.perf_counter()
+    oracle.make_suffix_array(t)
+    dt = time.perf_counter() - t0
+    return {"value": round(t.size / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port", "host_cpus": ncpu,
+            "sample": f"first {t.size} bytes of the same stream, C restatement of the two-stage sort, one run"}
+
+
+def golden_entry(workload, seed, n):
+    try:
+        full = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_full.json")))["full"]
+    except Exception:  # noqa: BLE001
+        return None
+    for e in full:
+        if e["generator"] == workload and e["seed"] == seed and e["n"] == n:
+            return e
+    return None
+
+
+def check_golden(entry, d_sa=None, d_bwt=None, sentinel=None, d_lcp=None):
+    """After the timed region: FNV-1a-64 of the device results (copied to the host) against what the unmodified reference
+    returned for the same input in the build container (tests/golden/make_golden_full.py).  The hash routine is the checker's."""
+    import oracle
+    ok, checked = True, []
+    if d_sa is not None and "sa_fnv" in entry:
+        ok = ok and ("%016x" % oracle.fnv1a64(d_sa.cpu().numpy())) == entry["sa_fnv"]; checked.append("sa")
+    if d_bwt is not None and "bwt_fnv" in entry:
+        ok = ok and ("%016x" % oracle.fnv1a64(d_bwt.cpu().numpy())) == entry["bwt_fnv"] and int(sentinel) == entry["sentinel"]; checked.append("bwt")
+    if d_lcp is not None and "lcp_fnv" in entry:
+        ok = ok and ("%016x" % oracle.fnv1a64(d_lcp.cpu().numpy())) == entry["lcp_fnv"]; checked.append("lcp")
+    return ok, checked
+
+
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` run directly: start the N ranks as a CHILD (torch.distributed.run, one rank per GPU) and
+    hand its exit code back - the library's own fan-out over its workers is msufsort.cpp:1652-1683.  Nothing in this
+    process has touched HIP yet (device_count() does not initialise the GPU), and nothing is exec'ed."""
+    import socket
+    import subprocess
+
+    import torch
+    have = torch.cuda.device_count()
+    if have < n_ranks and not os.environ.get("MSUFSORT_BENCH_ONE_DEVICE"):
+        print(f"bench.py: --gpus {n_ranks} but only {have} GPU(s) visible "
+              "(MSUFSORT_BENCH_ONE_DEVICE=1 lets all ranks share GPU 0 over gloo: a test hook, not a measurement)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Single:
+    """One single-GPU measurement: `steps` timed steps of ops over one input resident in HBM."""
+
+    def __init__(self, M, torch, ctx, dev, workload, seed, n, ops):
+        from msufsort_amd import gen
+        self.M, self.torch, self.ctx, self.dev, self.workload, self.seed, self.n, self.ops = M, torch, ctx, dev, workload, seed, n, ops
+        t = gen.GENERATORS[workload](n, seed)
+        self.d_text = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+        self.d_text[:n] = torch.from_numpy(t).to(dev)
+        del t
+        self.d_sa = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        need_bwt = any(o in ops for o in ("bwt", "ibwt", "fbwt"))
+        self.d_bwt = torch.empty(n, dtype=torch.uint8, device=dev) if need_bwt else None
+        self.d_inv = torch.empty(n, dtype=torch.uint8, device=dev) if "ibwt" in ops else None
+        self.d_lcp = torch.empty(n, dtype=torch.int32, device=dev) if "lcp" in ops else None
+        torch.cuda.synchronize(dev)          # the engine works on its own HIP stream: the upload must have landed
+        self.op_ms = {k: 0.0 for k in ops}
+        self.ibwt_us = [0, 0]
+        self.phases = []
+        self.sentinel = None
+
+    def _timed(self, name, f):
         t0 = time.perf_counter()
-        oracle.make_suffix_array(t)
-        med = time.perf_counter() - t0
-        note = "one run"
-    return {"value": round(sample_bytes / med / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": kind,
-            "sample": f"first {sample_bytes} bytes of the same stream, make_suffix_array wall time incl. SA allocation, {note}"}
+        r = f()
+        self.op_ms[name] += (time.perf_counter() - t0) * 1e3
+        return r
+
+    def step(self):
+        c, n, ops = self.ctx, self.n, self.ops
+        self._timed("sa", lambda: c.make_sa(self.d_text, n, self.d_sa))
+        self.phases.append(c.timings())
+        sent = None
+        if "fbwt" in ops:      # the forward transform as ONE call (own suffix-array build + BWT, reference cpp:1771-1817)
+            sent = self._timed("fbwt", lambda: c.forward_bwt(self.d_text, n, self.d_bwt))
+        elif self.d_bwt is not None:
+            sent = self._timed("bwt" if "bwt" in ops else "ibwt", lambda: c.bwt_from_sa(self.d_text, n, self.d_sa, self.d_bwt))
+        if "ibwt" in ops:
+            self._timed("ibwt", lambda: c.inverse_bwt(self.d_bwt, n, sent, self.d_inv))
+            tmi = c.timings()
+            self.ibwt_us[0] += tmi.ibwt_walk_us; self.ibwt_us[1] += tmi.ibwt_total_us
+        if "lcp" in ops:
+            self._timed("lcp", lambda: c.lcp(self.d_text, n, self.d_sa, self.d_lcp))
+        self.sentinel = sent
+
+    def run(self, steps, warmup):
+        torch, dev = self.torch, self.dev
+        for _ in range(warmup):
+            self.step()
+        self.phases.clear()
+        for k in self.op_ms:
+            self.op_ms[k] = 0.0
+        self.ibwt_us = [0, 0]
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize(dev)
+        self.dt = time.perf_counter() - t0
+        self.steps = steps
+        return self.dt
+
+    def validate(self):
+        """On-device checker + the round trip; then the reference hashes when this exact input has a golden entry."""
+        ok = self.ctx.validate_sa(self.d_text, self.n, self.d_sa) == 0
+        if self.d_inv is not None:
+            ok = ok and bool(self.torch.equal(self.d_inv, self.d_text[:self.n]))          # config 4: the round trip restores the text
+        against = "on-device checker (adjacent-pair order + permutation)" + (" + round trip" if self.d_inv is not None else "")
+        e = golden_entry(self.workload, self.seed, self.n)
+        if e is not None:
+            try:
+                gok, checked = check_golden(e, self.d_sa, self.d_bwt, self.sentinel, self.d_lcp)
+                ok = ok and gok
+                against = "reference hash (FNV-1a-64 of " + ", ".join(checked) + "; tests/golden/golden_full.json) + " + against
+            except Exception as ex:  # noqa: BLE001
+                against += f" (reference hash not checked: {ex})"
+        return bool(ok), against
+
+
+def kernel_table(phases, K, n, workload, ops, ibwt_us):
+    """Per-launch device time (HIP events on the engine's stream) and ALGORITHMIC bytes."""
+    m = phases[-1].m
+    avg = lambda f: sum(getattr(p, f) for p in phases) / K   # noqa: E731
+    refilled = sum(p.gathered_records for p in phases) / K
+    # two-stage build (text-like inputs): the sort phases below handle the B* suffixes only; the others are induced
+    mstar = phases[-1].bstar_suffixes
+    two_stage = mstar > 0
+    ms_ = mstar if two_stage else m          # suffixes the sort phases handle
+    kern = {
+        "k_hist16": (avg("hist16_ms"), n),
+        "k_scatter0": (avg("scatter0_ms"), n + 8 * ms_),
+        "k_partition(level 1)": (avg("scatter1_ms"), 16 * ms_),
+        ("bucket sort (LDS sorts of the two-byte buckets)" if workload == "random" else "round-0 LDS sorts (k_sort_mid/k_sort_tiny/bucket sort)"): (avg("bucket_sort_ms"), 12 * ms_),
+    }
+    if two_stage:
+        rows_read = phases[-1].b_suffixes + n        # pass B reads the B rows, pass A every row
+        fetches = mstar + (n - mstar) / 3            # one 4-byte text fetch per B* suffix and per third induced suffix
+        if os.environ.get("MSUFSORT_HIP_IND_CLASSIC"):
+            # three kernels per level: rows read twice (count + scatter: 4 B index + 4 B characters each time)
+            kern["induction (k_ind_count + k_ind_scan + k_ind_scatter)"] = (avg("other_ms"), int(16 * rows_read + 8 * (n - mstar) + 4 * fetches))
+        else:
+            # single-pass levels: every source row read once (4 B index + 4 B characters), every induced row written once (8 B)
+            kern["induction (k_ind_fused + k_ind_small)"] = (avg("other_ms"), int(8 * rows_read + 8 * (n - mstar) + 4 * fetches))
+    if refilled > 0.01 * m:
+        # SURVEY 8(d): per still-tied suffix and key round: index read (4) + key (8) + index written (4)
+        kern["key rounds (k_refill + k_partition levels + LDS sorts)"] = (avg("refine_ms"), int(16 * refilled))
+    if "ibwt" in ops and ibwt_us[0]:
+        kern["k_ibwt_walk"] = (ibwt_us[0] / K / 1e3, 9 * n)       # n hops x 8 B entry + n bytes written (SURVEY 8(d))
+    return kern, avg, two_stage, mstar
+
+
+def roofline_of(kern, n, workload, single_gpu):
+    dom = max(kern, key=lambda k: kern[k][0])
+    dms, dbytes = kern[dom]
+    ach = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+    traffic, traffic_source = None, None
+    try:   # HBM bytes per launch: NOT measured in this run - copied from the committed PMC passes of the same command
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pt.get("n") == n and single_gpu and workload == pt.get("workload", "random") and dom in pt["kernels"]:
+            traffic = pt["kernels"][dom]
+            traffic_source = pt.get("source", "profiles/pmc_traffic.json") + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not measured in this run)"
+    except Exception:  # noqa: BLE001
+        traffic = None
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "launch_ms": round(dms, 4), "algorithmic_bytes": int(dbytes)}
+
+
+def kernels_json(kern):
+    out = {k: {"ms": round(v[0], 4), "algorithmic_GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None,
+               "frac_of_hbm_peak": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[0] > 0 else None}
+           for k, v in kern.items()}
+    # a fraction above 1 means a kernel is billed for bytes it did not move in the time it is billed for: refuse to print it
+    bad = [k for k, v in out.items() if v["frac_of_hbm_peak"] is not None and v["frac_of_hbm_peak"] > 1.0]
+    assert not bad, f"algorithmic bandwidth above the HBM peak for {bad}: the phase timers do not cover these kernels"
+    return out
+
+
+def config_lines(M, torch, ctx, dev, steps, no_cpu):
+    """BASELINE configs 3 and 4 under the same clock as the headline: text, 2^30 - 1 bytes (the reference's ceiling): SA,
+    forward BWT as one call, inverse BWT, LCP - all resident in HBM; reference hashes from tests/golden/golden_full.json."""
+    n, seed = (1 << 30) - 1, 3
+    ops = ["sa", "fbwt", "ibwt", "lcp"]
+    S = Single(M, torch, ctx, dev, "text", seed, n, ops)
+    S.run(steps, 1)
+    ok, against = S.validate()
+    K = steps
+    kern, avg, two_stage, mstar = kernel_table(S.phases, K, n, "text", ops, S.ibwt_us)
+    kj = kernels_json(kern)
+    sa_ms, fb_ms, ib_ms, lcp_ms = (S.op_ms[k] / K for k in ops)
+    sa_kern = {k: v for k, v in kern.items() if k != "k_ibwt_walk"}
+    cfg3 = {"workload": f"text (seed {seed}), n={n}: suffix array, then the forward BWT as one call", "valid": ok, "valid_against": against,
+            "sa_ms": round(sa_ms, 3), "forward_bwt_ms": round(fb_ms, 3), "sa_MBps": round(n / sa_ms / 1e3, 1), "forward_bwt_MBps": round(n / fb_ms / 1e3, 1),
+            "steps": K, "roofline": roofline_of(sa_kern, n, "text", True), "kernels": {k: kj[k] for k in sa_kern},
+            "sa_device_ms": round(avg("total_ms"), 3)}
+    if two_stage:
+        cfg3["two_stage"] = {"bstar_suffixes": int(mstar), "induced_suffixes": int(n - mstar), "front_ms": round(avg("front_ms"), 3),
+                             "induction_ms": round(avg("other_ms"), 3), "level_launches": int(S.phases[-1].induction_launches)}
+    cfg3["fallbacks"] = int(sum(p.fallbacks & 1 for p in S.phases))
+    walk_ms = S.ibwt_us[0] / K / 1e3
+    cfg4 = {"workload": f"forward BWT of that text -> inverse BWT, n={n}, output compared with the text on the device", "valid": ok,
+            "inverse_bwt_ms": round(ib_ms, 3), "inverse_bwt_MBps": round(n / ib_ms / 1e3, 1), "round_trip_ms": round(fb_ms + ib_ms, 3), "steps": K,
+            "device_total_ms": round(S.ibwt_us[1] / K / 1e3, 3),
+            "roofline": {"bound": "hbm", "kernel": "k_ibwt_walk", "achieved": round(9 * n / (walk_ms * 1e-3) / 1e9, 1) if walk_ms else None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(9 * n / (walk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if walk_ms else None, "traffic": None,
+                         "launch_ms": round(walk_ms, 3), "algorithmic_bytes": 9 * n,
+                         "line_GBps": round(128 * n / (walk_ms * 1e-3) / 1e9, 1) if walk_ms else None},
+            "lcp_ms": round(lcp_ms, 3)}
+    if not no_cpu:
+        try:
+            cfg3["cpu_baseline"] = cpu_baseline(1 << 28, seed, "text", "fbwt", n)
+        except Exception as e:  # noqa: BLE001
+            cfg3["cpu_baseline"] = {"error": str(e)}
+    del S
+    torch.cuda.empty_cache()
+    return {"cfg3": cfg3, "cfg4": cfg4}, ok
 
 
 def main():
@@ -63,11 +318,17 @@ def main():
     ap.add_argument("--workload", default="random")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--op", default="sa")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 28)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="bytes of the stream the CPU baseline sorts (0: the whole input)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="headline only: skip the config 3 / 4 lines")
     args = ap.parse_args()
 
-    import numpy as np
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}", file=sys.stderr)
+        return 2
+
     import torch
 
     import msufsort_amd as M
@@ -77,66 +338,93 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MSUFSORT_BENCH_BACKEND", "nccl")     # "nccl" IS RCCL on ROCm
-        if os.environ.get("MSUFSORT_BENCH_ONE_DEVICE"):                # test hook: all ranks share GPU 0
-            local = 0
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    dev = torch.device("cuda", local)
+    ops = [x for x in args.op.split(",") if x]
+    assert ops and ops[0] == "sa" and set(ops) <= {"sa", "bwt", "fbwt", "ibwt", "lcp"} and (world == 1 or ops == ["sa"]), "--op sa[,bwt][,fbwt][,ibwt][,lcp] (N > 1: sa only)"
     n = args.size
+    headline = args.workload == "random" and ops == ["sa"]
+    metric = "MB/s input for SA build on 1 GiB random bytes" if headline else f"MB/s input for {'+'.join(ops)} on {args.workload}"
+
+    if world == 1:
+        dev = torch.device("cuda", local)
+        ctx = M.DeviceContext(local, n)
+        S = Single(M, torch, ctx, dev, args.workload, args.seed, n, ops)
+        dt = S.run(args.steps, args.warmup)
+        ok, against = S.validate()
+        K = args.steps
+        kern, avg, two_stage, mstar = kernel_table(S.phases, K, n, args.workload, ops, S.ibwt_us)
+        radix_ms = kern["k_hist16"][0] + kern["k_scatter0"][0]
+        out = {
+            "metric": metric, "value": round(n / (dt / K) / 1e6, 2), "unit": "MB/s",
+            "n_gpus": 1, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "valid": ok, "valid_against": against,
+            "config": {"workload": f"{args.workload} bytes (splitmix64 seed {args.seed}), n={n}, int32 SA, one GPU", "n": n, "index": "int32", "ops": ops,
+                       "allgatherv": None, "rccl_ranks": None, "pipelined": False},
+            "roofline": roofline_of(kern, n, args.workload, True),
+            "radix_pass": {"read_bytes": 2 * n, "ms": round(radix_ms, 4),
+                           "read_frac_of_hbm_peak": round((2 * n / (radix_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4) if radix_ms > 0 else None,
+                           "note": "SURVEY 8(d) literal definition: 2n read bytes over k_hist16 + k_scatter0; the scatter is write bound (n + 8m bytes), see kernels"},
+            "end_to_end": {"compulsory_bytes": 5 * n + 4, "frac_of_hbm_peak": round(((5 * n + 4) / (dt / K) / 1e9) / HBM_PEAK_GBS, 5)},
+            "kernels": kernels_json(kern),
+            "phases_ms": {k: round(v[0], 4) for k, v in kern.items()} | {"refine": round(avg("refine_ms"), 4), "device_total": round(avg("total_ms"), 4)},
+            "fallbacks": int(sum(p.fallbacks & 1 for p in S.phases)),
+        }
+        if two_stage:
+            out["two_stage"] = {"bstar_suffixes": int(mstar), "induced_suffixes": int(n - mstar), "front_ms": round(avg("front_ms"), 3),
+                                "induction_ms": round(avg("other_ms"), 3), "level_launches": int(S.phases[-1].induction_launches)}
+        if len(ops) > 1:
+            out["ops_ms"] = {k: round(v / K, 3) for k, v in S.op_ms.items()}
+            if "ibwt" in ops:
+                out["ibwt"] = {"walk_ms": round(S.ibwt_us[0] / K / 1e3, 3), "device_total_ms": round(S.ibwt_us[1] / K / 1e3, 3),
+                               "walk_sector_GBps": round(64 * n / (S.ibwt_us[0] / K / 1e6) / 1e9, 1) if S.ibwt_us[0] else None}
+        del S
+        torch.cuda.empty_cache()
+        if headline and n == (1 << 30) - 1 and not args.no_configs:
+            try:
+                out["configs"], cok = config_lines(M, torch, ctx, dev, 3, args.no_cpu)
+                ok = ok and cok
+            except Exception as e:  # noqa: BLE001
+                out["configs"] = {"error": repr(e)}
+        if not args.no_cpu:
+            try:
+                sample = args.cpu_sample or n
+                out["cpu_baseline"] = cpu_baseline(min(sample, n), args.seed, args.workload, "sa", n)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out), flush=True)
+        return 0 if ok else 1
+
+    # ---------------------------------------------------------------- N > 1: one rank per GPU
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("MSUFSORT_BENCH_BACKEND", "nccl")     # "nccl" IS RCCL on ROCm
+    if os.environ.get("MSUFSORT_BENCH_ONE_DEVICE"):                # test hook: all ranks share GPU 0
+        local = 0
+    torch.cuda.set_device(local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    dev = torch.device("cuda", local)
     t = gen.GENERATORS[args.workload](n, args.seed)
     d_text = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
     d_text[:n] = torch.from_numpy(t).to(dev)
+    del t
     d_sa = torch.empty(n + 1, dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)          # the engine works on its own HIP stream: the upload must have landed
-    ctx = M.DeviceContext(local, n if world == 1 else n // world + n // (8 * world) + (1 << 20))     # workspace: my shard's suffixes
+    ctx = M.DeviceContext(local, n // world + n // (8 * world) + (1 << 20))     # workspace: my shard's suffixes
 
-    bounds = ctx.shard_bounds(d_text, n, world) if world > 1 else None
-    exchange = mdist.select_exchange(dist, dev) if world > 1 else None
-    d_grp = torch.empty(n + 1, dtype=torch.int32, device=dev) if world > 1 else None
-    # N > 1: two output buffers, so the all-gatherv of build k can travel while build k+1 is being sorted
+    bounds = ctx.shard_bounds(d_text, n, world)
+    exchange = mdist.select_exchange(dist, dev)
+    d_grp = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    # two output buffers, so the all-gatherv of build k can travel while build k+1 is being sorted
     # (every build and every exchange is complete before the closing barrier of the timed region)
-    sa_bufs = [d_sa, torch.empty(n + 1, dtype=torch.int32, device=dev)] if world > 1 else [d_sa]
+    sa_bufs = [d_sa, torch.empty(n + 1, dtype=torch.int32, device=dev)]
     pending = {"works": [], "buf": None, "last": d_sa, "k": 0}
-    shard_state = mdist.ShardState() if world > 1 else None
-
-    ops = [x for x in args.op.split(",") if x]
-    assert ops and ops[0] == "sa" and set(ops) <= {"sa", "bwt", "fbwt", "ibwt", "lcp"} and (world == 1 or ops == ["sa"]), "--op sa[,bwt][,fbwt][,ibwt][,lcp] (N > 1: sa only)"
-    d_bwt = torch.empty(n, dtype=torch.uint8, device=dev) if ("bwt" in ops or "ibwt" in ops or "fbwt" in ops) else None
-    d_inv = torch.empty(n, dtype=torch.uint8, device=dev) if "ibwt" in ops else None
-    d_lcp = torch.empty(n, dtype=torch.int32, device=dev) if "lcp" in ops else None
-    op_ms = {k: 0.0 for k in ops}
-    ibwt_us = [0, 0]
-
-    def timed(name, f):
-        t0 = time.perf_counter()
-        r = f()
-        op_ms[name] += (time.perf_counter() - t0) * 1e3
-        return r
+    shard_state = mdist.ShardState()
+    phases = []
 
     def step():
-        if world == 1:
-            timed("sa", lambda: ctx.make_sa(d_text, n, d_sa))
-            phases.append(ctx.timings())
-            sent = None
-            if "fbwt" in ops:      # the forward transform as ONE call (own suffix-array build + BWT, reference cpp:1771-1817)
-                sent = timed("fbwt", lambda: ctx.forward_bwt(d_text, n, d_bwt))
-            elif d_bwt is not None:
-                sent = timed("bwt" if "bwt" in ops else "ibwt", lambda: ctx.bwt_from_sa(d_text, n, d_sa, d_bwt))
-            if "ibwt" in ops:
-                timed("ibwt", lambda: ctx.inverse_bwt(d_bwt, n, sent, d_inv))
-                tmi = ctx.timings()
-                ibwt_us[0] += tmi.reserved[3]; ibwt_us[1] += tmi.reserved[4]
-            if "lcp" in ops:
-                timed("lcp", lambda: ctx.lcp(d_text, n, d_sa, d_lcp))
-            return
         out = sa_bufs[pending["k"] & 1]
         pending["k"] += 1
         works = mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp_full=d_grp, overlap=True, state=shard_state)
@@ -148,145 +436,85 @@ def main():
         pending["works"] = []
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize(dev)
 
-    phases = []
     for _ in range(args.warmup):
         step()
     drain()
-    phases.clear()
-    for k in op_ms:
-        op_ms[k] = 0.0
-    ibwt_us[0] = ibwt_us[1] = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if world > 1:
-            phases.append(ctx.timings())
+        phases.append(ctx.timings())
     drain()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        x = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(x, op=dist.ReduceOp.MAX)
-        dt = float(x.item())
+    x = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(x, op=dist.ReduceOp.MAX)
+    dt = float(x.item())
 
-    # N > 1: the timed loop pipelines build k+1 over the exchange of build k (throughput).  The latency of ONE build -
+    # The timed loop pipelines build k+1 over the exchange of build k (throughput).  The latency of ONE build -
     # sort, then its exchange, nothing overlapped - is measured separately, outside the timed region.
-    latency = None
-    if world > 1:
-        lat, exc = [], []
-        for _ in range(2):
-            barrier()
-            a = time.perf_counter()
-            w = mdist.build_sa_sharded(ctx, d_text, n, sa_bufs[0], rank, world, dist, bounds, d_grp_full=d_grp, overlap=True, state=shard_state)
-            torch.cuda.synchronize(dev)
-            b = time.perf_counter()
-            mdist.wait_all(w, sa_bufs[0])
-            barrier()
-            c_ = time.perf_counter()
-            lat.append((c_ - a) * 1e3); exc.append((c_ - b) * 1e3)
-        x = torch.tensor([min(lat), min(exc)], dtype=torch.float64, device=dev)
-        dist.all_reduce(x, op=dist.ReduceOp.MAX)
-        latency = {"latency_ms": round(float(x[0]), 3), "exchange_ms": round(float(x[1]), 3)}
-        pending["last"] = sa_bufs[0]
+    lat, exc = [], []
+    for _ in range(2):
+        barrier()
+        a = time.perf_counter()
+        w = mdist.build_sa_sharded(ctx, d_text, n, sa_bufs[0], rank, world, dist, bounds, d_grp_full=d_grp, overlap=True, state=shard_state)
+        torch.cuda.synchronize(dev)
+        b = time.perf_counter()
+        mdist.wait_all(w, sa_bufs[0])
+        barrier()
+        c_ = time.perf_counter()
+        lat.append((c_ - a) * 1e3); exc.append((c_ - b) * 1e3)
+    x = torch.tensor([min(lat), min(exc), ctx.timings().total_ms], dtype=torch.float64, device=dev)
+    per = [torch.zeros_like(x) for _ in range(world)]
+    dist.all_gather(per, x)                       # per-rank figures: is one shard slower than the others?
+    dist.all_reduce(x, op=dist.ReduceOp.MAX)
+    latency = {"latency_ms": round(float(x[0]), 3), "exchange_ms": round(float(x[1]), 3), "sort_ms": round(float(x[2]), 3),
+               "per_rank": {"latency_ms": [round(float(q[0]), 3) for q in per], "exchange_ms": [round(float(q[1]), 3) for q in per],
+                            "sort_ms": [round(float(q[2]), 3) for q in per],
+                            "rows": [int(bounds[g + 1] - bounds[g]) for g in range(world)]}}
+    pending["last"] = sa_bufs[0]
 
     ok = True
     if rank == 0:
         ok = ctx.validate_sa(d_text, n, pending["last"]) == 0     # on-device checker on the assembled array
-        if d_inv is not None:
-            ok = ok and bool(torch.equal(d_inv, d_text[:n]))          # config 4: the round trip restores the text
-
-    if rank == 0:
-        K = args.steps
-        ms_per_step = dt / K * 1e3
-        m = phases[-1].m
-        avg = lambda f: sum(getattr(p, f) for p in phases) / K   # noqa: E731
-        # per-launch device time (HIP events on the engine's stream) and ALGORITHMIC bytes
-        refilled = sum(p.reserved[2] for p in phases) / K
-        # two-stage build (text-like inputs): the sort phases below handle the B* suffixes only; the others are induced
-        mstar = phases[-1].reserved[5]
-        two_stage = mstar > 0
-        ms_ = mstar if two_stage else m          # suffixes the sort phases handle
-        kern = {
-            "k_hist16": (avg("hist16_ms"), n),
-            "k_scatter0": (avg("scatter0_ms"), n + 8 * ms_),
-            "k_partition(level 1)": (avg("scatter1_ms"), 16 * ms_),
-            ("k_sort_fast2(bucket sort)" if args.workload == "random" else "round-0 LDS sorts (k_sort_mid/k_sort_tiny/k_sort_fast2)"): (avg("bucket_sort_ms"), 12 * ms_),
-        }
-        if two_stage:
-            # rows read twice (count + scatter: 4 B index + 4 B characters), every induced row written once (8 B),
-            # one 4-byte text fetch per B* suffix and per third induced suffix
-            rows_read = phases[-1].reserved[7] + n
-            kern["induction (k_ind_count + k_ind_scan + k_ind_scatter)"] = (avg("other_ms"), int(16 * rows_read + 8 * (n - mstar) + 4 * (mstar + (n - mstar) / 3)))
-        if refilled > 0.01 * m:
-            # per still-tied suffix and key round: index read (4) + key (8) + index written (4)
-            kern["key rounds (k_refill + k_partition levels + LDS sorts)"] = (avg("refine_ms"), int(16 * refilled))
-        if "ibwt" in ops and ibwt_us[0]:
-            # n hops x 8 B entry + n bytes written
-            kern["k_ibwt_walk"] = (ibwt_us[0] / K / 1e3, 9 * n)
-        dom = max(kern, key=lambda k: kern[k][0])
-        dms, dbytes = kern[dom]
-        ach = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
-        traffic, traffic_source = None, None
-        try:   # HBM bytes per launch: NOT measured in this run - copied from the committed PMC passes of the same command
-            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt.get("n") == n and world == 1 and args.workload == "random":
-                traffic = pt["kernels"].get(dom)
-                traffic_source = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not measured in this run)"
-        except Exception:  # noqa: BLE001
-            traffic = None
-        radix_ms = kern["k_hist16"][0] + kern["k_scatter0"][0]
-        out = {
-            "metric": "MB/s input for SA build on 1 GiB random bytes" if (args.workload == "random" and ops == ["sa"]) else f"MB/s input for {'+'.join(ops)} on {args.workload}",
-            "value": round(n / (dt / K) / 1e6, 2),
-            "unit": "MB/s",
-            "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "valid": bool(ok),
-            "config": {"workload": f"{args.workload} bytes (splitmix64 seed {args.seed}), n={n}, int32 SA, 16-bit-key range sharding x{world}",
-                       "n": n, "index": "int32", "ops": ops, "allgatherv": exchange, "rccl_ranks": world if world > 1 else None,
-                       "pipelined": world > 1},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "launch_ms": round(dms, 4), "algorithmic_bytes": int(dbytes)},
-            "radix_pass": {"read_bytes": 2 * n, "ms": round(radix_ms, 4),
-                           "read_frac_of_hbm_peak": round((2 * n / (radix_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4) if radix_ms > 0 else None},
-            "end_to_end": {"compulsory_bytes": 5 * n + 4, "frac_of_hbm_peak": round(((5 * n + 4) / (dt / K) / 1e9) / HBM_PEAK_GBS, 5)},
-            "kernels": {k: {"ms": round(v[0], 4), "algorithmic_GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None,
-                            "frac_of_hbm_peak": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[0] > 0 else None}
-                        for k, v in kern.items()},
-            "phases_ms": {k: round(v[0], 4) for k, v in kern.items()} | {"refine": round(avg("refine_ms"), 4), "device_total": round(avg("total_ms"), 4)},
-        }
-        if two_stage:
-            out["two_stage"] = {"bstar_suffixes": int(mstar), "induced_suffixes": int(n - mstar), "induction_ms": round(avg("other_ms"), 3),
-                                "level_launches": int(phases[-1].reserved[6])}
-        if len(ops) > 1:
-            out["ops_ms"] = {k: round(v / K, 3) for k, v in op_ms.items()}
-            if "ibwt" in ops:
-                out["ibwt"] = {"walk_ms": round(ibwt_us[0] / K / 1e3, 3), "device_total_ms": round(ibwt_us[1] / K / 1e3, 3),
-                               "walk_sector_GBps": round(64 * n / (ibwt_us[0] / K / 1e6) / 1e9, 1) if ibwt_us[0] else None}
-        if latency:
-            out.update(latency)           # one build incl. its exchange, nothing overlapped (ms_per_step above is the pipelined rate)
-        if world > 1 and shard_state.stats:
-            out["doubling"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in shard_state.stats.items()}
-        if not args.no_cpu and world == 1:
+        against = "on-device checker (adjacent-pair order + permutation) on the assembled array"
+        e = golden_entry(args.workload, args.seed, n)
+        if e is not None:
             try:
-                out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.seed, args.workload)
-            except Exception as e:  # noqa: BLE001
-                out["cpu_baseline"] = {"error": str(e)}
+                gok, _ = check_golden(e, pending["last"])
+                ok = ok and gok
+                against = "reference hash (FNV-1a-64 of sa; tests/golden/golden_full.json) + " + against
+            except Exception as ex:  # noqa: BLE001
+                against += f" (reference hash not checked: {ex})"
+        K = args.steps
+        kern, avg, two_stage, mstar = kernel_table(phases, K, n, args.workload, ops, [0, 0])
+        # a rank reads the whole text (hist + scatter) but sorts only its shard: bill the record passes with the shard's suffixes
+        my = int(bounds[1] - bounds[0])
+        kern = {"k_hist16": kern["k_hist16"], "k_scatter0": (kern["k_scatter0"][0], n + 8 * my),
+                "k_partition(level 1)": (kern["k_partition(level 1)"][0], 16 * my),
+                "bucket sort (rank 0's shard)": (avg("bucket_sort_ms"), 12 * my)} | {k: v for k, v in kern.items() if k.startswith("key rounds")}
+        out = {
+            "metric": metric, "value": round(n / (dt / K) / 1e6, 2), "unit": "MB/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "valid": bool(ok), "valid_against": against,
+            "config": {"workload": f"{args.workload} bytes (splitmix64 seed {args.seed}), n={n}, int32 SA, 4-byte-prefix range sharding x{world}",
+                       "n": n, "index": "int32", "ops": ops, "allgatherv": exchange, "rccl_ranks": world, "pipelined": True,
+                       "backend": backend},
+            "roofline": roofline_of(kern, n, args.workload, False),
+            "kernels": kernels_json(kern),
+            "phases_ms": {k: round(v[0], 4) for k, v in kern.items()} | {"refine": round(avg("refine_ms"), 4), "device_total": round(avg("total_ms"), 4)},
+            "allgatherv_bytes_per_rank": int(4 * (n + 1) * (world - 1) / world),
+        }
+        out.update(latency)           # one build incl. its exchange, nothing overlapped (ms_per_step above is the pipelined rate)
+        if shard_state.stats:
+            out["doubling"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in shard_state.stats.items()}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
     return 0 if ok else 1
 
 

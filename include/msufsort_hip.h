@@ -77,12 +77,21 @@ typedef struct msufsort_hip_timings {
     int32_t rounds;            /* rounds after round 0 */
     int32_t doubling_rounds;
     int64_t unresolved_after_round0;
-    int64_t reserved[8];       /* [0] depth at which a sharded build stopped its key rounds, [1] logical shards of the last build,
-                                  [2] records whose key was gathered, summed over the rounds after round 0 (each: 4 B index read,
-                                  one 64 B sector of text or ranks, 8 B record written, 4 B row written by the sorts),
-                                  [3] inverse BWT: microseconds of the chain walk (k_ibwt_walk), [4] of the whole inverse,
-                                  two-stage builds (B* sort + induction; the sort phases above then cover the B* suffixes only,
-                                  other_ms is the induction): [5] B* suffixes, [6] level launches, [7] B suffixes */
+    int64_t stop_depth;        /* depth (bytes every remaining tie group shares) at which a sharded build stopped its key rounds */
+    int64_t logical_shards;    /* logical shards of the last build */
+    int64_t gathered_records;  /* records whose key was gathered, summed over the rounds after round 0 (each: 4 B index read,
+                                  one 64 B sector of text or ranks, 8 B record written, 4 B row written by the sorts) */
+    int64_t ibwt_walk_us;      /* inverse BWT: microseconds of the chain walk (k_ibwt_walk) ... */
+    int64_t ibwt_total_us;     /* ... and of the whole inverse */
+    /* two-stage builds (B* sort + induction; the sort phases above then cover the B* suffixes only, other_ms is the induction) */
+    int64_t bstar_suffixes;    /* 0: the last build sorted all suffixes */
+    int64_t induction_launches;/* level launches of the two passes */
+    int64_t b_suffixes;        /* B-type suffixes (rows pass B reads) */
+    double front_ms;           /* two-stage builds: typing + histograms before stage 1 (k_hist16, k_types, k_maxrun, k_hist16<2>);
+                                  hist16_ms above is then the k_hist16 launch inside it */
+    int64_t fallbacks;         /* bit 0: a two-stage attempt was abandoned and the sort-all path ran (deep ties / look-back time-out /
+                                  policy decline after the front end); bits 8..: reason code of the abandon */
+    int64_t reserved[6];
 } msufsort_hip_timings;
 
 int msufsort_hip_device_count(void);

@@ -26,7 +26,10 @@ class Timings(C.Structure):
                 ("scatter1_ms", C.c_double), ("bucket_sort_ms", C.c_double), ("refine_ms", C.c_double),
                 ("other_ms", C.c_double), ("n", C.c_int64), ("m", C.c_int64), ("rounds", C.c_int32),
                 ("doubling_rounds", C.c_int32), ("unresolved_after_round0", C.c_int64),
-                ("reserved", C.c_int64 * 8)]
+                ("stop_depth", C.c_int64), ("logical_shards", C.c_int64), ("gathered_records", C.c_int64),
+                ("ibwt_walk_us", C.c_int64), ("ibwt_total_us", C.c_int64), ("bstar_suffixes", C.c_int64),
+                ("induction_launches", C.c_int64), ("b_suffixes", C.c_int64), ("front_ms", C.c_double), ("fallbacks", C.c_int64),
+                ("reserved", C.c_int64 * 6)]
 
 
 # every symbol include/msufsort_hip.h declares (checked by tests/test_cabi.py)

@@ -113,7 +113,7 @@ struct msufsort_hip_ctx {
     u64 cap_m = 0;               // records capacity
     u64 cap_for_m = 0;           // largest m the workspace was sized for
     msufsort_hip_timings tm{};
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int sync_debug = 0;          // MSUFSORT_HIP_SYNC_DEBUG, read once when the context is created
 
     template <bool W> int set_mid_attrs()
@@ -907,7 +907,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
                 HIP_TRY(hipGetLastError());
                 float ms_ = 0;
                 (void)hipEventElapsedTime(&ms_, c->ev[0], c->ev[5]); tm.total_ms = ms_;
-                tm.reserved[0] = (int64_t)depth;
+                tm.stop_depth = (int64_t)depth;
                 return MSUFSORT_HIP_UNRESOLVED;
             }
             if constexpr (!W) {
@@ -945,7 +945,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         DBG("k_refill");
         if (R.mode == MODE_TEXT) depth += ks.cpk; else { depth *= 2; tm.doubling_rounds++; }
         tm.rounds++;
-        tm.reserved[2] += (int64_t)(actP + actS);          // records whose next key was gathered (roofline of the key rounds)
+        tm.gathered_records += (int64_t)(actP + actS);          // records whose next key was gathered (roofline of the key rounds)
     }
     finish_groups();
     HIP_TRY(hipEventRecord(c->ev[5], st));
@@ -1155,7 +1155,7 @@ int build_logical(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* 
         acc.bucket_sort_ms += c->tm.bucket_sort_ms; acc.refine_ms += c->tm.refine_ms; acc.rounds = std::max(acc.rounds, c->tm.rounds);
         acc.unresolved_after_round0 += c->tm.unresolved_after_round0;
         if (r == MSUFSORT_HIP_UNRESOLVED) {
-            const u64 d = (u64)c->tm.reserved[0];
+            const u64 d = (u64)c->tm.stop_depth;
             if (any && d != depth) { set_error("shards stopped at different depths (%llu, %llu)", (unsigned long long)depth, (unsigned long long)d); return MSUFSORT_HIP_ERR_INTERNAL; }
             any = true; depth = d;
         }
@@ -1213,8 +1213,8 @@ int build_logical(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* 
     acc.n = (int64_t)n; acc.m = (int64_t)(n - z);
     acc.doubling_rounds = steps;
     acc.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-    acc.reserved[0] = (int64_t)depth;
-    acc.reserved[1] = G;
+    acc.stop_depth = (int64_t)depth;
+    acc.logical_shards = G;
     acc.other_ms = dbl_ms;              // wall time of the distributed doubling phase
     c->tm = acc;
     return MSUFSORT_HIP_OK;
@@ -1414,11 +1414,14 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     int two_stage = o.two_stage;
     if (const char* e = getenv("MSUFSORT_HIP_TWO_STAGE")) two_stage = atoi(e);
     bool hist_done = false;
+    int why = 0;                 // why a two-stage attempt was handed back (IND_WHY_*; 0: not tried / nothing spent)
     if (two_stage > 0 || (two_stage == 0 && (u64)n >= (48ull << 20) && tail_values <= 128u)) {
-        const int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, two_stage > 0, &hist_done);
+        const int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, two_stage > 0, &hist_done, &why);
         if (r != MSUFSORT_HIP_UNRESOLVED) return r;
     }
-    return build_sa<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 1ull << 32, z, true, &o, hist_done);
+    const int r = build_sa<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 1ull << 32, z, true, &o, hist_done);
+    if (why) c->tm.fallbacks = 1 | ((int64_t)why << 8);      // the attempt cost device time that total_ms of the rebuild does not show
+    return r;
 }
 
 int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t n_shards, int64_t* bounds)
@@ -1492,7 +1495,7 @@ int msufsort_hip_make_sa_shard_groups_dev(msufsort_hip_ctx* c, uint8_t* d_text, 
 {
     if (!d_grp_slice_out) return MSUFSORT_HIP_ERR_BAD_ARG;
     const int r = make_sa_shard_impl<false>(c, d_text, n, reinterpret_cast<u32*>(d_slice_out), d_grp_slice_out, slice_capacity, slice_lo, slice_hi, opts);
-    if (depth_out) *depth_out = (r == MSUFSORT_HIP_UNRESOLVED) ? c->tm.reserved[0] : 0;
+    if (depth_out) *depth_out = (r == MSUFSORT_HIP_UNRESOLVED) ? c->tm.stop_depth : 0;
     return r;
 }
 
@@ -1502,7 +1505,7 @@ int msufsort_hip_make_sa_shard_groups_i64_dev(msufsort_hip_ctx* c, uint8_t* d_te
 {
     if (!d_grp_slice_out) return MSUFSORT_HIP_ERR_BAD_ARG;
     const int r = make_sa_shard_impl<true>(c, d_text, n, reinterpret_cast<u64*>(d_slice_out), d_grp_slice_out, slice_capacity, slice_lo, slice_hi, opts);
-    if (depth_out) *depth_out = (r == MSUFSORT_HIP_UNRESOLVED) ? c->tm.reserved[0] : 0;
+    if (depth_out) *depth_out = (r == MSUFSORT_HIP_UNRESOLVED) ? c->tm.stop_depth : 0;
     return r;
 }
 

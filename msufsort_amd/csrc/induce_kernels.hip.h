@@ -180,7 +180,8 @@ struct IndState {
     u32 cur[256];           // pass B: next free row + 1 (right end, exclusive) of sub-bucket (c0, current c1); pass A: next free row of A(c)
     u32 rng[2][2];          // source rows [lo, hi) of the level being processed / of the next level
     u32 flags;
-    u32 pad[3];
+    u32 spin_limit;         // bound of the look-back spins (host: 2^22; MSUFSORT_HIP_IND_SPIN shrinks it for the time-out test)
+    u32 pad[2];
     u32 ticket[IND_MAX_LEVELS];   // single-pass levels: next tile to hand out, one counter per level launch (zeroed with the state)
 };
 
@@ -190,6 +191,7 @@ struct IndState {
 // "nothing yet"); [47:0] the count
 #define IND_ST_AGG 1ull
 #define IND_ST_INC 2ull
+__device__ __forceinline__ bool ind_failed(const IndState* st) { return (__hip_atomic_load(&st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & IND_FLAG_LOOKBACK) != 0; }
 __device__ __forceinline__ u64 ind_status(u64 flag, u32 epoch, u64 value) { return (flag << 62) | ((u64)(epoch & 0x3fffu) << 48) | value; }
 
 // sorted B* suffixes -> the left ends of their sub-buckets; one workgroup per non-empty (c0,c1)
@@ -372,6 +374,7 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const u32 cnt = hi - lo;
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    __shared__ u32 s_fail;
     __shared__ u8 s_codes[256];            // dense number of every byte value (255: not in use; all 256 in use: the identity)
     __syncthreads();
     s_codes[t] = (u8)my_code;
@@ -471,6 +474,7 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
                 const u32 code = cbase + (t >> 3);
                 const bool active = code < tb.nsym;
                 u32 excl = 0, pbase = tile, spins = 0;
+                const u32 spin_limit = st->spin_limit;
                 bool done = !active;
                 for (;;) {
                     const bool in = !done && sub < pbase;
@@ -484,7 +488,7 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
                     u32 part = (!blocked && in && (int)sub <= f) ? (u32)v : 0u;
                     part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
                     if (!done && !blocked) { excl += part; if (gi) done = true; else pbase -= 8u; }
-                    if (!done && blocked && ++spins > (1u << 22)) { atomicOr(&st->flags, IND_FLAG_LOOKBACK); done = true; }
+                    if (!done && blocked && ++spins > spin_limit) { atomicOr(&st->flags, IND_FLAG_LOOKBACK); __threadfence(); done = true; }
                     if (__ballot(!done) == 0) break;
                     if (__ballot(blocked)) __builtin_amdgcn_s_sleep(1);
                 }
@@ -506,7 +510,12 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
             }
         }
     }
+    // A look-back that timed out (this tile's or an earlier one's) leaves `excl` short: nothing computed from it may be written.
+    // The flag is sticky - every later level and bucket returns at once (ind_failed) and the host rebuilds with the sort-all path.
+    // (one thread reads it for the workgroup: the decision must be uniform, the caller's loop has barriers)
+    if (FUSED && t == 0) s_fail = ind_failed(st) ? 1u : 0u;
     __syncthreads();
+    if (FUSED && s_fail) return;
 #pragma unroll
     for (int i = 0; i < IND_ITEMS; ++i)
         if (bin[i] < 256u) {
@@ -541,6 +550,7 @@ __global__ __launch_bounds__(256) void k_ind_fused(IndState* st, IndLevel lv, u3
     __shared__ u32 s_sub[257];
     __shared__ u32 s_tile;
     const u32 t = threadIdx.x;
+    if (ind_failed(st)) return;          // an earlier level lost a look-back: its rows (and everything induced from them) are not there
     s_base[t] = st->cur[t];              // the cursors as the level finds them (the last tile moves them: read before taking a tile)
     const u32 lo = st->rng[lv.slot][0], hi = st->rng[lv.slot][1];
     const u32 ntiles = (hi - lo + IND_TILE - 1) / IND_TILE;
@@ -569,6 +579,7 @@ __global__ __launch_bounds__(256) void k_ind_small(IndState* st, IndLevel lv, u3
     __shared__ u32 goff[256];
     __shared__ u32 s_sub[257];
     const u32 t = threadIdx.x;
+    if (ind_failed(st)) return;
     if (lv.stars) { s_sub[t] = tb.sub_start[lv.c * 256u + t]; if (t == 0) s_sub[256] = tb.bkt[lv.c + 1]; }
     const u32 my_code = tb.code[t];
     u32 slot = lv.slot;

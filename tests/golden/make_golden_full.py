@@ -26,6 +26,8 @@ CASES = [
     ("text", 3, (1 << 30) - 1, ("sa", "bwt", "lcp")),            # config 3 / 4
     ("dna", 2024, (1 << 30) - 1, ("sa", "bwt")),                 # first 2^30-1 bytes of the config-5 style stream of tests/test_gpu_big.py
     ("dna_tandem", 9, 1 << 28, ("sa", "bwt")),                   # config-5 workload (long tandem repeats) at 256 MiB
+    ("random", 12345, (1 << 30) - 1, ("sa", "bwt")),             # the bench headline (SURVEY 8(d) north-star input)
+    ("random", 12345, 1 << 28, ("sa",)),                         # config 2
 ]
 
 
@@ -38,7 +40,7 @@ def main():
     if only and os.path.exists(path):
         out = json.load(open(path))
     for name, seed, n, what in CASES:
-        if only and name not in only:
+        if only and name not in only and f"{name}:{n}" not in only:
             continue
         t0 = time.time()
         t = gen.GENERATORS[name](n, seed)

@@ -73,12 +73,12 @@ def test_beyond_int32_logical_shards(n, shards, need_gb):
     ctx.make_sa_i64(d, n, sa, n_shards=shards)       # again, with every buffer in place (the first call allocates ~200 GB)
     t2b = time.time()
     tm = ctx.timings()
-    assert tm.reserved[1] >= shards and tm.doubling_rounds >= 1
+    assert tm.logical_shards >= shards and tm.doubling_rounds >= 1
     assert int(sa[0]) == n
     ctx.trim()
     errs = ctx.validate_sa(d, n, sa, index_bytes=8)
     t3 = time.time()
-    print(f"\nn={n}: generate {t1 - t0:.1f}s, wide SA build {t2 - t1:.2f}s with allocations, {t2b - t2:.2f}s again ({tm.reserved[1]} logical shards, depth {tm.reserved[0]}, "
+    print(f"\nn={n}: generate {t1 - t0:.1f}s, wide SA build {t2 - t1:.2f}s with allocations, {t2b - t2:.2f}s again ({tm.logical_shards} logical shards, depth {tm.stop_depth}, "
           f"{tm.doubling_rounds} doubling steps, doubling {tm.other_ms:.0f} ms), check {t3 - t2b:.1f}s, errors {errs}")
     assert errs == 0
     # the checker sees damage at this size too
@@ -142,10 +142,10 @@ def test_int32_limit_and_first_wide_size():
     ctx.make_sa_i64(d, n, sa64)
     t1 = time.time()
     tm = ctx.timings()
-    assert tm.reserved[1] >= 2                       # logical shards: the wide engine ran
+    assert tm.logical_shards >= 2                       # logical shards: the wide engine ran
     ctx.trim()
     assert int(sa64[0]) == n and ctx.validate_sa(d, n, sa64, index_bytes=8) == 0
-    print(f"n=2^31+5 random, int64 rows, wide engine ({tm.reserved[1]} logical shards): {t1 - t0:.3f}s")
+    print(f"n=2^31+5 random, int64 rows, wide engine ({tm.logical_shards} logical shards): {t1 - t0:.3f}s")
     # forward BWT beyond the int32 rows (wide engine inside): every byte equal to T[SA[r] - 1], sentinel row where SA[r] == 0
     bwt = torch.empty(n, dtype=torch.uint8, device=dev)
     sent = ctx.forward_bwt(d, n, bwt)
@@ -180,13 +180,13 @@ def test_two_stage_at_int32_limit():
     ctx.make_sa(d, n, sa, two_stage=1)
     t1 = time.time()
     tm = ctx.timings()
-    assert tm.reserved[5] > 0, "two-stage path declined"
+    assert tm.bstar_suffixes > 0, "two-stage path declined"
     assert int(sa[0]) == n and ctx.validate_sa(d, n, sa) == 0
-    print(f"\nn=2^31-2, 30 letters, two-stage: {t1 - t0:.3f}s (device {tm.total_ms:.1f} ms, {tm.reserved[5]} B* suffixes, induction {tm.other_ms:.1f} ms)")
+    print(f"\nn=2^31-2, 30 letters, two-stage: {t1 - t0:.3f}s (device {tm.total_ms:.1f} ms, {tm.bstar_suffixes} B* suffixes, induction {tm.other_ms:.1f} ms)")
     b1 = torch.empty(n, dtype=torch.uint8, device=dev)
     s1 = ctx.bwt_from_sa(d, n, sa, b1)
     del sa
     b2 = torch.empty(n, dtype=torch.uint8, device=dev)
     s2 = ctx.forward_bwt(d, n, b2, two_stage=1)
-    assert ctx.timings().reserved[5] > 0
+    assert ctx.timings().bstar_suffixes > 0
     assert s1 == s2 and torch.equal(b1, b2)

@@ -14,22 +14,45 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_two_ranks_one_gpu():
     env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    # `python bench.py --gpus 2` DIRECTLY, the way the driver calls it: bench.py starts its two ranks itself
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--size", str(1 << 24), "--no-cpu"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["valid"] is True and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["rccl_ranks"] == 2 and d["latency_ms"] > 0 and d["exchange_ms"] >= 0
+    assert len(d["per_rank"]["sort_ms"]) == 2 and sum(d["per_rank"]["rows"]) == (1 << 24) + 1
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """Without the one-device test hook `--gpus N` on a box with fewer GPUs must fail loudly, not measure one GPU."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("MSUFSORT_BENCH_ONE_DEVICE", "WORLD_SIZE", "RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
+                        "--size", str(1 << 20), "--no-cpu"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_under_torchrun():
+    """The other launch form (the ranks started by torch.distributed.run around bench.py) still works."""
+    env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--size", str(1 << 22), "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+    assert json.loads(lines[-1])["n_gpus"] == 2
 
 
 def test_bench_two_ranks_deep_ties():
     """Same flow on DNA with planted tandem repeats: the shards stop unresolved and finish with the distributed prefix
     doubling (each rank sorts its own groups, rank updates are all-gathered once per step)."""
     env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29612", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
            "--size", str(3 << 20), "--workload", "dna_tandem", "--no-cpu"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

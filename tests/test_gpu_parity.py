@@ -228,7 +228,7 @@ def test_logical_shards_deep_ties(M, oracle_mod, shards):
         sa = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
         ctx.make_sa(d, n, sa, logical_shards=shards, text_rounds=1)
         tm = ctx.timings()
-        assert tm.reserved[1] == shards and tm.reserved[0] == 5 + _symbols_per_key(t) and tm.doubling_rounds >= 1
+        assert tm.logical_shards == shards and tm.stop_depth == 5 + _symbols_per_key(t) and tm.doubling_rounds >= 1
         assert (sa.cpu().numpy() == _want(oracle_mod, t)).all()
 
 
@@ -316,7 +316,7 @@ def test_wide_engine_device_api(M, oracle_mod):
     d = _dev(M, t)
     sa = torch.empty(n + 1, dtype=torch.int64, device="cuda")
     ctx.make_sa_i64(d, n, sa, force_wide=True, n_shards=4)
-    assert ctx.timings().reserved[1] >= 4
+    assert ctx.timings().logical_shards >= 4
     assert ctx.validate_sa(d, n, sa, index_bytes=8) == 0
     bad = sa.clone(); bad[1000], bad[1001] = sa[1001].item(), sa[1000].item()
     assert ctx.validate_sa(d, n, bad, index_bytes=8) > 0
@@ -470,7 +470,7 @@ def test_single_process_multi_gpu_entry(M, oracle_mod, devices, shards):
     for t in cases:
         sa, tm = M.make_suffix_array_multi(t, devices, n_shards=shards, text_rounds=1, timings=True)
         assert (sa == _want(oracle_mod, t)).all(), (t.size, devices, shards)
-        assert tm.reserved[1] == (shards if shards else len(devices) * (8 if t.size >= (64 << 20) else 1))
+        assert tm.logical_shards == (shards if shards else len(devices) * (8 if t.size >= (64 << 20) else 1))
     t = gen.dna_tandem_bytes(500000, 3)
     sa = M.make_suffix_array_multi(t, devices, n_shards=shards, index_bytes=8, force_wide=True)
     assert sa.dtype == np.int64 and (sa == _want(oracle_mod, t)).all()
@@ -540,13 +540,13 @@ def _two_stage(M, oracle_mod, t, taken=True):
     d = _dev(M, t)
     sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
     ctx.make_sa(d, n, sa, two_stage=1)
-    assert (ctx.timings().reserved[5] > 0) == taken, "two-stage path %s" % ("declined" if taken else "taken")
+    assert (ctx.timings().bstar_suffixes > 0) == taken, "two-stage path %s" % ("declined" if taken else "taken")
     if n <= (4 << 20):
         want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
         assert (sa.cpu().numpy() == want).all()
     all_ = torch.empty(n + 1, dtype=torch.int32, device="cuda")
     ctx.make_sa(d, n, all_, two_stage=-1)
-    assert ctx.timings().reserved[5] == 0
+    assert ctx.timings().bstar_suffixes == 0
     assert torch.equal(sa, all_)
     assert ctx.validate_sa(d, n, sa) == 0
 
@@ -583,6 +583,35 @@ def test_two_stage_declines(M, oracle_mod):
     assert (sa == M.make_suffix_array(body, two_stage=-1)).all()
 
 
+def test_two_stage_lookback_timeout_is_sticky(M, oracle_mod, monkeypatch):
+    """A look-back that times out (bound shrunk to one spin by the test hook) must not leave later levels reading rows that
+    were never written (round-2 advisor finding): the flag is sticky, every later launch returns at once, the build is handed
+    to the sort-all path - exact rows, and the abandoned attempt is visible in the timings."""
+    import torch
+    t = gen.text_bytes(6 << 20, 31)
+    n = t.size
+    ctx = M.DeviceContext(0)
+    d = _dev(M, t)
+    sa = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+    monkeypatch.setenv("MSUFSORT_HIP_IND_SPIN", "1")
+    ctx.make_sa(d, n, sa, two_stage=1)
+    tm = ctx.timings()
+    monkeypatch.delenv("MSUFSORT_HIP_IND_SPIN")
+    assert ctx.validate_sa(d, n, sa) == 0
+    assert tm.bstar_suffixes == 0 and (tm.fallbacks & 1) == 1 and (tm.fallbacks >> 8) == 6, (tm.bstar_suffixes, tm.fallbacks)
+    ref = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, n, ref, two_stage=1)
+    tm = ctx.timings()
+    assert tm.bstar_suffixes > 0 and tm.fallbacks == 0 and tm.front_ms > 0 and tm.hist16_ms > 0 and tm.hist16_ms < tm.front_ms
+    assert torch.equal(sa, ref)
+    # policy declines after the front end are counted too (reason 4), declines that cost nothing are not
+    r = gen.random_bytes(1 << 20, 5)
+    dr = _dev(M, r)
+    sr = torch.empty(r.size + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(dr, r.size, sr, two_stage=-1)
+    assert ctx.timings().fallbacks == 0
+
+
 def test_two_stage_forward_bwt(M, oracle_mod):
     """The forward transform after a two-stage build reads its bytes from the rows' preceding characters (no text gather)."""
     import torch
@@ -593,7 +622,7 @@ def test_two_stage_forward_bwt(M, oracle_mod):
         d = _dev(M, t)
         b1 = torch.empty(n, dtype=torch.uint8, device="cuda")
         s1 = ctx.forward_bwt(d, n, b1, two_stage=1)
-        assert ctx.timings().reserved[5] > 0
+        assert ctx.timings().bstar_suffixes > 0
         b0 = torch.empty(n, dtype=torch.uint8, device="cuda")
         s0 = ctx.forward_bwt(d, n, b0, two_stage=-1)
         assert s0 == s1 and torch.equal(b0, b1)
@@ -663,7 +692,7 @@ def test_two_stage_repeatable(M):
     for r in range(30):
         sa.zero_()
         ctx.make_sa(d, n, sa, two_stage=1)
-        assert ctx.timings().reserved[5] > 0 and torch.equal(sa, ref), r
+        assert ctx.timings().bstar_suffixes > 0 and torch.equal(sa, ref), r
 
 
 def test_two_stage_three_kernel_levels(M, oracle_mod, monkeypatch):

@@ -14,4 +14,4 @@ for r in range(3):
         ctx.inverse_bwt(b, n, s, inv)
     except Exception as e:
         print("err", str(e)[:80])
-    tm = ctx.timings(); print("inverse device ms", tm.reserved[4] / 1e3, "walk", tm.reserved[3] / 1e3, flush=True)
+    tm = ctx.timings(); print("inverse device ms", tm.ibwt_total_us / 1e3, "walk", tm.ibwt_walk_us / 1e3, flush=True)

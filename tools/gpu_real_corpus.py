@@ -46,5 +46,5 @@ for mode, out in ((-1, sa0), (1, sa1), (0, sa1)):
         ctx.make_sa(d, n, out, two_stage=mode, verbose=(1 if (mode == 1 and r == 0) else 0))
         best = min(best, ctx.timings().total_ms)
     tm = ctx.timings()
-    print(f"two_stage={mode:2d}: {best:8.2f} ms  (taken: {tm.reserved[5] > 0}, rounds {tm.rounds}, doubling rounds {tm.doubling_rounds}, induction {tm.other_ms:.2f} ms)", flush=True)
+    print(f"two_stage={mode:2d}: {best:8.2f} ms  (taken: {tm.bstar_suffixes > 0}, rounds {tm.rounds}, doubling rounds {tm.doubling_rounds}, induction {tm.other_ms:.2f} ms)", flush=True)
 print("equal", bool(torch.equal(sa0, sa1)), "checker errors", ctx.validate_sa(d, n, sa1))

@@ -24,5 +24,5 @@ for mib in [int(x) for x in sys.argv[2:]]:
             best = min(best, ctx.timings().total_ms)
         res[mode] = best
     tm = ctx.timings()
-    print(f"{w} {mib} MiB: sort-all {res[-1]:.2f} ms, two-stage {res[1]:.2f} ms (induction {tm.other_ms:.2f}, launches {tm.reserved[6]})", flush=True)
+    print(f"{w} {mib} MiB: sort-all {res[-1]:.2f} ms, two-stage {res[1]:.2f} ms (induction {tm.other_ms:.2f}, launches {tm.induction_launches})", flush=True)
     del d, sa

@@ -41,4 +41,4 @@ for mode in (-1, 0, 1):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ctx.make_sa(d, n, sa, two_stage=mode)
         torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) * 1e3)
-    print(f"{w} {n >> 20} MiB two_stage={mode:2d}: wall {best:8.2f} ms (taken: {ctx.timings().reserved[5] > 0})", flush=True)
+    print(f"{w} {n >> 20} MiB two_stage={mode:2d}: wall {best:8.2f} ms (taken: {ctx.timings().bstar_suffixes > 0})", flush=True)
