@@ -15,7 +15,9 @@
 // no CPU fallback behind this header.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -35,8 +37,14 @@ namespace maniscalco
 
         // The reference constructor spawns its worker pool (msufsort.h:315-341); this one owns a GPU context
         // (stream + workspace), created on first use and reused by every call on the instance.
-        msufsort(std::int32_t numThreads = 1) : numThreads_(numThreads) {}
-        ~msufsort() { if (ctx_) ::msufsort_hip_ctx_destroy(ctx_); }
+        msufsort(std::int32_t numThreads = 1) : numThreads_(numThreads) { ++instances(); }
+        ~msufsort()
+        {
+            if (ctx_) ::msufsort_hip_ctx_destroy(ctx_);
+            // the streaming entry point pools its contexts (stream + workspace + a text copy per device) for the life of the
+            // process; the last instance gives them back, as the reference's destructor joins its worker pool (msufsort.h:343-349)
+            if (--instances() == 0 && pooled()) { ::msufsort_hip_release_cached(); pooled() = false; }
+        }
         msufsort(msufsort const &) = delete;
         msufsort & operator = (msufsort const &) = delete;
 
@@ -44,10 +52,17 @@ namespace maniscalco
         {
             auto n = static_cast<std::int64_t>(inputEnd - inputBegin);
             suffix_array sa(static_cast<std::size_t>(n) + 1);
-            // large inputs: every visible GPU (or MSUFSORT_DEVICES) sorts a range of buckets, finished slices stream to the
-            // host while the rest is sorted; small ones: this instance's context (lowest latency)
+            // large inputs: the streaming entry point - finished slices leave for the host while the rest is sorted - on this
+            // instance's device; several GPUs only when the caller asks for them (MSUFSORT_DEVICES="0,1,..."): a library that
+            // allocates on every visible GPU of a shared node by default is a bad neighbour.  Small inputs: this instance's
+            // context (lowest latency)
             if (n >= (std::int64_t(32) << 20))
-                check(::msufsort_hip_make_sa_multi(nullptr, 0, inputBegin, n, sa.data(), 4, nullptr, nullptr), "make_suffix_array");
+            {
+                std::int32_t const own = 0;
+                bool const listed = std::getenv("MSUFSORT_DEVICES") != nullptr;
+                pooled() = true;
+                check(::msufsort_hip_make_sa_multi(listed ? nullptr : &own, listed ? 0 : 1, inputBegin, n, sa.data(), 4, nullptr, nullptr), "make_suffix_array");
+            }
             else
                 check(::msufsort_hip_make_sa_i32_ctx(ctx(), inputBegin, n, sa.data(), nullptr), "make_suffix_array");
             return sa;
@@ -92,6 +107,9 @@ namespace maniscalco
             if (!ctx_) check(::msufsort_hip_ctx_create(&ctx_, 0, 0), "context");
             return ctx_;
         }
+
+        static std::atomic<int> & instances() { static std::atomic<int> n{0}; return n; }
+        static std::atomic<bool> & pooled() { static std::atomic<bool> p{false}; return p; }      // (the pool only frees idle contexts)
 
         std::int32_t numThreads_;
         ::msufsort_hip_ctx * ctx_ = nullptr;

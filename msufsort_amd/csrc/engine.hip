@@ -1465,14 +1465,23 @@ int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, typename
     TRY(trailing_zeros(c, d_text, (u64)n, &z));
     const u64 m = (u64)n - z;
     ShardCuts sc;
+    HIP_TRY(hipEventRecord(c->ev[8], c->stream));
     TRY(plan_shards<W>(c, d_text, (u64)n, z, opts->n_shards, sc));
+    HIP_TRY(hipEventRecord(c->ev[9], c->stream));
     const int g = opts->shard;
     const u64 lo = sc.rows[g], hi = sc.rows[g + 1];
     if (slice_lo) *slice_lo = (int64_t)lo;
     if (slice_hi) *slice_hi = (int64_t)hi;
     if ((int64_t)(hi - lo) > slice_capacity) { set_error("slice needs %llu rows, capacity %lld", (unsigned long long)(hi - lo), (long long)slice_capacity); return MSUFSORT_HIP_ERR_BAD_ARG; }
     if (hi == lo) return MSUFSORT_HIP_OK;
-    return build_sa<W>(c, d_text, (u64)n, d_slice_out, lo, z, sc.cuts[g], sc.cuts[g + 1], sc.rank0[g], g == 0, opts, m > 0, d_grp_slice_out, hi - lo);
+    const int r = build_sa<W>(c, d_text, (u64)n, d_slice_out, lo, z, sc.cuts[g], sc.cuts[g + 1], sc.rank0[g], g == 0, opts, m > 0, d_grp_slice_out, hi - lo);
+    if (r == MSUFSORT_HIP_OK || r == MSUFSORT_HIP_UNRESOLVED) {
+        // the histogram (every shard reads the whole text) and the planning of the cuts ran before build_sa started its clock
+        float ms_ = 0;
+        (void)hipEventElapsedTime(&ms_, c->ev[8], c->ev[9]);
+        c->tm.hist16_ms += ms_; c->tm.total_ms += ms_;
+    }
+    return r;
 }
 
 __global__ __launch_bounds__(256) void k_widen(const int32_t* __restrict__ in, u64 rows, int64_t* __restrict__ out)
