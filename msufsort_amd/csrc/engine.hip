@@ -512,6 +512,7 @@ struct Rounds {
     int verbose = 0;
     bool exact_sticky = false, fast_gave_up = false, force_retry = false, no_pack = false;
     bool safe_rank = getenv("MSUFSORT_HIP_SAFE_RANK") != nullptr;
+    bool bucket_sort_bits = !(getenv("MSUFSORT_HIP_BUCKET_SORT") && !strcmp(getenv("MSUFSORT_HIP_BUCKET_SORT"), "fast2"));
     u32 nA = 0, nB = 0, nC = 0, nP = 0;
     u32 deep_cap = 0;                    // != 0: k_sort_tiny finishes its runs by comparing the suffixes themselves (two-stage builds)
     GatherSpec gather{nullptr, 0, {}};   // text rounds: the sorts (and the first partition level) gather the keys themselves
@@ -670,11 +671,29 @@ struct Rounds {
             nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
             const bool spread = keys_spread();
             const bool use_fast = wants_fast();
+            const bool use_bits = bucket_sort_bits;          // k_sort_bits (round 3) or k_sort_fast2 (MSUFSORT_HIP_BUCKET_SORT=fast2)
             if (use_fast && (nB || nC)) hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << C_FBB) | (1u << C_FBC));
             if (nC) {
                 const u32* ids = nullptr;
                 if constexpr (!W) {
-                    if (use_fast) {
+                    if (use_fast && use_bits) {
+                        k_sort_bits<BITS_C_SHAPE><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), 0, st>>>(
+                            bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, em, counters, c->doneC.template as<u32>(), (u32)C_FBC);
+                        DBG("k_sort_bits C");
+#ifdef BITS_PROF
+                        {
+                            unsigned long long h[16];
+                            hipStreamSynchronize(st);
+                            hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bits_prof), sizeof h);
+                            fprintf(stderr, "[bits prof] nC=%u cycles/1e6: clear=%.1f A=%.1f scan=%.1f B=%.1f D01=%.1f D2=%.1f D3=%.1f out=%.1f end=%.1f | per segment: dirty %.1f ties %.2f; list overflows %llu, sample len<<32|nl %llx, nl>1700: %llu, nl>2048: %llu\n", nC,
+                                    h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[6] / 1e6, h[7] / 1e6, h[8] / 1e6, h[9] / 1e6,
+                                    (double)h[10] / nC, (double)h[11] / nC, h[12], h[13], h[14], h[15]);
+                            memset(h, 0, sizeof h);
+                            hipMemcpyToSymbol(HIP_SYMBOL(g_bits_prof), h, sizeof h);
+                        }
+#endif
+                        ids = c->doneC.template as<u32>();
+                    } else if (use_fast) {
                         k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_fast2_lds_bytes<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C>(), st>>>(
                             bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, em, counters, c->doneC.template as<u32>(), (u32)C_FBC);
                         DBG("k_sort_fast C");
@@ -715,7 +734,12 @@ struct Rounds {
             if (nB) {
                 const u32* ids = nullptr;
                 if constexpr (!W) {
-                    if (use_fast) {
+                    if (use_fast && use_bits) {
+                        k_sort_bits<BITS_B_SHAPE><<<dim3(std::min<u32>(nB, 256u * 4u)), dim3(CLS_B_THREADS), 0, st>>>(
+                            bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, em, counters, c->doneB.template as<u32>(), (u32)C_FBB);
+                        DBG("k_sort_bits B");
+                        ids = c->doneB.template as<u32>();
+                    } else if (use_fast) {
                         k_sort_fast2<CLS_B_THREADS, CLS_B_ITEMS, FAST_BITS_B, FAST2_TL_B><<<dim3(std::min<u32>(nB, 256u * 4u)), dim3(CLS_B_THREADS), sort_fast2_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS, FAST_BITS_B, FAST2_TL_B>(), st>>>(
                             bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, em, counters, c->doneB.template as<u32>(), (u32)C_FBB);
                         DBG("k_sort_fast B");
@@ -854,6 +878,8 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
             fprintf(stderr, "[msufsort_hip] round %d mode %s depth %llu: sorted A=%u B=%u C=%u tiny=%u -> next tiny=%llu seg=%llu (A=%u B=%u C=%u L=%u)\n",
                     round, R.mode == MODE_TEXT ? "text" : "isa", (unsigned long long)depth, R.nA, R.nB, R.nC, R.nP, (unsigned long long)actP, (unsigned long long)actS,
                     c->h_counters[nb_base], c->h_counters[nb_base + 1], c->h_counters[nb_base + 2], c->h_counters[nb_base + 3]);
+        if (verbose && (c->h_counters[C_FBB] || c->h_counters[C_FBC]))
+            fprintf(stderr, "[msufsort_hip] round %d: the bucket sort handed %u class-B and %u class-C segments to k_sort_mid\n", round, c->h_counters[C_FBB], c->h_counters[C_FBC]);
         if (round == 0) tm.unresolved_after_round0 = (int64_t)(actP + actS);
         if (actP + actS == 0) break;
         if (round == 0) {     // key packing for the gather rounds (k_alphabet ran with the histogram)

@@ -1607,9 +1607,12 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
         }
 }
 
+#include "bucket_sort_bits.hip.h"
+
 // ------------------------------------------------------------------------------------------------
 // Fast LDS sort for segments whose keys are spread out (the two-byte buckets of round 0 on random-like
-// input) - the hot kernel of the whole build.  Persistent workgroups stride over the list.
+// input) - the hot kernel of rounds 1 and 2; since round 3 k_sort_bits (bucket_sort_bits.hip.h) is tried first and this
+// one stays selectable (MSUFSORT_HIP_BUCKET_SORT=fast2).  Persistent workgroups stride over the list.
 //   1. one MSD split on the top BITS of the kbits varying key bits into 2^BITS sub-buckets; the rank r
 //      inside the sub-bucket comes from a returning LDS atomic (arrival order, arbitrary);
 //   2. block-wide exclusive scan of the sub-bucket counts;
