@@ -67,18 +67,23 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
     constexpr int NW = THREADS * 16;                  // LDS words, 16 buckets each; a thread scans 4 quads of words
     constexpr int NL = ITEMS / 2;
     constexpr int LPT = LCAP / THREADS;               // dirty-list entries per thread
-    constexpr int BATCH = 6;                          // LDS reads in flight per lane in phase B
+    constexpr int BATCH = 18;                         // LDS reads in flight per lane in phase B
     static_assert(ITEMS % 2 == 0 && ITEMS % BATCH == 0 && LCAP % THREADS == 0 && (THREADS & (THREADS - 1)) == 0 && W * 4 <= 64, "shapes");
     static_assert(LEN_MAX <= THREADS * ITEMS && LEN_MAX + 64 < 32768, "segment length limit (rows are 15-bit fields)");
     constexpr u32 GB = THREADS == 1024 ? 18u : THREADS == 512 ? 17u : THREADS == 256 ? 16u : THREADS == 128 ? 15u : 14u;      // log2(buckets)
     static_assert((1u << GB) == (u32)NW * 16u, "GB");
     constexpr u32 TRASH_ROW = LEN_MAX + 32;           // where lanes outside the segment and records of dirty words store
-    __shared__ __attribute__((aligned(16))) u32 bw[NW + 4];           // [NW] = len << 16 (closes the last word's row range); [NW + 1]: word of the lanes outside the segment
-    __shared__ __attribute__((aligned(16))) u32 out[LEN_MAX + 64];    // rows (suffix indices in final order); mailbox of the dirty words
-    __shared__ __attribute__((aligned(16))) uint2 lst[LCAP];          // {key, index} of the records of dirty words
-    __shared__ u32 tl[3 * TL];                                        // tie list {index, rs | rl << 16 | ro << 24, local offset}
-    __shared__ u32 tot[64];                                           // wave totals of the scan: [quad row][wave]
-    __shared__ u32 misc[16];
+    struct Lds {
+        u32 bw[NW + 4];               // the words, at LDS address 0 (a word's address is a shifted key, nothing to add);
+                                      // [NW] = len << 16 closes the last word's row range; [NW + 1]: word of the lanes outside the segment
+        u32 out[LEN_MAX + 64];        // rows (suffix indices in final order); mailbox of the dirty words
+        uint2 lst[LCAP];              // {key, index} of the records of dirty words
+        u32 tl[3 * TL];               // tie list {index, rs | rl << 16 | ro << 24, local offset}
+        u32 tot[64];                  // wave totals of the scan: [quad row][wave]
+        u32 misc[16];
+    };
+    __shared__ __attribute__((aligned(16))) Lds L;
+    u32* const bw = L.bw; u32* const out = L.out; uint2* const lst = L.lst; u32* const tl = L.tl; u32* const tot = L.tot; u32* const misc = L.misc;
 
     u32 t = threadIdx.x;
 #define BITS_P(j) (((((u32)(j) >> 1) * (u32)THREADS + t) << 1) + ((u32)(j) & 1u))
@@ -153,12 +158,15 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
         }
         BPROF(0);
         BITS_LOAD(0, LB);
+        const u32 shw = sh + 2u;                                 // byte offset of a key's word: (key >> shw) & ~3
+#define BITS_WORD(k) (*reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(bw) + (((k) >> shw) & 0x3fffcu)))
         if (ok) {                                                // ---- A: one add per record, nothing returned
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-                if (j < rows) {
-                    const u32 g = key[j] >> sh;
-                    atomicAdd(&bw[g >> 4], (1u << (g & 15u)) | 0x100000u);
+            for (int q = 0; q < NL; ++q)
+                if (2 * q < rows) {
+#pragma unroll
+                    for (int j = 2 * q; j < 2 * q + 2; ++j)
+                        atomicAdd(&BITS_WORD(key[j]), (1u << ((key[j] >> sh) & 15u)) | 0x100000u);
                 }
             __syncthreads();                                                        // (2)
         }
@@ -214,15 +222,19 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
                 if (j0 < rows) {
                     u32 e[BATCH];
 #pragma unroll
-                    for (int b = 0; b < BATCH; ++b) if (j0 + b < rows) e[b] = bw[(key[j0 + b] >> sh) >> 4];
+                    for (int b = 0; b < BATCH; b += 2)
+                        if (j0 + b < rows) { e[b] = BITS_WORD(key[j0 + b]); e[b + 1] = BITS_WORD(key[j0 + b + 1]); }
 #pragma unroll
-                    for (int b = 0; b < BATCH; ++b)
-                        if (j0 + b < rows) {                     // (scalar test: the registers of rows behind the segment hold anything)
-                            const int j = j0 + b;
-                            const u32 g = key[j] >> sh;
-                            const u32 row = (u32)__popc(e[b] & ((1u << (g & 15u)) - 1u)) + ((e[b] >> 16) & 0x7fffu);
-                            out[(int)e[b] < 0 ? TRASH_ROW : row] = idx[j];
-                            dmask |= (e[b] >> 31) << j;
+                    for (int b = 0; b < BATCH; b += 2)
+                        if (j0 + b < rows) {                     // (scalar test per pair: the registers of rows behind the segment hold anything)
+#pragma unroll
+                            for (int c = b; c < b + 2; ++c) {
+                                const int j = j0 + c;
+                                const u32 g = key[j] >> sh;
+                                const u32 row = (u32)__popc(e[c] & ((1u << (g & 15u)) - 1u)) + ((e[c] >> 16) & 0x7fffu);
+                                out[(int)e[c] < 0 ? TRASH_ROW : row] = idx[j];
+                                dmask |= (e[c] >> 31) << j;
+                            }
                         }
                 }
             // ONE list reservation per wave and segment: wave scan of the per-thread counts
@@ -259,8 +271,8 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
                 if (e < nl) {
                     const uint2 r = lst[e];
                     dk[i] = r.x; di[i] = r.y;
-                    const u32 dw = (r.x >> sh) >> 4;
-                    const u32 w0 = atomicAdd(&bw[dw], 1u), w1 = bw[dw + 1u];       // claim a slot of the word's row range
+                    u32* const dwp = &BITS_WORD(r.x);
+                    const u32 w0 = atomicAdd(dwp, 1u), w1 = dwp[1];                // claim a slot of the word's row range
                     db[i] = (w0 >> 16) & 0x7fffu;
                     dc[i] = ((w1 >> 16) & 0x7fffu) - db[i];
                     ds[i] = w0 & 0xffffu;
@@ -381,4 +393,5 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
 #undef BITS_P
 #undef BITS_SRC
 #undef BITS_LOAD
+#undef BITS_WORD
 }
