@@ -67,7 +67,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
     constexpr int NW = THREADS * 16;                  // LDS words, 16 buckets each; a thread scans 4 quads of words
     constexpr int NL = ITEMS / 2;
     constexpr int LPT = LCAP / THREADS;               // dirty-list entries per thread
-    constexpr int BATCH = 18;                         // LDS reads in flight per lane in phase B
+    constexpr int BATCH = 6;                          // LDS reads in flight per lane in phase B
     static_assert(ITEMS % 2 == 0 && ITEMS % BATCH == 0 && LCAP % THREADS == 0 && (THREADS & (THREADS - 1)) == 0 && W * 4 <= 64, "shapes");
     static_assert(LEN_MAX <= THREADS * ITEMS && LEN_MAX + 64 < 32768, "segment length limit (rows are 15-bit fields)");
     constexpr u32 GB = THREADS == 1024 ? 18u : THREADS == 512 ? 17u : THREADS == 256 ? 16u : THREADS == 128 ? 15u : 14u;      // log2(buckets)
