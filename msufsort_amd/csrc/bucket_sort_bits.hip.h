@@ -27,7 +27,7 @@
 // LDS per workgroup (1024 threads, 16,384 words, segments up to 17,408 records): words 64 KiB, rows 68 KiB, dirty list
 // 16 KiB, tie list 1.5 KiB = 150 KiB: one workgroup per CU.  Static LDS: every address is a compile-time constant.
 //
-// Handed back to k_sort_mid through fb_list (as k_sort_fast2 does): segments longer than LEN_MAX, more than 24 varying key
+// Handed back to k_sort_mid through fb_list (as k_sort_fast2 does): segments longer than LEN_MAX, more than 30 varying key
 // bits, a dirty list or tie list that overflows (skewed keys), runs of more than 255 equal keys.
 #pragma once
 
@@ -43,20 +43,6 @@ __device__ unsigned long long g_bits_prof[16];
 #else
 #define BPROF(i) do { } while (0)
 #endif
-
-// inclusive wave scan with DPP row shifts / row broadcasts (no LDS traffic, 10 vector instructions)
-__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 v)
-{
-    // within rows of 16 lanes: Kogge-Stone with row_shr 1, 2, 4, 8 (lanes without a source add 0)
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-    // across rows: lane 15 of the previous row to rows 1 and 3, then lane 31 to rows 2 and 3
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-    return v;
-}
 
 template <int THREADS, int ITEMS, int LEN_MAX, int LCAP, int TL>
 __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
@@ -134,7 +120,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
         dn = list[seg + gridDim.x < nseg ? seg + gridDim.x : nseg - 1u];
         const u32 nrows = (len + 127u) >> 7;                     // a wave covers 128 consecutive positions per pair load
         const int rows = 2 * (nrows > wv ? (int)((nrows - wv + W - 1) / W) : 0);     // items of this wave that can be inside the segment (scalar)
-        bool ok = kbits <= 24u && len != 0 && len <= (u32)LEN_MAX;
+        bool ok = kbits <= 30u && len != 0 && len <= (u32)LEN_MAX;       // (key_out must fit 32 bits: (2^GB + 16) << (kbits - GB))
         u32 res_t = 0, res_s = 0;
 
         if (ok) {                                                // ---- clear the words
@@ -157,7 +143,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
             __syncthreads();                                                        // (1)
         }
         BPROF(0);
+#ifndef BITS_LATE_LOADS
         BITS_LOAD(0, LB);
+#endif
         const u32 shw = sh + 2u;                                 // byte offset of a key's word: (key >> shw) & ~3
 #define BITS_WORD(k) (*reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(bw) + (((k) >> shw) & 0x3fffcu)))
         if (ok) {                                                // ---- A: one add per record, nothing returned
@@ -171,7 +159,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
             __syncthreads();                                                        // (2)
         }
         BPROF(1);
+#ifndef BITS_LATE_LOADS
         BITS_LOAD(LB, 2 * LB);
+#endif
         if (ok) {                                                // ---- S: first row of every word
             // thread t owns the word quads (k THREADS + t), k = 0..3: 16-byte LDS accesses, consecutive lanes on consecutive quads
             uint4 q4[4];
@@ -212,7 +202,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
             __syncthreads();                                                        // (4)
         }
         BPROF(2);
+#ifndef BITS_LATE_LOADS
         BITS_LOAD(2 * LB, 3 * LB);
+#endif
         u32 nl = 0;
         if (ok && misc[1]) ok = false;
         if (ok) {                                                // ---- B: final rows of the clean words' records
@@ -261,7 +253,11 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
             if (misc[1]) ok = false;                             // skewed keys: k_sort_mid takes the segment
         }
         BPROF(3);
+#ifndef BITS_LATE_LOADS
         BITS_LOAD(3 * LB, 4 * LB);
+#else
+        BITS_LOAD(0, 3 * LB);          // experiment: the records of the next segment are requested only now, when this one's are dead
+#endif
         if (ok && nl) {                                          // ---- D: the records of the dirty words, one list entry per lane
             u32 dk[LPT], di[LPT], db[LPT], dc[LPT], ds[LPT];
 #pragma unroll
@@ -330,7 +326,11 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
             if (misc[1] || misc[4] > (u32)TL) ok = false;
         }
         BPROF(7);
+#ifndef BITS_LATE_LOADS
         BITS_LOAD(4 * LB, NL);
+#else
+        BITS_LOAD(3 * LB, NL);
+#endif
         if (ok) {                                                // ---- rows out
             const u32 nt = misc[4];
             if (t == 0 && nt != 0) {

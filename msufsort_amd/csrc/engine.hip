@@ -671,7 +671,11 @@ struct Rounds {
             nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
             const bool spread = keys_spread();
             const bool use_fast = wants_fast();
-            const bool use_bits = bucket_sort_bits;          // k_sort_bits (round 3) or k_sort_fast2 (MSUFSORT_HIP_BUCKET_SORT=fast2)
+            // k_sort_bits (round 3) where the keys are spread like random bytes; k_sort_fast2 for the dense base-sigma keys of later
+            // rounds (random DNA at depth 18: an eighth of the records of a segment tie - more than the dirty list of k_sort_bits
+            // holds - and k_sort_fast2 sorts such segments in 2.4 ms per GiB where k_sort_mid takes 3.8) and on request
+            // (MSUFSORT_HIP_BUCKET_SORT=fast2)
+            const bool use_bits = bucket_sort_bits && spread;
             if (use_fast && (nB || nC)) hipLaunchKernelGGL(k_zero_idx, dim3(1), dim3(64), 0, st, counters, (1u << C_FBB) | (1u << C_FBC));
             if (nC) {
                 const u32* ids = nullptr;
@@ -1446,7 +1450,13 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
         if (r != MSUFSORT_HIP_UNRESOLVED) return r;
     }
     const int r = build_sa<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 1ull << 32, z, true, &o, hist_done);
-    if (why) c->tm.fallbacks = 1 | ((int64_t)why << 8);      // the attempt cost device time that total_ms of the rebuild does not show
+    if (why) c->tm.fallbacks = 1 | ((int64_t)why << 8);      // an abandoned two-stage attempt: its device time is part of this build
+    if (hist_done && r == MSUFSORT_HIP_OK) {
+        // the histogram (and whatever else the attempt ran) happened before build_sa started its clock: bill it
+        float ms_ = 0;
+        (void)hipEventElapsedTime(&ms_, c->ev[6], c->ev[8]); c->tm.hist16_ms = ms_;
+        (void)hipEventElapsedTime(&ms_, c->ev[6], c->ev[5]); c->tm.total_ms = ms_;
+    }
     return r;
 }
 

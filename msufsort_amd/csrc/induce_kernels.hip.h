@@ -188,7 +188,9 @@ struct IndState {
 #define IND_FLAG_LOOKBACK 8u      // a look-back waited longer than any kernel runs: the build is reported as failed, not hung
 // tile status of the single-pass levels, one 64-bit word per (tile, byte value in use): [63:62] 1 = this tile's count,
 // 2 = count of all tiles up to and including this one; [61:48] level launch number (stale words of earlier levels read as
-// "nothing yet"); [47:0] the count
+// "nothing yet"); [47] POISON: a tile in front of this one lost its look-back (its running total is short), nothing computed
+// from it may be written - the tiles behind learn it from the words they read anyway, not from another load; [46:0] the count
+#define IND_ST_POISON (1ull << 47)
 #define IND_ST_AGG 1ull
 #define IND_ST_INC 2ull
 __device__ __forceinline__ bool ind_failed(const IndState* st) { return (__hip_atomic_load(&st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & IND_FLAG_LOOKBACK) != 0; }
@@ -377,6 +379,7 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
     __shared__ u32 s_fail;
     __shared__ u8 s_codes[256];            // dense number of every byte value (255: not in use; all 256 in use: the identity)
     __syncthreads();
+    if (t == 0) s_fail = 0u;
     s_codes[t] = (u8)my_code;
 #pragma unroll
     for (int w2 = 0; w2 < 4; ++w2) wcnt[w2][t] = 0;
@@ -475,6 +478,7 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
                 const bool active = code < tb.nsym;
                 u32 excl = 0, pbase = tile, spins = 0;
                 const u32 spin_limit = st->spin_limit;
+                bool poisoned = false;
                 bool done = !active;
                 for (;;) {
                     const bool in = !done && sub < pbase;
@@ -485,22 +489,24 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
                     const u32 gi = (u32)(inc_m >> (grp * 8u)) & 255u, gw = (u32)(wait_m >> (grp * 8u)) & 255u;
                     const int f = gi ? __ffs((int)gi) - 1 : 7;                   // nearest running total, or the whole window
                     const bool blocked = (gw & ((2u << f) - 1u)) != 0;
+                    poisoned |= in && ready && (v & IND_ST_POISON) != 0;
                     u32 part = (!blocked && in && (int)sub <= f) ? (u32)v : 0u;
                     part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
                     if (!done && !blocked) { excl += part; if (gi) done = true; else pbase -= 8u; }
-                    if (!done && blocked && ++spins > spin_limit) { atomicOr(&st->flags, IND_FLAG_LOOKBACK); __threadfence(); done = true; }
+                    if (!done && blocked && ++spins > spin_limit) { atomicOr(&st->flags, IND_FLAG_LOOKBACK); poisoned = true; done = true; }
                     if (__ballot(!done) == 0) break;
                     if (__ballot(blocked)) __builtin_amdgcn_s_sleep(1);
                 }
                 if (active && sub == 0) goff[tb.sym[code]] = excl;
+                if (poisoned) s_fail = 1u;
             }
         }
         __syncthreads();
         if (my_code != 255u || tb.nb == 256u) {
             const u32 excl = goff[t];
             const u32 mine_tot = tot_t;
-            if (tile != 0) __hip_atomic_store(status + (u64)tile * tb.nb + my_code, ind_status(IND_ST_INC, epoch, (u64)excl + mine_tot), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
+            if (tile != 0) __hip_atomic_store(status + (u64)tile * tb.nb + my_code, ind_status(IND_ST_INC, epoch, ((u64)excl + mine_tot) | (s_fail ? IND_ST_POISON : 0ull)),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 base = s_base[t];
             goff[t] = lv.pass_b ? base - 1u - excl : base + excl;
             if (tile == ntiles - 1u) {           // the last tile knows the level's totals: cursors move, the next level's rows are named
@@ -510,10 +516,10 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
             }
         }
     }
-    // A look-back that timed out (this tile's or an earlier one's) leaves `excl` short: nothing computed from it may be written.
-    // The flag is sticky - every later level and bucket returns at once (ind_failed) and the host rebuilds with the sort-all path.
-    // (one thread reads it for the workgroup: the decision must be uniform, the caller's loop has barriers)
-    if (FUSED && t == 0) s_fail = ind_failed(st) ? 1u : 0u;
+    // A look-back that timed out (this tile's, or one in front of it: the poison bit of the status words) leaves `excl` short:
+    // nothing computed from it may be written.  The flag in the state is sticky - every later level and bucket returns at
+    // once (ind_failed) and the host rebuilds with the sort-all path.  (s_fail is workgroup-uniform behind the barrier: the
+    // caller's loop has barriers.)
     __syncthreads();
     if (FUSED && s_fail) return;
 #pragma unroll

@@ -170,15 +170,25 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 T)
 // neighbouring records travel together wherever they can: one dwordx4 per lane instead of two dwordx2.
 struct __attribute__((aligned(8))) Rec2 { u64 a, b; };
 
+// inclusive wave scan with DPP row shifts / row broadcasts: 12 vector instructions, no LDS traffic (the __shfl_up form costs
+// six ds_bpermute round trips - and the first wave of every scatter tile runs one while fifteen waves wait at a barrier)
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 v)
+{
+    // within rows of 16 lanes: Kogge-Stone with row_shr 1, 2, 4, 8 (lanes without a source add 0)
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    // across rows: lane 15 of the previous row to rows 1 and 3, then lane 31 to rows 2 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 __device__ __forceinline__ u32 wave_excl_scan(u32 v, u32& total)
 {
-    u32 x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 y = __shfl_up(x, d, 64);
-        if ((int)lane_id() >= d) x += y;
-    }
-    total = __shfl(x, 63, 64);
+    const u32 x = wave_incl_scan_dpp(v);
+    total = (u32)__builtin_amdgcn_readlane((int)x, 63);
     return x - v;
 }
 

@@ -12,6 +12,7 @@ import pytest
 from msufsort_amd import gen
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _dna_gpu(n, seed, dev):
@@ -86,6 +87,48 @@ def test_beyond_int32_logical_shards(n, shards, need_gb):
     sa[5], sa[6] = int(bad[6]), int(bad[5])
     assert ctx.validate_sa(d, n, sa, index_bytes=8) > 0
     del sa, d, bad
+    ctx.trim()
+    torch.cuda.empty_cache()
+
+
+def test_config5_own_stream_full_size():
+    """BASELINE config 5 on ITS OWN stream: alternating random stretches and tandem blocks (unit 1-50, 10-2010
+    copies) end to end - gen.dna_tandem_bytes, the generator of the 2^28 golden vector - at the full n = 2^33, int64 rows,
+    32 logical shards on the one GPU, distributed prefix doubling; 64-bit on-device checker (order + permutation)."""
+    import torch
+
+    import msufsort_amd as M
+    dev = torch.device("cuda")
+    free, total = torch.cuda.mem_get_info()
+    if free < 255 << 30:
+        pytest.skip("needs ~255 GB of free HBM")
+    n = 1 << 33
+    t0 = time.time()
+    t = gen.dna_tandem_bytes(n, 9)
+    # (the first 2^28 bytes are the golden input whose reference hashes tests/golden/golden_full.json holds)
+    import json
+    g = [e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "golden_full.json")))["full"] if e["generator"] == "dna_tandem"][0]
+    import oracle
+    assert "%016x" % oracle.fnv1a64(t[: 1 << 28]) == g["input_fnv"]
+    d = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    for s in range(0, n, 1 << 30):
+        d[s: s + (1 << 30)] = torch.from_numpy(t[s: s + (1 << 30)]).to(dev)
+    del t
+    torch.cuda.synchronize()
+    t1 = time.time()
+    ctx = M.DeviceContext(0)
+    sa = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    ctx.make_sa_i64(d, n, sa, n_shards=32)
+    t2 = time.time()
+    tm = ctx.timings()
+    assert int(sa[0]) == n and tm.logical_shards >= 32 and tm.doubling_rounds >= 1
+    ctx.trim()
+    errs = ctx.validate_sa(d, n, sa, index_bytes=8)
+    t3 = time.time()
+    print(f"\nconfig 5 stream, n=2^33: generate + upload {t1 - t0:.1f}s, wide SA build {t2 - t1:.2f}s with allocations ({tm.logical_shards} logical shards, "
+          f"depth {tm.stop_depth}, {tm.doubling_rounds} doubling steps, doubling {tm.other_ms:.0f} ms), check {t3 - t2:.1f}s, errors {errs}")
+    assert errs == 0
+    del sa, d
     ctx.trim()
     torch.cuda.empty_cache()
 
