@@ -882,6 +882,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
             fprintf(stderr, "[msufsort_hip] round %d mode %s depth %llu: sorted A=%u B=%u C=%u tiny=%u -> next tiny=%llu seg=%llu (A=%u B=%u C=%u L=%u)\n",
                     round, R.mode == MODE_TEXT ? "text" : "isa", (unsigned long long)depth, R.nA, R.nB, R.nC, R.nP, (unsigned long long)actP, (unsigned long long)actS,
                     c->h_counters[nb_base], c->h_counters[nb_base + 1], c->h_counters[nb_base + 2], c->h_counters[nb_base + 3]);
+        if (verbose && c->h_counters[C_CHAIN]) fprintf(stderr, "[msufsort_hip] round %d: %u suffixes finished as arithmetic progressions (tandem repeats) so far\n", round, c->h_counters[C_CHAIN]);
         if (verbose && (c->h_counters[C_FBB] || c->h_counters[C_FBC]))
             fprintf(stderr, "[msufsort_hip] round %d: the bucket sort handed %u class-B and %u class-C segments to k_sort_mid\n", round, c->h_counters[C_FBB], c->h_counters[C_FBC]);
         if (round == 0) tm.unresolved_after_round0 = (int64_t)(actP + actS);
@@ -968,6 +969,19 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         R.round = round;
         R.code = c->alpha.as<u8>();
         R.gather = GatherSpec{fuse ? d_text : nullptr, n, ks};
+        // tandem repeats: tie groups that are one arithmetic progression of positions are finished at once (k_chain_resolve)
+        if constexpr (!W) {
+            if (R.mode == MODE_ISA && depth <= 4096 && n < 0x7fffff00ull && getenv("MSUFSORT_HIP_NO_CHAINS") == nullptr) {
+                const u32 nAc = c->h_counters[curL], nBc = c->h_counters[curL + 1], nCc = c->h_counters[curL + 2];
+                if (nAc) k_chain_resolve<CLS_A_THREADS, CLS_A_ITEMS><<<dim3(std::min<u32>(nAc, 8192u)), dim3(CLS_A_THREADS), 0, st>>>(
+                             bufs, c->lists[cur][0].template as<Desc>(), nAc, sa_local, R.isa32, d_text, (u32)n, (u32)depth, counters);
+                if (nBc) k_chain_resolve<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(std::min<u32>(nBc, 2048u)), dim3(CLS_B_THREADS), 0, st>>>(
+                             bufs, c->lists[cur][1].template as<Desc>(), nBc, sa_local, R.isa32, d_text, (u32)n, (u32)depth, counters);
+                if (nCc) k_chain_resolve<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(std::min<u32>(nCc, 512u)), dim3(CLS_C_THREADS), 0, st>>>(
+                             bufs, c->lists[cur][2].template as<Desc>(), nCc, sa_local, R.isa32, d_text, (u32)n, (u32)depth, counters);
+                DBG("k_chain_resolve");
+            }
+        }
         if (!fuse && actP) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
                                      d_text, isa_any, n, R.mode, c->alpha.as<u8>(), ks);
         if (!fuse && actS) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actS, 1024), 65536u)), dim3(256), 0, st, bufs.p[R.sb], counters, curS,

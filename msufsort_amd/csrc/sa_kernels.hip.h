@@ -93,6 +93,7 @@ enum {
     C_ASIGMA = 27,                    // number of codes (symbols that occur + the reserved zero)
     C_CARRY = 28,                     // records k_carry_alloc placed in NEXT round's segment array during this round (a repeated
                                       // sort attempt restarts that array behind them, not at 0)
+    C_CHAIN = 29,                     // suffixes k_chain_resolve finished (tie groups that are one arithmetic progression of positions)
     C_NCOUNTERS = 32
 };
 
@@ -1135,7 +1136,11 @@ __global__ __launch_bounds__(256) void k_refill(u64* __restrict__ rec, const u32
         u32 key[U];
         bool v[U];
 #pragma unroll
-        for (int k = 0; k < U; ++k) { const u64 i = base + (u64)k * 256u; v[k] = i < count; idx[k] = v[k] ? rec_idx<W>(rec[i]) : (idx_t)0; }
+        for (int k = 0; k < U; ++k) {
+            const u64 i = base + (u64)k * 256u;
+            v[k] = i < count; idx[k] = v[k] ? rec_idx<W>(rec[i]) : (idx_t)0;
+            if constexpr (!W) v[k] = v[k] && idx[k] != 0xffffffffu;       // (records k_chain_resolve finished)
+        }
         if (!packed) {
 #pragma unroll
             for (int k = 0; k < U; ++k) {
@@ -2392,6 +2397,110 @@ __global__ __launch_bounds__(256) void k_apply_updates(const u64* __restrict__ u
 }
 
 // SA[0] = n and the trailing-zero-run rows (descending index)
+// ------------------------------------------------------------------------------------------------
+// Tandem repeats (the reference's partition_tandem_repeats / complete_tandem_repeats, cpp:316-484, in the shape that suits
+// prefix doubling).  At doubling offset h a tie group = all suffixes that share their first h characters.  If two members
+// sit P <= h positions apart, the text has period P from the first of them to h characters behind the second; if the members of the group are ONE arithmetic
+// progression i0, i0 + P, ..., i0 + (len-1) P (a single run of a repeated unit: the usual case for units of ten characters
+// and more), their order is fixed by ONE character comparison: suffix(i) and suffix(i + P) agree as long as the repeat goes
+// on and first differ where it ends, e = first position with T[e] != T[e - P] - there suffix(i + P) holds T[e] and suffix(i)
+// still holds the unit's T[e - P].  So all of them are ordered by position, descending if T[e] < T[e - P], ascending
+// otherwise, and the run end lies less than P characters behind the h known to match from the last member (else that
+// member's successor would be in the group as well).  Doubling alone needs log2(run length / h) more rounds over the whole
+// group (DNA with tandem repeats: 78 % of all suffixes stay tied for eight rounds); this kernel finishes such a group at
+// once: final rows and ranks are written, the descriptor is neutralised (len = 0).
+// One workgroup per segment (persistent); membership tests go through the rank array: same group <=> same rank value
+// (MODE_ISA: every member of a segment emitted by the previous round holds 1 + the group's first row).
+// ------------------------------------------------------------------------------------------------
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_chain_resolve(RecBufs bufs, Desc* __restrict__ list, u32 nseg, u32* __restrict__ sa_out,
+                                                           u32* __restrict__ isa, const u8* __restrict__ text, u32 n, u32 h,
+                                                           u32* __restrict__ counters)
+{
+    __shared__ u32 s_P, s_nf, s_tail, s_res;
+    const u32 t = threadIdx.x;
+    const u32 rank0 = counters[C_RANK0];
+    const u32 wmax = h < 64u ? h : 64u;                      // steps looked for (the argument needs P <= h only: the repeat's end then
+                                                             // lies in [last + h, last + h + P))
+    for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const Desc d = list[s];
+        __syncthreads();
+        if (d.len < 4u || d.len > (u32)(THREADS * ITEMS) || (d.buf & DESC_STALE)) continue;      // (workgroup-uniform)
+        u64* src = bufs.p[d.buf & 3u] + d.rec_off;
+        if (t == 0) { s_P = 0xffffffffu; s_nf = 0; s_tail = 0xffffffffu; s_res = 0; }
+        __syncthreads();
+        u32 idx[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { const u32 p = (u32)j * THREADS + t; idx[j] = p < d.len ? (u32)src[p] : 0xffffffffu; }
+        const u32 g0 = rank0 + d.sa_off + 1u;                 // the rank every member holds
+        // 1. the period: the first 64 members look for their next member within wmax positions
+        if (t < 64u && t < d.len) {
+            const u32 i = idx[0];
+            u32 found = 0xffffffffu;
+            if (isa[i] == g0) {
+                for (u32 q0 = 1; q0 <= wmax && found == 0xffffffffu; q0 += 8) {
+                    u32 v[8];
+#pragma unroll
+                    for (u32 k = 0; k < 8; ++k) v[k] = (q0 + k <= wmax && i + q0 + k < n) ? isa[i + q0 + k] : 0u;
+#pragma unroll
+                    for (u32 k = 0; k < 8; ++k) if (found == 0xffffffffu && v[k] == g0) found = q0 + k;
+                }
+            } else found = 0u;                                // (the segment does not hold its first row as rank: leave it alone)
+            if (found != 0xffffffffu) atomicMin(&s_P, found);
+        }
+        __syncthreads();
+        const u32 P = s_P;
+        if (P == 0u || P == 0xffffffffu) continue;
+        // 2. one progression?  every member but one must have its successor i + P in the group
+        u32 nf = 0, tail = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (idx[j] != 0xffffffffu) {
+                const bool f = idx[j] + P < n && isa[idx[j] + P] == g0;
+                nf += f;
+                if (!f) tail = idx[j];
+            }
+        nf = wave_sum(nf);
+        if ((t & 63u) == 0 && nf) atomicAdd(&s_nf, nf);
+        if (tail != 0xffffffffu) atomicMin(&s_tail, tail);    // (more than one: rejected by the count)
+        __syncthreads();
+        if (s_nf != d.len - 1u) continue;
+        const u32 last = s_tail, first = last - (d.len - 1u) * P;
+        // 3. where the repeat ends behind the last member: the direction of the whole progression
+        if (t == 0) {
+            u32 res = 0;
+            for (u32 j = 0; j < P && res == 0; ++j) {
+                const u64 pos = (u64)last + h + j;
+                const u32 c1 = pos < n ? text[pos] : 0u, c0 = pos - P < n ? text[pos - P] : 0u;
+                if (c1 != c0) res = c1 < c0 ? 1u : 2u;        // 1: later positions are smaller (descending), 2: ascending
+            }
+            s_res = res;
+        }
+        __syncthreads();
+        const u32 res = s_res;
+        if (res == 0) continue;
+        // 4. final rows and ranks
+        bool okp = true;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (idx[j] != 0xffffffffu) {
+                const u32 off = idx[j] - first, k = off / P;
+                okp &= idx[j] >= first && k * P == off && k < d.len;
+            }
+        if (!__syncthreads_and(okp)) continue;                // (not the progression it seemed to be: doubling goes on)
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (idx[j] != 0xffffffffu) {
+                const u32 k = (idx[j] - first) / P;
+                const u32 r = res == 1u ? d.len - 1u - k : k;
+                sa_out[d.sa_off + r] = idx[j];
+                isa[idx[j]] = rank0 + d.sa_off + r + 1u;
+                src[(u32)j * THREADS + t] = ~0ull;            // a finished record: k_refill, which sweeps the whole record array, skips it
+            }
+        if (t == 0) { list[s].len = 0; atomicAdd(&counters[C_CHAIN], d.len); }
+    }
+}
+
 template <bool W>
 __global__ __launch_bounds__(256) void k_sa_head(typename Wd<W>::sa_t* __restrict__ sa, u64 n, u64 z)
 {
