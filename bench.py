@@ -501,7 +501,8 @@ def main():
         my = int(bounds[1] - bounds[0])
         kern = {"k_hist16": kern["k_hist16"], "k_scatter0": (kern["k_scatter0"][0], n + 8 * my),
                 "k_partition(level 1)": (kern["k_partition(level 1)"][0], 16 * my),
-                "bucket sort (rank 0's shard)": (avg("bucket_sort_ms"), 12 * my)} | {k: v for k, v in kern.items() if k.startswith("key rounds")}
+                "bucket sort (rank 0's shard)": (avg("bucket_sort_ms"), 12 * my)}
+        # (key rounds / distributed doubling of a sharded build are several calls with their own timings: see "doubling")
         out = {
             "metric": metric, "value": round(n / (dt / K) / 1e6, 2), "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),

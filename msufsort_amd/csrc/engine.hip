@@ -543,6 +543,18 @@ struct Rounds {
                (keys_spread() || (dense_uniform && !fast_gave_up) || getenv("MSUFSORT_HIP_FORCE_FAST"));
     }
 
+    // tandem repeats (k_chain_resolve): the class lists of `slot` in a doubling round at offset h
+    void chain_resolve(int slot, const u32 (&cnt)[3], sa_t* rows, sa_t* isa_rw, const sa_t* isa_ro, u64 n, u64 h)
+    {
+        if (getenv("MSUFSORT_HIP_NO_CHAINS")) return;
+        if (cnt[0]) k_chain_resolve<CLS_A_THREADS, CLS_A_ITEMS, W><<<dim3(std::min<u32>(cnt[0], 8192u)), dim3(CLS_A_THREADS), 0, st>>>(
+                        bufs, c->lists[slot][0].template as<Desc>(), cnt[0], rows, isa_rw, isa_ro, grp_out, mode, n, h, counters);
+        if (cnt[1]) k_chain_resolve<CLS_B_THREADS, CLS_B_ITEMS, W><<<dim3(std::min<u32>(cnt[1], 2048u)), dim3(CLS_B_THREADS), 0, st>>>(
+                        bufs, c->lists[slot][1].template as<Desc>(), cnt[1], rows, isa_rw, isa_ro, grp_out, mode, n, h, counters);
+        if (cnt[2]) k_chain_resolve<CLS_C_THREADS, CLS_C_ITEMS, W><<<dim3(std::min<u32>(cnt[2], 512u)), dim3(CLS_C_THREADS), 0, st>>>(
+                        bufs, c->lists[slot][2].template as<Desc>(), cnt[2], rows, isa_rw, isa_ro, grp_out, mode, n, h, counters);
+    }
+
     Lists make_lists(int slot) const
     {
         Lists L;
@@ -971,15 +983,9 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         R.gather = GatherSpec{fuse ? d_text : nullptr, n, ks};
         // tandem repeats: tie groups that are one arithmetic progression of positions are finished at once (k_chain_resolve)
         if constexpr (!W) {
-            if (R.mode == MODE_ISA && depth <= 4096 && n < 0x7fffff00ull && getenv("MSUFSORT_HIP_NO_CHAINS") == nullptr) {
-                const u32 nAc = c->h_counters[curL], nBc = c->h_counters[curL + 1], nCc = c->h_counters[curL + 2];
-                if (nAc) k_chain_resolve<CLS_A_THREADS, CLS_A_ITEMS><<<dim3(std::min<u32>(nAc, 8192u)), dim3(CLS_A_THREADS), 0, st>>>(
-                             bufs, c->lists[cur][0].template as<Desc>(), nAc, sa_local, R.isa32, d_text, (u32)n, (u32)depth, counters);
-                if (nBc) k_chain_resolve<CLS_B_THREADS, CLS_B_ITEMS><<<dim3(std::min<u32>(nBc, 2048u)), dim3(CLS_B_THREADS), 0, st>>>(
-                             bufs, c->lists[cur][1].template as<Desc>(), nBc, sa_local, R.isa32, d_text, (u32)n, (u32)depth, counters);
-                if (nCc) k_chain_resolve<CLS_C_THREADS, CLS_C_ITEMS><<<dim3(std::min<u32>(nCc, 512u)), dim3(CLS_C_THREADS), 0, st>>>(
-                             bufs, c->lists[cur][2].template as<Desc>(), nCc, sa_local, R.isa32, d_text, (u32)n, (u32)depth, counters);
-                DBG("k_chain_resolve");
+            if (R.mode == MODE_ISA && depth <= 4096) {
+                const u32 cl[3] = {c->h_counters[curL], c->h_counters[curL + 1], c->h_counters[curL + 2]};
+                R.chain_resolve(cur, cl, sa_local, R.isa32, (const u32*)nullptr, n, depth);
             }
         }
         if (!fuse && actP) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
@@ -1032,7 +1038,7 @@ Digits plan_digits(u64 n)
 // Returns the number of rows that were still tied BEFORE the pass in *tied_in (0: nothing to do).
 template <bool W>
 int double_pass(msufsort_hip_ctx* c, u64 n, typename Wd<W>::sa_t* d_sa_slice, u32* d_grp_slice, u64 rows, const u32* act, u32 nact,
-                const typename Wd<W>::sa_t* d_isa, u64 h, u32 dig_shift, u32 dig_mask, int verbose, u64* tied_in)
+                const typename Wd<W>::sa_t* d_isa, u64 h, u32 dig_shift, u32 dig_mask, int verbose, u64* tied_in, bool first_pass)
 {
     hipStream_t st = c->stream;
     if (rows > 0xfffffff0ull) { set_error("slice of %llu rows: too large for one shard", (unsigned long long)rows); return MSUFSORT_HIP_ERR_TOO_LARGE; }
@@ -1060,6 +1066,13 @@ int double_pass(msufsort_hip_ctx* c, u64 n, typename Wd<W>::sa_t* d_sa_slice, u3
     const u64 nseg = (u64)c->h_counters[C_LIST0] + c->h_counters[C_LIST0 + 1] + c->h_counters[C_LIST0 + 2] + c->h_counters[C_LIST0 + 3];
     *tied_in = actP + nseg;            // (a count of pool rows + segments: only its being zero matters)
     if (actP + nseg == 0) return MSUFSORT_HIP_OK;
+    // tandem repeats: groups that are one arithmetic progression of positions are finished before anything is gathered for
+    // them (first digit pass of a step only: the second pass sorts inside the groups the first one left)
+    if (first_pass && h <= 4096) {
+        const u32 cl[3] = {c->h_counters[C_LIST0], c->h_counters[C_LIST0 + 1], c->h_counters[C_LIST0 + 2]};
+        R.chain_resolve(0, cl, d_sa_slice, (typename Wd<W>::sa_t*)nullptr, d_isa, n, h);
+        DBG("k_chain_resolve");
+    }
     KeySpec ks{};
     ks.depth = h; ks.sigma = 256; ks.cpk = W ? 3u : 4u; ks.zlow = 0; ks.dig_shift = dig_shift; ks.dig_mask = dig_mask;
     if (actP) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[0].as<u64>(), counters, (u32)C_POOL0,
@@ -1109,7 +1122,7 @@ int double_sort(msufsort_hip_ctx* c, ActiveSet& as, u64 n, typename Wd<W>::sa_t*
     u64 t0 = 0;
     for (u32 p = 0; p < dg.npass; ++p) {
         u64 t = 0;
-        TRY((double_pass<W>(c, n, d_sa_slice, d_grp_slice, rows, act, nact, d_isa, h, dg.shift[p], dg.mask[p], verbose, &t)));
+        TRY((double_pass<W>(c, n, d_sa_slice, d_grp_slice, rows, act, nact, d_isa, h, dg.shift[p], dg.mask[p], verbose, &t, p == 0)));
         if (p == 0) t0 = t;
         if (t == 0) break;
     }

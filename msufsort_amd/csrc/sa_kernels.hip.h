@@ -2400,102 +2400,106 @@ __global__ __launch_bounds__(256) void k_apply_updates(const u64* __restrict__ u
 // ------------------------------------------------------------------------------------------------
 // Tandem repeats (the reference's partition_tandem_repeats / complete_tandem_repeats, cpp:316-484, in the shape that suits
 // prefix doubling).  At doubling offset h a tie group = all suffixes that share their first h characters.  If two members
-// sit P <= h positions apart, the text has period P from the first of them to h characters behind the second; if the members of the group are ONE arithmetic
-// progression i0, i0 + P, ..., i0 + (len-1) P (a single run of a repeated unit: the usual case for units of ten characters
-// and more), their order is fixed by ONE character comparison: suffix(i) and suffix(i + P) agree as long as the repeat goes
-// on and first differ where it ends, e = first position with T[e] != T[e - P] - there suffix(i + P) holds T[e] and suffix(i)
-// still holds the unit's T[e - P].  So all of them are ordered by position, descending if T[e] < T[e - P], ascending
-// otherwise, and the run end lies less than P characters behind the h known to match from the last member (else that
-// member's successor would be in the group as well).  Doubling alone needs log2(run length / h) more rounds over the whole
-// group (DNA with tandem repeats: 78 % of all suffixes stay tied for eight rounds); this kernel finishes such a group at
-// once: final rows and ranks are written, the descriptor is neutralised (len = 0).
-// One workgroup per segment (persistent); membership tests go through the rank array: same group <=> same rank value
-// (MODE_ISA: every member of a segment emitted by the previous round holds 1 + the group's first row).
+// sit P <= h positions apart, the text has period P from the first of them to h characters behind the second.  If the members
+// of a group are ONE arithmetic progression i0, i0 + P, ..., last (a single run of a repeated unit: the usual case for units
+// of ten characters and more), the text repeats with period P from i0 to last + h, so suffix(i) and suffix(i + P) agree until
+// the repeat ends and first differ at the same text position for EVERY member - the members are ordered by position, all
+// one way, and the way is the order of suffix(last + P) against suffix(last): those two already differ inside their first h
+// characters (last + P is not in the group), so the rank array knows it.  No character is read.
+// Doubling alone needs log2(run length / h) more rounds over the whole group (DNA with tandem repeats: 78 % of all suffixes
+// stay tied for eight rounds); this kernel finishes such a group at once: final rows (and ranks, or group heads) are written
+// and the descriptor is neutralised (len = 0).
+// One workgroup per segment (persistent).  Membership tests go through the rank array: same group <=> same rank value.
+//   MODE_ISA   (narrow, in place): members of a segment emitted by the previous round hold 1 + the group's first row;
+//              ranks are updated here, the finished records are marked for k_refill.
+//   MODE_DEFER (sharded / wide): the rank array is read-only during a step; grp_out[row] = row marks the rows final and the
+//              rank updates are derived from that afterwards (k_emit_updates).
 // ------------------------------------------------------------------------------------------------
-template <int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS) void k_chain_resolve(RecBufs bufs, Desc* __restrict__ list, u32 nseg, u32* __restrict__ sa_out,
-                                                           u32* __restrict__ isa, const u8* __restrict__ text, u32 n, u32 h,
-                                                           u32* __restrict__ counters)
+template <int THREADS, int ITEMS, bool W>
+__global__ __launch_bounds__(THREADS) void k_chain_resolve(RecBufs bufs, Desc* __restrict__ list, u32 nseg, typename Wd<W>::sa_t* __restrict__ sa_rows,
+                                                           typename Wd<W>::sa_t* __restrict__ isa_rw, const typename Wd<W>::sa_t* __restrict__ isa_ro,
+                                                           u32* __restrict__ grp_out, u32 mode, u64 n, u64 h, u32* __restrict__ counters)
 {
-    __shared__ u32 s_P, s_nf, s_tail, s_res;
+    typedef typename Wd<W>::sa_t idx_t;
+    constexpr idx_t NONE = ~(idx_t)0;
+    const idx_t* isa = mode == MODE_ISA ? isa_rw : isa_ro;
+    __shared__ u32 s_P, s_nf;
+    __shared__ unsigned long long s_tail;
     const u32 t = threadIdx.x;
     const u32 rank0 = counters[C_RANK0];
-    const u32 wmax = h < 64u ? h : 64u;                      // steps looked for (the argument needs P <= h only: the repeat's end then
-                                                             // lies in [last + h, last + h + P))
+    const u32 wmax = h < 64u ? (u32)h : 64u;                 // steps looked for
     for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
         const Desc d = list[s];
         __syncthreads();
         if (d.len < 4u || d.len > (u32)(THREADS * ITEMS) || (d.buf & DESC_STALE)) continue;      // (workgroup-uniform)
-        u64* src = bufs.p[d.buf & 3u] + d.rec_off;
-        if (t == 0) { s_P = 0xffffffffu; s_nf = 0; s_tail = 0xffffffffu; s_res = 0; }
+        if (t == 0) { s_P = 0xffffffffu; s_nf = 0; s_tail = ~0ull; }
         __syncthreads();
-        u32 idx[ITEMS];
+        idx_t idx[ITEMS];
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { const u32 p = (u32)j * THREADS + t; idx[j] = p < d.len ? (u32)src[p] : 0xffffffffu; }
-        const u32 g0 = rank0 + d.sa_off + 1u;                 // the rank every member holds
-        // 1. the period: the first 64 members look for their next member within wmax positions
+        for (int j = 0; j < ITEMS; ++j) { const u32 p = (u32)j * THREADS + t; idx[j] = p < d.len ? sa_rows[d.sa_off + p] : NONE; }
+        const idx_t i00 = sa_rows[d.sa_off];
+        if ((u64)i00 >= n) continue;
+        const idx_t g0 = isa[i00];                            // the rank every member holds
+        // 1. the step: the first 64 members look for their next member within wmax positions
         if (t < 64u && t < d.len) {
-            const u32 i = idx[0];
+            const u64 i = idx[0];
             u32 found = 0xffffffffu;
-            if (isa[i] == g0) {
+            if (i < n && isa[i] == g0) {
                 for (u32 q0 = 1; q0 <= wmax && found == 0xffffffffu; q0 += 8) {
-                    u32 v[8];
+                    idx_t v[8];
 #pragma unroll
-                    for (u32 k = 0; k < 8; ++k) v[k] = (q0 + k <= wmax && i + q0 + k < n) ? isa[i + q0 + k] : 0u;
+                    for (u32 k = 0; k < 8; ++k) v[k] = (q0 + k <= wmax && i + q0 + k < n) ? isa[i + q0 + k] : (idx_t)0;
 #pragma unroll
                     for (u32 k = 0; k < 8; ++k) if (found == 0xffffffffu && v[k] == g0) found = q0 + k;
                 }
-            } else found = 0u;                                // (the segment does not hold its first row as rank: leave it alone)
+            } else found = 0u;                                // (not the ranks this kernel expects: leave the segment alone)
             if (found != 0xffffffffu) atomicMin(&s_P, found);
         }
         __syncthreads();
         const u32 P = s_P;
         if (P == 0u || P == 0xffffffffu) continue;
         // 2. one progression?  every member but one must have its successor i + P in the group
-        u32 nf = 0, tail = 0xffffffffu;
+        u32 nf = 0;
+        u64 tail = ~0ull;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j)
-            if (idx[j] != 0xffffffffu) {
-                const bool f = idx[j] + P < n && isa[idx[j] + P] == g0;
+            if (idx[j] != NONE) {
+                const bool f = (u64)idx[j] + P < n && isa[(u64)idx[j] + P] == g0;
                 nf += f;
-                if (!f) tail = idx[j];
+                if (!f) tail = (u64)idx[j] < n ? (u64)idx[j] : 0ull;      // (0: no progression can end there)
             }
         nf = wave_sum(nf);
         if ((t & 63u) == 0 && nf) atomicAdd(&s_nf, nf);
-        if (tail != 0xffffffffu) atomicMin(&s_tail, tail);    // (more than one: rejected by the count)
+        if (tail != ~0ull) atomicMin(&s_tail, (unsigned long long)tail);      // (more than one: rejected by the count)
         __syncthreads();
         if (s_nf != d.len - 1u) continue;
-        const u32 last = s_tail, first = last - (d.len - 1u) * P;
-        // 3. where the repeat ends behind the last member: the direction of the whole progression
-        if (t == 0) {
-            u32 res = 0;
-            for (u32 j = 0; j < P && res == 0; ++j) {
-                const u64 pos = (u64)last + h + j;
-                const u32 c1 = pos < n ? text[pos] : 0u, c0 = pos - P < n ? text[pos - P] : 0u;
-                if (c1 != c0) res = c1 < c0 ? 1u : 2u;        // 1: later positions are smaller (descending), 2: ascending
-            }
-            s_res = res;
-        }
-        __syncthreads();
-        const u32 res = s_res;
-        if (res == 0) continue;
-        // 4. final rows and ranks
+        const u64 last = s_tail;
+        if (last < (u64)(d.len - 1u) * P) continue;
+        const u64 first = last - (u64)(d.len - 1u) * P;
+        // 3. the direction: suffix(last + P) against suffix(last), as the ranks have it (rank 0 behind the end of the text)
+        const idx_t rx = last + P < n ? isa[last + P] : (idx_t)0;
+        const bool descending = rx < g0;                      // later positions are the smaller suffixes
+        // 4. final rows
         bool okp = true;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j)
-            if (idx[j] != 0xffffffffu) {
-                const u32 off = idx[j] - first, k = off / P;
-                okp &= idx[j] >= first && k * P == off && k < d.len;
+            if (idx[j] != NONE) {
+                const u64 off = (u64)idx[j] - first;
+                const u32 k = (u32)(off / P);
+                okp &= (u64)idx[j] >= first && (u64)k * P == off && k < d.len;
             }
         if (!__syncthreads_and(okp)) continue;                // (not the progression it seemed to be: doubling goes on)
+        u64* src = bufs.p[d.buf & 3u] + d.rec_off;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j)
-            if (idx[j] != 0xffffffffu) {
-                const u32 k = (idx[j] - first) / P;
-                const u32 r = res == 1u ? d.len - 1u - k : k;
-                sa_out[d.sa_off + r] = idx[j];
-                isa[idx[j]] = rank0 + d.sa_off + r + 1u;
-                src[(u32)j * THREADS + t] = ~0ull;            // a finished record: k_refill, which sweeps the whole record array, skips it
+            if (idx[j] != NONE) {
+                const u32 k = (u32)(((u64)idx[j] - first) / P);
+                const u32 r = descending ? d.len - 1u - k : k;
+                sa_rows[d.sa_off + r] = idx[j];
+                if (mode == MODE_ISA) {
+                    isa_rw[idx[j]] = (idx_t)(rank0 + d.sa_off + r + 1u);
+                    src[(u32)j * THREADS + t] = ~0ull;        // a finished record: k_refill, which sweeps the whole record array, skips it
+                } else grp_out[d.sa_off + r] = d.sa_off + r;
             }
         if (t == 0) { list[s].len = 0; atomicAdd(&counters[C_CHAIN], d.len); }
     }
