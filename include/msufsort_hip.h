@@ -91,7 +91,9 @@ typedef struct msufsort_hip_timings {
                                   hist16_ms above is then the k_hist16 launch inside it */
     int64_t fallbacks;         /* bit 0: a two-stage attempt was abandoned and the sort-all path ran (deep ties / look-back time-out /
                                   policy decline after the front end); bits 8..: reason code of the abandon */
-    int64_t reserved[6];
+    int64_t progression_suffixes; /* suffixes finished as arithmetic progressions of positions (tandem repeats, k_chain_resolve) by the
+                                  in-place doubling of the last build */
+    int64_t reserved[5];
 } msufsort_hip_timings;
 
 int msufsort_hip_device_count(void);

@@ -895,7 +895,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
                     round, R.mode == MODE_TEXT ? "text" : "isa", (unsigned long long)depth, R.nA, R.nB, R.nC, R.nP, (unsigned long long)actP, (unsigned long long)actS,
                     c->h_counters[nb_base], c->h_counters[nb_base + 1], c->h_counters[nb_base + 2], c->h_counters[nb_base + 3]);
         if (verbose && c->h_counters[C_CHAIN]) fprintf(stderr, "[msufsort_hip] round %d: %u suffixes finished as arithmetic progressions (tandem repeats) so far\n", round, c->h_counters[C_CHAIN]);
-        if (verbose && (c->h_counters[C_FBB] || c->h_counters[C_FBC]))
+        if (verbose && R.mode == MODE_TEXT && R.wants_fast() && (c->h_counters[C_FBB] || c->h_counters[C_FBC]))
             fprintf(stderr, "[msufsort_hip] round %d: the bucket sort handed %u class-B and %u class-C segments to k_sort_mid\n", round, c->h_counters[C_FBB], c->h_counters[C_FBC]);
         if (round == 0) tm.unresolved_after_round0 = (int64_t)(actP + actS);
         if (actP + actS == 0) break;
@@ -1001,6 +1001,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     HIP_TRY(hipEventRecord(c->ev[5], st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
+    tm.progression_suffixes = (int64_t)c->h_counters[C_CHAIN];
     float ms_ = 0;
     (void)hipEventElapsedTime(&ms_, c->ev[0], c->ev[5]); tm.total_ms = ms_;
     (void)hipEventElapsedTime(&ms_, c->ev[0], c->ev[1]); tm.hist16_ms = ms_;

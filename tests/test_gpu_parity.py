@@ -232,6 +232,63 @@ def test_logical_shards_deep_ties(M, oracle_mod, shards):
         assert (sa.cpu().numpy() == _want(oracle_mod, t)).all()
 
 
+def _tandem_edge_inputs():
+    """Repeats of a unit with every feature the progression shortcut (k_chain_resolve) has to get right: ends smaller / larger
+    than the unit's continuation, a repeat at the very end of the text, in front of trailing zero bytes, the same unit in several
+    runs (several progressions in one tie group: must be left to the doubling), periods around the 64-position window, a short
+    repeat nested in a longer period, runs of one byte."""
+    rng = np.random.default_rng(17)
+    rnd = lambda k: rng.integers(97, 101, k, dtype=np.uint8)          # noqa: E731  (a, b, c, d)
+    out = []
+    lo, hi = np.frombuffer(b"a", np.uint8), np.frombuffer(b"z", np.uint8)
+    for p in (1, 2, 3, 7, 31, 32, 33, 63, 64, 65, 100):
+        u = rnd(p)
+        u[0] = 98                                                      # 'b'
+        # the same unit three times (several progressions per tie group) ...
+        out.append(np.concatenate([rnd(500), np.tile(u, 600 // p + 40), lo, rnd(300), np.tile(u, 900 // p + 50), hi, rnd(200), np.tile(u, 300 // p + 30)]))
+        # ... and three different units (byte values of their own: one progression per group), ending low, high, and with the text
+        v, w = u + 10, u + 20
+        out.append(np.concatenate([rnd(400), np.tile(u, 700 // p + 40), lo, rnd(300), np.tile(v, 900 // p + 50), hi, rnd(200), np.tile(w, 500 // p + 40)]))
+    u = rnd(5)
+    out.append(np.concatenate([rnd(100), np.tile(u, 400), np.zeros(7, np.uint8)]))                          # repeat, then trailing zeros
+    out.append(np.concatenate([np.tile(np.frombuffer(b"ababac", np.uint8), 300), rnd(50), np.tile(np.frombuffer(b"ab", np.uint8), 500)]))
+    out.append(np.concatenate([np.full(3000, 99, np.uint8), rnd(10), np.full(5000, 99, np.uint8), np.frombuffer(b"a", np.uint8), np.full(2000, 99, np.uint8)]))
+    out.append(np.tile(np.concatenate([np.tile(rnd(9), 40), rnd(3)]), 25))                                  # a repeat of repeats
+    return out
+
+
+def test_tandem_progressions(M, oracle_mod, monkeypatch):
+    """Tie groups that are one arithmetic progression of positions are finished at once instead of by log2(run / h) doubling
+    rounds (reference partition_tandem_repeats / complete_tandem_repeats, cpp:316-484): in place, in the deferred doubling of
+    logical shards, and in the wide engine - rows identical to the reference's and to a build without the shortcut."""
+    import torch
+    hits = []
+    for t in _tandem_edge_inputs():
+        n = t.size
+        want = _want(oracle_mod, t)
+        d = _dev(M, t)
+        ctx = M.DeviceContext(0)
+        sa = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        taken = 0
+        for kw in ({"text_rounds": 1}, {"text_rounds": 3}, {"text_rounds": 1, "logical_shards": 3}):
+            sa.fill_(-1)
+            ctx.make_sa(d, n, sa, two_stage=-1, **kw)
+            assert ctx.timings().doubling_rounds >= 1
+            assert (sa.cpu().numpy() == want).all(), (n, kw)
+            taken += ctx.timings().progression_suffixes
+        hits.append(taken)
+        s64 = torch.full((n + 1,), -1, dtype=torch.int64, device="cuda")
+        ctx.make_sa_i64(d, n, s64, force_wide=True, n_shards=2, text_rounds=1)
+        assert (s64.cpu().numpy() == want).all(), (n, "wide")
+        monkeypatch.setenv("MSUFSORT_HIP_NO_CHAINS", "1")
+        sa.fill_(-1)
+        ctx.make_sa(d, n, sa, two_stage=-1, text_rounds=1)
+        monkeypatch.delenv("MSUFSORT_HIP_NO_CHAINS")
+        assert (sa.cpu().numpy() == want).all(), (n, "no shortcut")
+        assert ctx.timings().progression_suffixes == 0
+    assert sum(h > 0 for h in hits) >= 10, hits          # the shortcut really ran on most of these inputs
+
+
 @pytest.mark.parametrize("shards", [2, 3])
 def test_sharded_doubling_pieces(M, oracle_mod, shards):
     """The same flow through the per-shard C-ABI pieces a multi-process job uses (msufsort_amd/dist.py): shard build with
