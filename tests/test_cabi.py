@@ -62,3 +62,21 @@ def test_generators_deterministic():
     assert a.size == 5000 and set(np.unique(a)) <= set(b"abcdefghijklmnopqrstuvwxyz \n")
     d = gen.dna_tandem_bytes(50000, 9)
     assert set(np.unique(d)) <= set(b"ACGT")
+
+
+def test_bench_refuses_ranks_without_gpus():
+    """`python bench.py --gpus N` starts its own ranks - and must refuse, loudly and before touching HIP, when the box has fewer
+    GPUs than ranks (a silent one-GPU run is what the round-2 review found)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("MSUFSORT_BENCH_ONE_DEVICE", "WORLD_SIZE", "RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "4096", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
+    # a WORLD_SIZE that contradicts --gpus is an error as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
