@@ -143,9 +143,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
             __syncthreads();                                                        // (1)
         }
         BPROF(0);
-#ifndef BITS_LATE_LOADS
         BITS_LOAD(0, LB);
-#endif
         const u32 shw = sh + 2u;                                 // byte offset of a key's word: (key >> shw) & ~3
 #define BITS_WORD(k) (*reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(bw) + (((k) >> shw) & 0x3fffcu)))
         if (ok) {                                                // ---- A: one add per record, nothing returned
@@ -159,9 +157,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
             __syncthreads();                                                        // (2)
         }
         BPROF(1);
-#ifndef BITS_LATE_LOADS
         BITS_LOAD(LB, 2 * LB);
-#endif
         if (ok) {                                                // ---- S: first row of every word
             // thread t owns the word quads (k THREADS + t), k = 0..3: 16-byte LDS accesses, consecutive lanes on consecutive quads
             uint4 q4[4];
@@ -202,9 +198,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
             __syncthreads();                                                        // (4)
         }
         BPROF(2);
-#ifndef BITS_LATE_LOADS
         BITS_LOAD(2 * LB, 3 * LB);
-#endif
         u32 nl = 0;
         if (ok && misc[1]) ok = false;
         if (ok) {                                                // ---- B: final rows of the clean words' records
@@ -253,11 +247,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
             if (misc[1]) ok = false;                             // skewed keys: k_sort_mid takes the segment
         }
         BPROF(3);
-#ifndef BITS_LATE_LOADS
         BITS_LOAD(3 * LB, 4 * LB);
-#else
-        BITS_LOAD(0, 3 * LB);          // experiment: the records of the next segment are requested only now, when this one's are dead
-#endif
         if (ok && nl) {                                          // ---- D: the records of the dirty words, one list entry per lane
             u32 dk[LPT], di[LPT], db[LPT], dc[LPT], ds[LPT];
 #pragma unroll
@@ -326,11 +316,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
             if (misc[1] || misc[4] > (u32)TL) ok = false;
         }
         BPROF(7);
-#ifndef BITS_LATE_LOADS
         BITS_LOAD(4 * LB, NL);
-#else
-        BITS_LOAD(3 * LB, NL);
-#endif
         if (ok) {                                                // ---- rows out
             const u32 nt = misc[4];
             if (t == 0 && nt != 0) {
