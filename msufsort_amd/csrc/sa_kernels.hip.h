@@ -120,7 +120,9 @@ enum {
 #define P1_TILE (P1_THREADS * P1_ITEMS)      // 8192 records per tile
 #define CUR0_STRIDE 64                       // u32 stride of the 256 first-byte cursors: one 256-B line each,
                                              // so the per-tile claim atomics spread over memory channels
-#define S0_POS 8                             // level-0 scatter: text positions per thread
+#ifndef S0_POS
+#define S0_POS 8                             // level-0 scatter: text positions per thread (8 or 16)
+#endif
 #ifndef S0_THREADS
 #define S0_THREADS 1024
 #endif
@@ -682,8 +684,9 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
     }
     u32 rank[S0_POS];
     u32 validmask = 0;
-    u32 selmask = 0xffu;                 // (S0_POS == 8: the positions of one thread are one byte of the bitmap)
-    if (sel_bits) selmask = base < m ? sel_bits[base >> 3] : 0u;
+    static_assert(S0_POS == 8 || S0_POS == 16, "the positions of one thread are one or two bytes of the bitmap");
+    u32 selmask = S0_POS == 8 ? 0xffu : 0xffffu;
+    if (sel_bits) selmask = base < m ? (S0_POS == 8 ? (u32)sel_bits[base >> 3] : (u32)reinterpret_cast<const u16*>(sel_bits)[base >> 4]) : 0u;
 #pragma unroll
     for (int j = 0; j < S0_POS; ++j) {
         const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
