@@ -195,6 +195,24 @@ __device__ __forceinline__ u32 wave_excl_scan(u32 v, u32& total)
     return x - v;
 }
 
+// the same scan for max (unsigned, identity 0) and for bitwise or; lane 63 holds the wave's result
+#define DPP_SCAN_STEP(OP, ctrl, rmask, bc) { const u32 o_ = (u32)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, bc); v = OP; }
+__device__ __forceinline__ u32 wave_incl_scan_max_dpp(u32 v)
+{
+    DPP_SCAN_STEP(o_ > v ? o_ : v, 0x111, 0xf, true) DPP_SCAN_STEP(o_ > v ? o_ : v, 0x112, 0xf, true)
+    DPP_SCAN_STEP(o_ > v ? o_ : v, 0x114, 0xf, true) DPP_SCAN_STEP(o_ > v ? o_ : v, 0x118, 0xf, true)
+    DPP_SCAN_STEP(o_ > v ? o_ : v, 0x142, 0xa, false) DPP_SCAN_STEP(o_ > v ? o_ : v, 0x143, 0xc, false)
+    return v;
+}
+__device__ __forceinline__ u32 wave_or(u32 v)
+{
+    DPP_SCAN_STEP(o_ | v, 0x111, 0xf, true) DPP_SCAN_STEP(o_ | v, 0x112, 0xf, true)
+    DPP_SCAN_STEP(o_ | v, 0x114, 0xf, true) DPP_SCAN_STEP(o_ | v, 0x118, 0xf, true)
+    DPP_SCAN_STEP(o_ | v, 0x142, 0xa, false) DPP_SCAN_STEP(o_ | v, 0x143, 0xc, false)
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+#undef DPP_SCAN_STEP
+
 __device__ __forceinline__ u32 wave_sum(u32 v)
 {
 #pragma unroll
@@ -1308,8 +1326,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; if ((u32)j < rpw && p < len) diff |= key[j] ^ key0; }
     }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) diff |= __shfl_xor(diff, s, 64);
+    diff = wave_or(diff);
     if (lane == 0 && diff) atomicOr(&misc[0], diff);
     __syncthreads();
     diff = misc[0] & (0xffffffffu << KL);           // (wide: the index byte never decides an LSD pass; equal keys keep their order)
@@ -1418,12 +1435,10 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
             mx = vs[k] > mx ? vs[k] : mx;
             mn = ve[k] < mn ? ve[k] : mn;
         }
-        u32 pmx = mx, smn = mn;          // inclusive scans over lanes: prefix max, suffix min
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const u32 a = __shfl_up(pmx, dlt, 64); if ((int)lane >= dlt) pmx = a > pmx ? a : pmx;
-            const u32 c = __shfl_down(smn, dlt, 64); if ((int)lane + dlt < 64) smn = c < smn ? c : smn;
-        }
+        // inclusive scans over lanes: prefix max, suffix min (= complement of the prefix max of the complements, lanes reversed):
+        // DPP scans, three lane permutations instead of fourteen
+        const u32 pmx = wave_incl_scan_max_dpp(mx);
+        const u32 smn = ~(u32)__shfl(wave_incl_scan_max_dpp(~(u32)__shfl(mn, 63 - (int)lane, 64)), 63 - (int)lane, 64);
         u32 run_s = __shfl_up(pmx, 1, 64); if (lane == 0) run_s = 0;                 // exclusive prefix max
         u32 run_e = __shfl_down(smn, 1, 64); if (lane == 63) run_e = 0xffffffffu;    // exclusive suffix min
 #pragma unroll
