@@ -481,6 +481,9 @@ def main():
     dist.all_gather(per, x)                       # per-rank figures: is one shard slower than the others?
     dist.all_reduce(x, op=dist.ReduceOp.MAX)
     latency = {"latency_ms": round(float(x[0]), 3), "exchange_ms": round(float(x[1]), 3), "sort_ms": round(float(x[2]), 3),
+               # what the sorts alone sustain (every rank keeps its slice, nothing is gathered): NOT `value` - every GPU must take in
+               # (N-1)/N of the 4(n+1)-byte array over xGMI for the all-gatherv the metric asks for, and that, not the sort, bounds the step
+               "sorts_only_MBps": round(n / (float(x[2]) * 1e-3) / 1e6, 1) if float(x[2]) > 0 else None,
                "per_rank": {"latency_ms": [round(float(q[0]), 3) for q in per], "exchange_ms": [round(float(q[1]), 3) for q in per],
                             "sort_ms": [round(float(q[2]), 3) for q in per],
                             "rows": [int(bounds[g + 1] - bounds[g]) for g in range(world)]}}
