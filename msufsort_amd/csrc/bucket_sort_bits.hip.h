@@ -10,7 +10,7 @@
 // INSTRUCTIONS PER RECORD, and dependent LDS round trips per wave:
 //
 //   bitmap rank.  The kbits key bits that can still differ are cut down to 18 (16 for the small shape): 2^18 buckets for at
-//   most 17,408 records, one BIT each.  A 32-bit LDS word describes 16 neighbouring buckets.
+//   most 18,432 records, one BIT each.  A 32-bit LDS word describes 16 neighbouring buckets.
 //     A  every record ADDS  (1 << bucket & 15) | 1 << 20  to its word - one non-returning LDS atomic, nothing to wait for:
 //        bits 0..15 collect the buckets, bits 20..31 count the arrivals, bits 16..19 catch the carries of colliding adds
 //        (a second arrival in a bucket flips bits upwards instead of setting one: popcount(bits 0..19) < arrivals).
@@ -24,17 +24,17 @@
 //        counting smaller keys among the posted ones; equal keys are tie runs and go to the next round like everywhere else.
 //   Rows leave coalesced, as aligned 8-byte stores.  The next segment's records are loaded while this one is sorted.
 //
-// LDS per workgroup (1024 threads, 16,384 words, segments up to 17,408 records): words 64 KiB, rows 68 KiB, dirty list
-// 16 KiB, tie list 1.5 KiB = 150 KiB: one workgroup per CU.  Static LDS: every address is a compile-time constant.
+// LDS per workgroup (1024 threads, 16,384 words, segments up to 18,432 records): words 64 KiB, rows 72 KiB, dirty list
+// 20 KiB, tie list 1.5 KiB = 158 KiB: one workgroup per CU.  Static LDS: every address is a compile-time constant.
 //
 // Handed back to k_sort_mid through fb_list (as k_sort_fast2 does): segments longer than LEN_MAX, more than 30 varying key
 // bits, a dirty list or tie list that overflows (skewed keys), runs of more than 255 equal keys.
 #pragma once
 
-// class C: 1024 threads x 18 records, segments up to 17,408 records, 2048 dirty-list entries
-#define BITS_C_SHAPE 1024, 18, 17408, 2048, 128
-// class B: 256 threads x 18 records
-#define BITS_B_SHAPE 256, 18, 4352, 512, 64
+// class C: 1024 threads x 18 records = every class-C segment (18,432), 2560 dirty-list entries (a full segment: 2030 +- 80)
+#define BITS_C_SHAPE 1024, 18, 18432, 2560, 128
+// class B: 256 threads x 18 records = every class-B segment (4608), 640 dirty-list entries; 40,912 B of LDS: four workgroups per CU
+#define BITS_B_SHAPE 256, 18, 4608, 640, 32
 
 // Diagnostic build (-DBITS_PROF): clock64() per phase, summed over the workgroups' first threads, printed by the engine.
 #ifdef BITS_PROF
@@ -45,16 +45,16 @@ __device__ unsigned long long g_bits_prof[16];
 #endif
 
 template <int THREADS, int ITEMS, int LEN_MAX, int LCAP, int TL>
-__global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+__global__ __launch_bounds__(THREADS, 1024 / THREADS) void k_sort_bits(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                        u32* __restrict__ sa_out, Emit em, u32* __restrict__ counters,
                                                        u32* __restrict__ fb_list, u32 fb_cnt_idx)
 {
     constexpr int W = THREADS / 64;
     constexpr int NW = THREADS * 16;                  // LDS words, 16 buckets each; a thread scans 4 quads of words
     constexpr int NL = ITEMS / 2;
-    constexpr int LPT = LCAP / THREADS;               // dirty-list entries per thread
+    constexpr int LPT = (LCAP + THREADS - 1) / THREADS;      // dirty-list entries per thread
     constexpr int BATCH = 6;                          // LDS reads in flight per lane in phase B
-    static_assert(ITEMS % 2 == 0 && ITEMS % BATCH == 0 && LCAP % THREADS == 0 && (THREADS & (THREADS - 1)) == 0 && W * 4 <= 64, "shapes");
+    static_assert(ITEMS % 2 == 0 && ITEMS % BATCH == 0 && (THREADS & (THREADS - 1)) == 0 && W * 4 <= 64, "shapes");
     static_assert(LEN_MAX <= THREADS * ITEMS && LEN_MAX + 64 < 32768, "segment length limit (rows are 15-bit fields)");
     constexpr u32 GB = THREADS == 1024 ? 18u : THREADS == 512 ? 17u : THREADS == 256 ? 16u : THREADS == 128 ? 15u : 14u;      // log2(buckets)
     static_assert((1u << GB) == (u32)NW * 16u, "GB");
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
                 }
             }
             __syncthreads();                                                        // (5)
-            nl = misc[0];
+            nl = __builtin_amdgcn_readfirstlane(misc[0]);      // (uniform: list passes nobody takes part in are branched over)
 #ifdef BITS_PROF
             if (threadIdx.x == 0) { prof_acc[10] += nl; prof_acc[12] += misc[1]; prof_acc[14] += nl > 1700u; prof_acc[15] += nl > 2048u; if (nl > 2048u && prof_acc[13] == 0) prof_acc[13] = ((unsigned long long)len << 32) | nl; }
 #endif
@@ -254,6 +254,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
             for (int i = 0; i < LPT; ++i) {
                 const u32 e = t + (u32)i * THREADS;
                 dk[i] = 0; di[i] = 0; db[i] = TRASH_ROW; dc[i] = 0; ds[i] = 0;
+                if ((u32)i * THREADS >= nl) continue;
                 if (e < nl) {
                     const uint2 r = lst[e];
                     dk[i] = r.x; di[i] = r.y;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_bits(RecBufs bufs, const Desc*
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {
                 dl[i] = 0; dq[i] = 0;
+                if ((u32)i * THREADS >= nl) continue;
                 const bool in = t + (u32)i * THREADS < nl;
                 // the first eight posted keys at once (a dirty word holds 3 records on average); what lies behind the word's
                 // rows is read too and masked

@@ -154,6 +154,29 @@ def _random_gpu(n, seed, dev):
     return out
 
 
+@pytest.mark.parametrize("mib", [285, 300, 1090, 1122, 1180])
+def test_bucket_sort_at_the_class_limits(mib):
+    """Random bytes whose 65,536 two-byte buckets sit at the limits of the LDS sorts: ~4560 records (fills the 256-thread
+    shape of k_sort_bits, limit 4608), ~4800 (just over: the 1024-thread shape a quarter full), ~17,440 and ~17,950 (fill the
+    1024-thread shape, limit 18,432: its dirty list is nearly full) and ~18,880 (over: one more partition level).  Rows
+    checked on the device; up to the class-C limit no segment may be handed back to k_sort_mid."""
+    import torch
+
+    import msufsort_amd as M
+    dev = torch.device("cuda")
+    n = (mib << 20) + 7919
+    d = _random_gpu(n, 1000 + mib, dev)
+    ctx = M.DeviceContext(0)
+    sa = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    ctx.make_sa(d, n, sa)
+    tm = ctx.timings()
+    assert int(sa[0]) == n and ctx.validate_sa(d, n, sa) == 0
+    if mib < 1150:
+        assert tm.bucket_sort_ms < 2 * 2.9 * n / (1 << 30) + 1.0, tm.bucket_sort_ms      # (no cliff next to the limits)
+    del sa, d
+    ctx.trim(); torch.cuda.empty_cache()
+
+
 def test_int32_limit_and_first_wide_size():
     """The two sides of the index-width boundary on random bytes: n = 2^31 - 2 (largest int32 build, narrow engine) and
     n = 2^31 + 5 through the int64 entry point (smallest input that MUST take the wide engine), both checked on device."""
