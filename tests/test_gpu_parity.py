@@ -597,6 +597,18 @@ def test_cached_contexts_and_trim(M, oracle_mod):
 
 
 # ---- two-stage build: B* sort + induction (reference cpp:1496-1555, 646-791, 867-1017) ----
+def _type_counts(t):
+    """(B suffixes, B* suffixes) by the reference's typing (cpp:1496-1555: suffix i is B when it is smaller than suffix i+1 -
+    the empty suffix is the smallest - and B* when suffix i+1 is not), vectorised: a run of equal bytes takes the type of its end."""
+    n = t.size
+    det = np.ones(n, bool); lt = np.zeros(n, bool)
+    det[:-1] = t[:-1] != t[1:]
+    lt[:-1] = t[:-1] < t[1:]
+    nxt = np.minimum.accumulate(np.where(det, np.arange(n), n)[::-1])[::-1]
+    is_b = lt[nxt]
+    return int(is_b.sum()), int((is_b[:-1] & ~is_b[1:]).sum())
+
+
 def _two_stage(M, oracle_mod, t, taken=True):
     import torch
     n = t.size
@@ -604,7 +616,10 @@ def _two_stage(M, oracle_mod, t, taken=True):
     d = _dev(M, t)
     sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
     ctx.make_sa(d, n, sa, two_stage=1)
-    assert (ctx.timings().bstar_suffixes > 0) == taken, "two-stage path %s" % ("declined" if taken else "taken")
+    tm = ctx.timings()
+    assert (tm.bstar_suffixes > 0) == taken, "two-stage path %s" % ("declined" if taken else "taken")
+    if taken:                        # k_types / k_hist16<2> against numpy
+        assert (tm.b_suffixes, tm.bstar_suffixes) == _type_counts(t)
     if n <= (4 << 20):
         want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
         assert (sa.cpu().numpy() == want).all()
