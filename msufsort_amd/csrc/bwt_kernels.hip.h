@@ -398,10 +398,14 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const u32* __restrict__ link,
         id[c] = IBWT_PULL(); my[c] = id[c]; len[c] = 0; cur[c] = id[c] < K ? ibwt_start(id[c], sent, kreg) : 0u;
         acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0;
     }
+#if defined(IBWT_EXP) && (IBWT_EXP & 1)      // experiment: no byte stores
+#define IBWT_FLUSH(c, at) do { if (acc[c][0] == 0x123456789abcull) segbuf[my[c]] = 1; acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0; } while (0)
+#else
 #define IBWT_FLUSH(c, at) do { uint4* o_ = reinterpret_cast<uint4*>(segbuf + (u64)my[c] * IBWT_CW + (at)); \
         o_[0] = make_uint4((u32)acc[c][0], (u32)(acc[c][0] >> 32), (u32)acc[c][1], (u32)(acc[c][1] >> 32)); \
         o_[1] = make_uint4((u32)acc[c][2], (u32)(acc[c][2] >> 32), (u32)acc[c][3], (u32)(acc[c][3] >> 32)); \
         acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0; } while (0)
+#endif
     for (;;) {
         bool any = false;
         u32 nx[IBWT_NCH];
@@ -412,8 +416,12 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const u32* __restrict__ link,
         for (int c = 0; c < IBWT_NCH; ++c) {
             if (id[c] >= K) continue;
             // symbol of the row I am leaving (independent of the load above)
+#if defined(IBWT_EXP) && (IBWT_EXP & 2)      // experiment: no symbol search
+            u32 sy = cur[c] & 255u;
+#else
             u32 sy = s_T[cur[c] >> shift];
             while (cur[c] >= s_C[sy + 1]) ++sy;
+#endif
             {
                 const u64 v = (u64)sy << (8u * (len[c] & 7u));
                 const u32 wsel = (len[c] >> 3) & 3u;

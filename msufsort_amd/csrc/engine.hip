@@ -886,14 +886,16 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
             const u64 pool_n = c->h_counters[R.cur ? C_POOL1 : C_POOL0];
             if (pool_n <= ms / 16 || round >= 12) R.deep_cap = 65536u;
         }
+        const auto round_t0 = std::chrono::steady_clock::now();
         TRY(R.levels_and_sorts());
+        const double round_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - round_t0).count();
         const int nxt = R.cur ^ 1;
         const u32 nb_base = nxt ? C_LIST1 : C_LIST0;
         const u64 actP = c->h_counters[nxt ? C_POOL1 : C_POOL0], actS = c->h_counters[nxt ? C_SEG1 : C_SEG0];
         if (verbose)
-            fprintf(stderr, "[msufsort_hip] round %d mode %s depth %llu: sorted A=%u B=%u C=%u tiny=%u -> next tiny=%llu seg=%llu (A=%u B=%u C=%u L=%u)\n",
+            fprintf(stderr, "[msufsort_hip] round %d mode %s depth %llu: sorted A=%u B=%u C=%u tiny=%u -> next tiny=%llu seg=%llu (A=%u B=%u C=%u L=%u), levels + sorts %.2f ms (host clock)\n",
                     round, R.mode == MODE_TEXT ? "text" : "isa", (unsigned long long)depth, R.nA, R.nB, R.nC, R.nP, (unsigned long long)actP, (unsigned long long)actS,
-                    c->h_counters[nb_base], c->h_counters[nb_base + 1], c->h_counters[nb_base + 2], c->h_counters[nb_base + 3]);
+                    c->h_counters[nb_base], c->h_counters[nb_base + 1], c->h_counters[nb_base + 2], c->h_counters[nb_base + 3], round_ms);
         if (verbose && c->h_counters[C_CHAIN]) fprintf(stderr, "[msufsort_hip] round %d: %u suffixes finished as arithmetic progressions (tandem repeats) so far\n", round, c->h_counters[C_CHAIN]);
         if (verbose && R.mode == MODE_TEXT && R.wants_fast() && (c->h_counters[C_FBB] || c->h_counters[C_FBC]))
             fprintf(stderr, "[msufsort_hip] round %d: the bucket sort handed %u class-B and %u class-C segments to k_sort_mid\n", round, c->h_counters[C_FBB], c->h_counters[C_FBC]);
