@@ -345,13 +345,17 @@ __device__ __forceinline__ u32 ibwt_start(u32 id, u32 sent, u32 kreg) { return i
 // the symbol of text position p is F[row(p)], and F is the sorted column - a search in the cumulative symbol counts C[],
 // which live in LDS (a 4096-entry coarse table gives the first candidate, then a step or two), computed while the load
 // of the next row is in flight.  Every lane runs IBWT_NCH independent chains (the reference interleaves many chains per
-// thread the same way, cpp:1922,1976-2018): the walk is bound by dependent random sector reads, and the loads in
-// flight per lane are what one lane can add to the memory-level parallelism.
+// thread, cpp:1922,1976-2018).  ONE since round 3: the walk is bound by dependent random sector reads, 2048 lanes per CU
+// with one chain each already reach what the chip gives (tools/microbench/exp_random_lines.hip), and the registers of a
+// second chain are better spent on 64-byte pieces.
 #ifndef IBWT_CW
 #define IBWT_CW 1024u
 #endif
 #ifndef IBWT_NCH
-#define IBWT_NCH 2
+#define IBWT_NCH 1                  // chains per lane (2048 lanes per CU walk one chain each: more adds nothing)
+#endif
+#ifndef IBWT_PIECE
+#define IBWT_PIECE 64u              // bytes per scattered store of a chain (a power of two, 16 .. 128): one whole 64-byte sector
 #endif
 __global__ __launch_bounds__(256) void k_ibwt_walk(const u32* __restrict__ link, const u32* __restrict__ offs /* [ntiles][256]: C[c] = offs[c] (tile 0) */,
                                                    u32 ntiles, u32 rows, u32 sent, u32 kreg, u32 K, u32 kt_cap,
@@ -390,21 +394,23 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const u32* __restrict__ link,
     const u32 shift = s_shift;
 #define IBWT_PULL() ([&]() { const u32 i_ = atomicAdd(&s_next, 1u); return i_ < s_end ? i_ : K; }())
     u32 id[IBWT_NCH], cur[IBWT_NCH], len[IBWT_NCH], my[IBWT_NCH];
-    u64 acc[IBWT_NCH][4];              // the last (len & 31) bytes met: bytes leave as aligned 32-byte pieces (one scattered
-                                       // write per 32 hops and chain: the walk is bound by random DRAM accesses, and every
-                                       // 8-byte store of round 1's version was one more of them - 31 -> 28 ms at 1 GiB)
+    constexpr u32 PW = IBWT_PIECE / 8u;          // 8-byte words per piece
+    u64 acc[IBWT_NCH][PW];             // the last (len % IBWT_PIECE) bytes met: bytes leave as aligned pieces - one whole 64-byte
+                                       // sector per 64 hops of a chain (the walk is bound by random DRAM accesses and every
+                                       // scattered store is one more: 8-byte stores 31 ms, 32-byte pieces 29.4, 64-byte 28.1)
 #pragma unroll
     for (int c = 0; c < IBWT_NCH; ++c) {
         id[c] = IBWT_PULL(); my[c] = id[c]; len[c] = 0; cur[c] = id[c] < K ? ibwt_start(id[c], sent, kreg) : 0u;
-        acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0;
+#pragma unroll
+        for (u32 w = 0; w < PW; ++w) acc[c][w] = 0;
     }
 #if defined(IBWT_EXP) && (IBWT_EXP & 1)      // experiment: no byte stores
-#define IBWT_FLUSH(c, at) do { if (acc[c][0] == 0x123456789abcull) segbuf[my[c]] = 1; acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0; } while (0)
+#define IBWT_FLUSH(c, at) do { if (acc[c][0] == 0x123456789abcull) segbuf[my[c]] = 1; _Pragma("unroll") for (u32 w_ = 0; w_ < PW; ++w_) acc[c][w_] = 0; } while (0)
 #else
 #define IBWT_FLUSH(c, at) do { uint4* o_ = reinterpret_cast<uint4*>(segbuf + (u64)my[c] * IBWT_CW + (at)); \
-        o_[0] = make_uint4((u32)acc[c][0], (u32)(acc[c][0] >> 32), (u32)acc[c][1], (u32)(acc[c][1] >> 32)); \
-        o_[1] = make_uint4((u32)acc[c][2], (u32)(acc[c][2] >> 32), (u32)acc[c][3], (u32)(acc[c][3] >> 32)); \
-        acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0; } while (0)
+        _Pragma("unroll") for (u32 w_ = 0; w_ < PW; w_ += 2) { \
+            o_[w_ >> 1] = make_uint4((u32)acc[c][w_], (u32)(acc[c][w_] >> 32), (u32)acc[c][w_ + 1], (u32)(acc[c][w_ + 1] >> 32)); \
+            acc[c][w_] = acc[c][w_ + 1] = 0; } } while (0)
 #endif
     for (;;) {
         bool any = false;
@@ -424,15 +430,15 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const u32* __restrict__ link,
 #endif
             {
                 const u64 v = (u64)sy << (8u * (len[c] & 7u));
-                const u32 wsel = (len[c] >> 3) & 3u;
-                acc[c][0] |= wsel == 0u ? v : 0ull; acc[c][1] |= wsel == 1u ? v : 0ull;
-                acc[c][2] |= wsel == 2u ? v : 0ull; acc[c][3] |= wsel == 3u ? v : 0ull;
+                const u32 wsel = (len[c] >> 3) & (PW - 1u);
+#pragma unroll
+                for (u32 w = 0; w < PW; ++w) acc[c][w] |= wsel == w ? v : 0ull;
             }
             ++len[c];
-            if ((len[c] & 31u) == 0) IBWT_FLUSH(c, len[c] - 32u);
+            if ((len[c] & (IBWT_PIECE - 1u)) == 0) IBWT_FLUSH(c, len[c] - IBWT_PIECE);
             const u32 r = nx[c];
             if (ibwt_marked(r, sent)) {
-                if (len[c] & 31u) IBWT_FLUSH(c, len[c] & ~31u);      // (tail bytes beyond len are never read; the buffer has room: len < IBWT_CW here)
+                if (len[c] & (IBWT_PIECE - 1u)) IBWT_FLUSH(c, len[c] & ~(IBWT_PIECE - 1u));      // (tail bytes beyond len are never read; the buffer has room: len < IBWT_CW here)
                 nxt[my[c]] = ibwt_id(r, sent, kreg);
                 dist[my[c]] = len[c];
                 id[c] = IBWT_PULL();
