@@ -40,31 +40,70 @@ __global__ __launch_bounds__(256) void k_bwt_from_pc(const u8* __restrict__ text
 // demo convention (main.cpp:66-101): out[i] = lcp(SA[i+1], SA[i+2]), i in [0, n-2]; out[n-1] = 0.
 // Direct compare like the demo's match_length, but capped: a pair that is still equal after `cap` bytes raises
 // *flag and the host switches to the PLCP method below (periodic inputs have LCPs of 10^4..10^5).
+// the first 32 bytes of suffix p as four little-endian words, zero beyond the end of the text (no padding is assumed)
+__device__ __forceinline__ void lcp_head(const u8* __restrict__ text, u64 n, u64 p, u64 (&w)[4])
+{
+    if (p + 32 <= n) {
+        uint4 lo, hi;
+        __builtin_memcpy(&lo, text + p, 16);
+        __builtin_memcpy(&hi, text + p + 16, 16);
+        w[0] = (u64)lo.x | ((u64)lo.y << 32); w[1] = (u64)lo.z | ((u64)lo.w << 32);
+        w[2] = (u64)hi.x | ((u64)hi.y << 32); w[3] = (u64)hi.z | ((u64)hi.w << 32);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            u64 x = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const u64 at = p + 8u * k + q; if (at < n) x |= (u64)text[at] << (8 * q); }
+            w[k] = x;
+        }
+    }
+}
+
+// out[i] = lcp(SA[i+1], SA[i+2]).  A wave takes 63 consecutive rows: lane l fetches the first 32 bytes of suffix SA[base + l + 1]
+// ONCE (two 16-byte loads from one line) and gets its right neighbour's from lane l + 1 - every suffix is touched by one lane
+// instead of two, and pairs that differ inside 32 bytes (nearly all of a text, all of random bytes) need no second trip to
+// memory; the bound of this kernel is random line fetches, one per row.  Longer matches continue 8 bytes at a time.
 __global__ __launch_bounds__(256) void k_lcp(const u8* __restrict__ text, u64 n, const u32* __restrict__ sa, u32* __restrict__ out,
                                              u32 cap, u32* __restrict__ flag)
 {
-    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 nwin = (n + 62) / 63;
+    for (u64 win = (u64)blockIdx.x * 4u + (threadIdx.x >> 6); win < nwin; win += (u64)gridDim.x * 4u) {
         if (*reinterpret_cast<volatile u32*>(flag)) return;       // somebody met a pair beyond the cap: the host switches to PLCP, stop here
-        u32 v = 0;
-        if (i + 1 < n) {
-            u64 a = sa[i + 1], b = sa[i + 2];
-            if (a > b) { const u64 x = a; a = b; b = x; }
-            u64 m = 0;
-            bool open = true;
+        const u64 i = win * 63 + lane;                            // my suffix is SA[i + 1]; my row (lanes 0..62) is i
+        const bool have = i < n;                                  // rows 1 .. n of the suffix array exist
+        const u64 a0 = have ? sa[i + 1] : 0;
+        u64 w[4] = {0, 0, 0, 0};
+        if (have) lcp_head(text, n, a0, w);
+        const u64 b0 = __shfl_down(a0, 1, 64);
+        u64 v4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v4[k] = __shfl_down(w[k], 1, 64);
+        if (lane == 63u || i + 1 >= n) {                          // no row here: the last suffix's row is 0 by definition
+            if (lane != 63u && have) out[i] = 0;
+            continue;
+        }
+        u64 a = a0, b = b0;
+        if (a > b) { const u64 x = a; a = b; b = x; }
+        const u64 limit = n - b;                                  // bytes of the shorter suffix
+        u64 m = 32;
+        bool open = true;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) { const u64 x = w[k] ^ v4[k]; if (x) { m = 8u * k + ((u64)(__ffsll((long long)x) - 1) >> 3); open = false; } }
+        if (m >= limit) { m = limit; open = false; }              // (zero fill beyond the end compares equal)
+        if (open) {
             while (open && b + m + 8 <= n && m < cap) {
                 u64 x, y;
                 __builtin_memcpy(&x, text + a + m, 8);
                 __builtin_memcpy(&y, text + b + m, 8);
-                if (x != y) { m += (u64)(__ffsll((long long)(x ^ y)) - 1) >> 3; open = false; }
+                if (x != y) { m += (u64)(__ffsll((long long)x ^ (long long)y) - 1) >> 3; open = false; }
                 else m += 8;
             }
-            if (open) {
-                if (m >= cap) *flag = 1u;
-                while (b + m < n && text[a + m] == text[b + m] && m < (u64)cap + 16) ++m;
-            }
-            v = (u32)m;
+            if (open) while (b + m < n && text[a + m] == text[b + m] && m < (u64)cap + 16) ++m;
         }
-        out[i] = v;
+        if (m >= cap) *flag = 1u;
+        out[i] = (u32)m;
     }
 }
 

@@ -134,6 +134,20 @@ def test_lcp_plcp_path(M, oracle_mod, monkeypatch):
     assert (M.make_lcp_array(t, sa) == oracle_mod.lcp(t, sa)).all()
 
 
+def test_lcp_window_edges(M, oracle_mod):
+    """k_lcp takes 63 rows per wave and compares 32-byte heads fetched once per suffix: sizes around the window and the head,
+    suffixes that end inside a head (zero fill must not count), long matches next to the end, zero bytes in the text."""
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 3, 7, 8, 9, 31, 32, 33, 34, 62, 63, 64, 65, 66, 125, 126, 127, 128, 129, 189, 190, 1000, 4097):
+        for sigma in (1, 2, 3, 256):
+            t = rng.integers(0, sigma, n, dtype=np.uint8) if sigma > 1 else np.full(n, 7, np.uint8)
+            sa = oracle_mod.make_suffix_array(t)
+            assert (M.make_lcp_array(t, sa) == oracle_mod.lcp(t, sa)).all(), (n, sigma)
+    t = np.concatenate([gen.text_bytes(5000, 3), np.zeros(40, np.uint8), gen.text_bytes(100, 4), np.zeros(33, np.uint8)])
+    sa = oracle_mod.make_suffix_array(t)
+    assert (M.make_lcp_array(t, sa) == oracle_mod.lcp(t, sa)).all()
+
+
 def _symbols_per_key(t):
     """Symbols one gather round consumes: as many symbols of the dense alphabet code as fit one 32-bit number in base
     sigma (k_alphabet, k_refill) when that is more than the 4 bytes of a plain window (sigma <= 84)."""
