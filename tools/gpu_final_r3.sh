@@ -17,9 +17,12 @@ tools/gpu_prof_bench.sh kernel_stats_random --steps 3 --warmup 1 --no-configs > 
 tools/gpu_prof_bench.sh kernel_stats_text --workload text --op sa,fbwt,ibwt,lcp --steps 2 --warmup 1 > $O/kernel_stats_text.txt 2>&1; cp gpurun_out/prof/kernel_stats_text.csv $O/
 tools/gpu_prof_bench.sh kernel_stats_dna --workload dna --steps 2 --warmup 1 > $O/kernel_stats_dna.txt 2>&1; cp gpurun_out/prof/kernel_stats_dna.csv $O/
 tools/gpu_prof_bench.sh kernel_stats_tandem --workload dna_tandem --size 268435456 --steps 2 --warmup 1 > $O/kernel_stats_tandem.txt 2>&1; cp gpurun_out/prof/kernel_stats_tandem.csv $O/
-bash tools/gpu_pmc_traffic.sh $O/pmc_traffic_random.txt --no-configs > /dev/null 2>&1; cat $O/pmc_traffic_random.txt
-bash tools/gpu_pmc_sq.sh $O/pmc_sq_random.txt --no-configs > /dev/null 2>&1; cat $O/pmc_sq_random.txt
-bash tools/gpu_pmc_traffic.sh $O/pmc_traffic_text.txt --workload text --op sa,fbwt,ibwt --no-configs > /dev/null 2>&1
+timeout 900 bash tools/gpu_pmc_traffic.sh $O/pmc_traffic_random.txt --no-configs > /dev/null 2>&1; cat $O/pmc_traffic_random.txt
+timeout 600 bash tools/gpu_pmc_sq.sh $O/pmc_sq_random.txt --no-configs > /dev/null 2>&1; cat $O/pmc_sq_random.txt
+timeout 900 bash tools/gpu_pmc_traffic.sh $O/pmc_traffic_text.txt --workload text --op sa,fbwt,ibwt --no-configs > /dev/null 2>&1
 python tools/gpu_verbose_any.py dna_tandem 268435456 -1 2>&1 | grep -E "msufsort_hip|errors" > $O/tandem_rounds.txt
-for b in exp_lds_rates exp_lds_valu_overlap exp_bits_phases exp_bits_phases2; do ./tools/microbench/bin/$b > $O/microbench_$b.txt 2>&1; done
+for b in exp_lds_rates exp_lds_valu_overlap exp_bits_phases exp_bits_phases2 exp_random_lines exp_random_lines_k1; do timeout 120 ./tools/microbench/bin/$b > $O/microbench_$b.txt 2>&1; done
+timeout 600 bash tools/gpu_pmc_sq.sh $O/pmc_sq_text.txt --workload text --op sa --no-configs > /dev/null 2>&1
+timeout 600 bash tools/gpu_trace_py.sh trace_text_two_stage 700 tools/gpu_two_stage_only.py text 1073741823 2 > /dev/null 2>&1; cp gpurun_out/prof/trace_text_two_stage.txt $O/ 2>/dev/null
+timeout 300 python tools/gpu_bits_sizes.py 2>&1 | grep "MiB:" > $O/bits_sizes.txt
 MSUFSORT_HIP_LIB=$GRAFT_REPO_ROOT/msufsort_amd/lib/libmsufsort_hip_prof.so python bench.py --steps 2 --warmup 1 --no-cpu --no-configs 2>&1 | grep "bits prof" | tail -1 > $O/bits_phase_clocks.txt; cat $O/bits_phase_clocks.txt
