@@ -776,6 +776,20 @@ struct Rounds {
             DBG("k_sort_tiny");
             if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
             TRY(c->read_counters(attempt == 0));
+#ifdef MID_PROF
+            {
+                unsigned long long h[3][16];
+                hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mid_prof), sizeof h);
+                for (int k = 0; k < 3; ++k) {
+                    if (!h[k][8]) continue;
+                    const double sg = (double)h[k][8];
+                    fprintf(stderr, "[mid prof] round %d class %c: %.0f segments seen by thread 0 of each workgroup, %.0f records each; clocks per segment: records %.0f, keys %.0f, sort %.0f, runs+rows %.0f, reserve %.0f, emit %.0f, between %.0f\n",
+                            round, "ABC"[k], sg, h[k][9] / sg, h[k][0] / sg, h[k][1] / sg, h[k][2] / sg, h[k][3] / sg, h[k][4] / sg, h[k][5] / sg, h[k][6] / sg);
+                }
+                memset(h, 0, sizeof h);
+                hipMemcpyToSymbol(HIP_SYMBOL(g_mid_prof), h, sizeof h);
+            }
+#endif
             if (c->h_counters[C_ERR] & 0x400u) return MSUFSORT_HIP_UNRESOLVED;      // a deep comparison gave up: the caller sorts all suffixes
             if (attempt == 0 && force_retry) c->h_counters[C_ERR] |= 0x8000u;      // test hook: MSUFSORT_HIP_FORCE_RETRY=1
             if (c->h_counters[C_ERR] == 0) {

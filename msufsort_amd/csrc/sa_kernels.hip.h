@@ -1243,6 +1243,20 @@ __global__ __launch_bounds__(256) void k_refill_rows(const typename Wd<W>::sa_t*
 // suffix array, equal-key runs are detected with ballot bitmaps and the still-tied runs are compacted into next
 // round's tiny pool / segment array.
 // ------------------------------------------------------------------------------------------------
+// Diagnostic build (-DMID_PROF): clock64() per phase of sort_mid_segment, summed by thread 0 of every workgroup into
+// g_mid_prof[class][phase] (printed by the engine after every launch): 0 records loaded, 1 keys gathered, 2 sorted, 3 runs found +
+// rows written, 4 room reserved, 5 emitted, 6 between segments; 8 segments, 9 records.
+#ifdef MID_PROF
+__device__ unsigned long long g_mid_prof[3][16];
+#define MPROF(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); mprof[i] += now_ - mprof[15]; mprof[15] = now_; } } while (0)
+#define MPROF_PARAM , unsigned long long* mprof
+#define MPROF_ARG , mprof
+#else
+#define MPROF(i) do { } while (0)
+#define MPROF_PARAM
+#define MPROF_ARG
+#endif
+
 template <int THREADS, int ITEMS>
 constexpr size_t sort_mid_lds_bytes()
 {
@@ -1254,7 +1268,7 @@ constexpr size_t sort_mid_lds_bytes()
 template <int THREADS, int ITEMS, bool W>
 __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc d,
                                                  typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
-                                                 const Emit& em, u32* __restrict__ counters, const GatherSpec& g, const u8* s_code)
+                                                 const Emit& em, u32* __restrict__ counters, const GatherSpec& g, const u8* s_code MPROF_PARAM)
 {
     constexpr u32 KL = klow<W>();                   // low bits of the key word that are not key (wide: index bits 32..39)
     // Output room (tiny pool, segment array, descriptor lists) is reserved from the global counters in CHUNKS
@@ -1280,6 +1294,10 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 
     const u32 len = d.len;
     if (len == 0) return;                           // neutral list entry (unused chunk tail)
+    MPROF(6);
+#ifdef MID_PROF
+    if (threadIdx.x == 0) { mprof[8] += 1; mprof[9] += len; }
+#endif
     // (the thread id is re-materialised per segment: the address arithmetic hanging off it is then redone here instead
     // of being hoisted out of the caller's segment loop into registers that cost a whole wave of occupancy)
     u32 t;
@@ -1310,6 +1328,10 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
             valid[j] = (u32)j < rpw && p < len;
             fi[j] = valid[j] ? rec_idx<W>(src[p]) : 0;
         }
+#ifdef MID_PROF
+        asm volatile("" :: "v"(fi[0]));
+        MPROF(0);
+#endif
         gather_keys<W, ITEMS, (ITEMS > 8 ? 6 : 8)>(g, s_code, fi, valid, key);
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -1327,6 +1349,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
         for (int j = 0; j < ITEMS; ++j) { const u32 p = wbase + j * 64 + lane; if ((u32)j < rpw && p < len) diff |= key[j] ^ key0; }
     }
     diff = wave_or(diff);
+    MPROF(1);
     if (lane == 0 && diff) atomicOr(&misc[0], diff);
     __syncthreads();
     diff = misc[0] & (0xffffffffu << KL);           // (wide: the index byte never decides an LSD pass; equal keys keep their order)
@@ -1401,6 +1424,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
         __syncthreads();
     }
 
+    MPROF(2);
     // ---- equal-key runs ----
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[wbase + j * 64 + lane] = key[j];
@@ -1512,6 +1536,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
             }
         }
     }
+    MPROF(3);
     if (em.discard) return;                         // stateless doubling step: the caller rebuilds the groups from grp_out
     if (!__syncthreads_or(any_eq)) return;
 
@@ -1606,6 +1631,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
         }
     }
     __syncthreads();
+    MPROF(4);
     if (misc[3]) return;
     // neutral-fill the chunk tails that were just abandoned
     {
@@ -1638,6 +1664,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                 }
             }
         }
+    MPROF(5);
 }
 
 #include "bucket_sort_bits.hip.h"
@@ -2009,6 +2036,10 @@ __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(
     if (threadIdx.x < 24) ach[threadIdx.x] = 0;
     if (g.text) for (u32 i = threadIdx.x; i < 256u; i += THREADS) s_code[i] = code[i];
     __syncthreads();
+#ifdef MID_PROF
+    __shared__ unsigned long long mprof[16];
+    if (threadIdx.x == 0) { for (int i = 0; i < 15; ++i) mprof[i] = 0; mprof[15] = clock64(); }
+#endif
     const u32 total = ids ? counters[ids_cnt_idx] : nseg;
     if (blockIdx.x < total) {
         // the next descriptor is fetched while the current segment is sorted (one memory round trip less per segment)
@@ -2016,11 +2047,14 @@ __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(
         for (u32 i = blockIdx.x; i < total; i += gridDim.x) {
             const u32 ni = i + gridDim.x < total ? i + gridDim.x : i;
             const Desc dn = list[ids ? ids[ni] : ni];
-            sort_mid_segment<THREADS, ITEMS, W>(bufs, d, sa_out, isa, mode, em, counters, g, s_code);
+            sort_mid_segment<THREADS, ITEMS, W>(bufs, d, sa_out, isa, mode, em, counters, g, s_code MPROF_ARG);
             __syncthreads();
             d = dn;
         }
     }
+#ifdef MID_PROF
+    if (threadIdx.x == 0) for (int i = 0; i < 15; ++i) atomicAdd(&g_mid_prof[THREADS == 64 ? 0 : (THREADS == 256 ? 1 : 2)][i], mprof[i]);
+#endif
     // give back what is left of my chunks as neutral entries
     for (u32 i = ach[0] + threadIdx.x; i < ach[1]; i += THREADS) { em.pool_rec[i] = 0; em.pool_hdr[i] = 0; }
     for (u32 i = ach[2] + threadIdx.x; i < ach[3]; i += THREADS) em.seg_rec[i] = 0;
