@@ -251,6 +251,8 @@ struct IndLevel {
     u32 slot;        // which rng[] holds this level's rows
     u32 stars;       // pass B level 0: the sources include B* rows, whose pc is not known yet
     u32 src_a;       // pass A: the sources are A rows (an equal preceding byte is then type A too)
+    u32 fixed_tiles; // 1: the launch has no more workgroups than the chip holds at once and workgroup g takes tiles g, g + G, ... (no
+                     // ticket: a returning atomic - one memory round trip - less before a tile publishes its counts)
 };
 
 // target bin of one source row, or 256: nothing to induce
@@ -564,6 +566,15 @@ __global__ __launch_bounds__(256) void k_ind_fused(IndState* st, IndLevel lv, u3
     const u32 my_code = tb.code[t];
     if (ntiles == 0) {                   // nothing to read: the next level is empty as well
         if (blockIdx.x == 0 && t == 0) { st->rng[lv.slot ^ 1u][0] = 0; st->rng[lv.slot ^ 1u][1] = 0; }
+        return;
+    }
+    if (lv.fixed_tiles) {
+        // every workgroup of the launch is resident, each takes its tiles in increasing order: the smallest unfinished tile is
+        // always being worked on, so the look-back cannot wait for a workgroup that has not started
+        for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            __syncthreads();
+            ind_tile<2>(st, lv, tb, sa, pc, text, nullptr, tile, lo, hi, my_code, wcnt, goff, s_sub, status, epoch, ntiles, s_base);
+        }
         return;
     }
     for (;;) {
