@@ -794,3 +794,11 @@ def test_two_stage_three_kernel_levels(M, oracle_mod, monkeypatch):
     monkeypatch.setenv("MSUFSORT_HIP_IND_CLASSIC", "1")
     _two_stage(M, oracle_mod, gen.text_bytes((2 << 20) + 9, 51))
     _two_stage(M, oracle_mod, gen.dna_bytes(1 << 20, 52))
+
+
+def test_two_stage_fixed_tile_assignment(M, oracle_mod, monkeypatch):
+    """MSUFSORT_HIP_IND_FIXED=1: induction tiles assigned by workgroup index instead of drawn from the ticket counter (opt-in:
+    it needs every workgroup of a launch resident - trivially true at these sizes) give the same rows."""
+    monkeypatch.setenv("MSUFSORT_HIP_IND_FIXED", "1")
+    _two_stage(M, oracle_mod, gen.text_bytes((2 << 20) + 9, 53))
+    _two_stage(M, oracle_mod, gen.dna_bytes(1 << 20, 54))
