@@ -32,10 +32,15 @@ import oracle
 from msufsort_amd import gen
 t = gen.GENERATORS[%(workload)r](%(n)d, %(seed)d)
 out = []
+bwt = None
 for threads, what in %(runs)r:
+    if what == "ibwt" and bwt is None:
+        bwt = oracle.ref_forward_bwt(t, 16)          # (input of the inverse: outside the timed part)
     t0 = time.perf_counter()
     if what == "sa":
         oracle.ref_make_suffix_array(t, threads)
+    elif what == "ibwt":
+        oracle.ref_reverse_bwt(bwt[0], bwt[1], threads)
     else:
         oracle.ref_forward_bwt(t, threads)
     dt = time.perf_counter() - t0
@@ -73,7 +78,7 @@ def cpu_baseline(sample_bytes, seed, workload="random", op="sa", full_n=None, al
         if not res:
             return {"error": "the reference did not finish within 240 s", "host_cpus": ncpu}
         best = max(res, key=lambda r: r["MB/s"])
-        what = "make_suffix_array" if op == "sa" else "forward_burrows_wheeler_transform"
+        what = {"sa": "make_suffix_array", "ibwt": "reverse_burrows_wheeler_transform"}.get(op, "forward_burrows_wheeler_transform")
         part = "the whole input" if full_n == sample_bytes else f"first {sample_bytes} bytes of the same stream"
         out = {"value": best["MB/s"], "unit": "MB/s", "cores": best["threads"], "kind": "reference", "host_cpus": ncpu, "runs": res,
                "sample": f"{part}, {what} wall time incl. allocation, one run per thread count ({', '.join(str(r['threads']) for r in res)}); value = the faster"}
@@ -313,6 +318,10 @@ def config_lines(M, torch, ctx, dev, steps, no_cpu):
             cfg3["cpu_baseline"] = cpu_baseline(1 << 28, seed, "text", "fbwt", n)
         except Exception as e:  # noqa: BLE001
             cfg3["cpu_baseline"] = {"error": str(e)}
+        try:       # the reference's inverse transform (cpp:1820-2103) on the same sample
+            cfg4["cpu_baseline"] = cpu_baseline(1 << 28, seed, "text", "ibwt", n)
+        except Exception as e:  # noqa: BLE001
+            cfg4["cpu_baseline"] = {"error": str(e)}
     del S
     torch.cuda.empty_cache()
     return {"cfg3": cfg3, "cfg4": cfg4}, ok
