@@ -93,7 +93,9 @@ typedef struct msufsort_hip_timings {
                                   policy decline after the front end); bits 8..: reason code of the abandon */
     int64_t progression_suffixes; /* suffixes finished as arithmetic progressions of positions (tandem repeats, k_chain_resolve) by the
                                   in-place doubling of the last build */
-    int64_t reserved[5];
+    int64_t bucket_sort_handed_back; /* round 0: segments the fast bucket sort (k_sort_bits / k_sort_fast2) gave to k_sort_mid (length,
+                                  key bits or skew outside its shapes); a handful of 65,536 on uniform random bytes up to the class-C limit */
+    int64_t reserved[4];
 } msufsort_hip_timings;
 
 int msufsort_hip_device_count(void);

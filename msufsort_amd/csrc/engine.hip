@@ -914,6 +914,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         if (verbose && R.mode == MODE_TEXT && R.wants_fast() && (c->h_counters[C_FBB] || c->h_counters[C_FBC]))
             fprintf(stderr, "[msufsort_hip] round %d: the bucket sort handed %u class-B and %u class-C segments to k_sort_mid\n", round, c->h_counters[C_FBB], c->h_counters[C_FBC]);
         if (round == 0) tm.unresolved_after_round0 = (int64_t)(actP + actS);
+        if (round == 0 && R.wants_fast()) tm.bucket_sort_handed_back = (int64_t)c->h_counters[C_FBB] + (int64_t)c->h_counters[C_FBC];
         if (actP + actS == 0) break;
         if (round == 0) {     // key packing for the gather rounds (k_alphabet ran with the histogram)
             const u32 b = c->h_counters[C_ABITS], sg = c->h_counters[C_ASIGMA];

@@ -159,7 +159,7 @@ def test_bucket_sort_at_the_class_limits(mib):
     """Random bytes whose 65,536 two-byte buckets sit at the limits of the LDS sorts: ~4560 records (fills the 256-thread
     shape of k_sort_bits, limit 4608), ~4800 (just over: the 1024-thread shape a quarter full), ~17,440 and ~17,950 (fill the
     1024-thread shape, limit 18,432: its dirty list is nearly full) and ~18,880 (over: one more partition level).  Rows
-    checked on the device; up to the class-C limit no segment may be handed back to k_sort_mid."""
+    checked on the device; up to the class-C limit all but a handful of segments must stay with k_sort_bits."""
     import torch
 
     import msufsort_amd as M
@@ -172,7 +172,8 @@ def test_bucket_sort_at_the_class_limits(mib):
     tm = ctx.timings()
     assert int(sa[0]) == n and ctx.validate_sa(d, n, sa) == 0
     if mib < 1150:
-        assert tm.bucket_sort_ms < 2 * 2.9 * n / (1 << 30) + 1.0, tm.bucket_sort_ms      # (no cliff next to the limits)
+        assert tm.bucket_sort_handed_back < 512, tm.bucket_sort_handed_back     # (of 65,536: a few with an overfull dirty list are
+                                                                                  # expected, thousands were the cliff next to the limits)
     del sa, d
     ctx.trim(); torch.cuda.empty_cache()
 
