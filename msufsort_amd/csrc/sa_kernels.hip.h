@@ -102,7 +102,9 @@ enum {
 #define TINY_MAX 32
 #endif
 #define CLS_A_THREADS 64
-#define CLS_A_ITEMS 8        // <= 512
+#ifndef CLS_A_ITEMS
+#define CLS_A_ITEMS 8        // <= 512 (12 / 16 measured on text: see DESIGN section 6)
+#endif
 #define CLS_B_THREADS 256
 #define CLS_B_ITEMS 18       // <= 4608
 #define CLS_C_THREADS 1024
