@@ -1123,7 +1123,7 @@ int double_sort(msufsort_hip_ctx* c, ActiveSet& as, u64 n, typename Wd<W>::sa_t*
     if (!as.valid && !as.tried_list) {
         // first step on this slice: one cheap look at the group heads tells whether the tied rows fit a list
         as.tried_list = true;
-        hipLaunchKernelGGL(k_list_tied, dim3(grid_for(rows, 256, 16384u)), dim3(256), 0, st, d_grp_slice, rows, as.act[as.cur].template as<u32>(), as.cap, as.cnt.template as<unsigned long long>());
+        hipLaunchKernelGGL(k_list_tied, dim3(grid_for(rows, 256 * UPD_K, 16384u)), dim3(256), 0, st, d_grp_slice, rows, as.act[as.cur].template as<u32>(), as.cap, as.cnt.template as<unsigned long long>());
         HIP_TRY(hipMemcpyAsync(c->h_upd, as.cnt.p, 32, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (c->h_upd[3] == 0) { as.valid = true; as.count = c->h_upd[2]; }
@@ -1165,7 +1165,7 @@ int emit_updates(msufsort_hip_ctx* c, ActiveSet& as, const typename Wd<W>::sa_t*
     const u64 c0 = c->h_upd[0], t0 = c->h_upd[1];
     if (i1 > i0) {
         // updates are written from index 0 of d_out in every window: pass the buffer shifted back by what earlier windows counted
-        hipLaunchKernelGGL(k_emit_updates<W>, dim3(grid_for(i1 - i0, 256, 16384u)), dim3(256), 0, st, d_sa_slice, d_grp_slice,
+        hipLaunchKernelGGL(k_emit_updates<W>, dim3(grid_for(i1 - i0, 256 * UPD_K, 16384u)), dim3(256), 0, st, d_sa_slice, d_grp_slice,
                            list ? as.prev.template as<u32>() : d_grp_prev_slice, list ? as.act[as.cur].template as<u32>() : (const u32*)nullptr,
                            rows, i0, i1, slice_lo, d_out - (W ? 2 : 1) * c0, cap + c0, as.act[as.cur ^ 1].template as<u32>(), as.cap, cnt);
     }

@@ -2362,6 +2362,10 @@ __global__ __launch_bounds__(256) void k_import_groups(const typename Wd<W>::sa_
 // cnt[0] = updates written (the caller sizes the window so that it cannot overflow), cnt[1] += rows still tied,
 // cnt[2] = length of next step's active list act_next (tied rows, unordered), cnt[3] = 1 if it did not fit act_cap.
 template <bool W>
+// (Both kernels below reserve their output room with returning atomics on ONE global counter, which the chip serves at ~90 per
+// microsecond: a workgroup therefore takes UPD_K x 256 rows per reservation - with one per 256 rows the 2^33-byte config-5 stream
+// spent half of its doubling time here, k_list_tied 44 ms per 268 M-row shard.)
+#define UPD_K 16
 __global__ __launch_bounds__(256) void k_emit_updates(const typename Wd<W>::sa_t* __restrict__ sa_rows, const u32* __restrict__ grp, const u32* __restrict__ prev,
                                                       const u32* __restrict__ act, u64 rows, u64 i0, u64 i1, u64 slice_lo, u64* __restrict__ out, u64 cap,
                                                       u32* __restrict__ act_next, u64 act_cap, unsigned long long* __restrict__ cnt)
@@ -2369,42 +2373,57 @@ __global__ __launch_bounds__(256) void k_emit_updates(const typename Wd<W>::sa_t
     __shared__ u32 s_cnt, s_tied;
     __shared__ unsigned long long s_base, s_abase;
     const u64 lt_mask = lane_id() ? (~0ull >> (64 - lane_id())) : 0ull;
-    for (u64 b = i0 + (u64)blockIdx.x * 256u; b < i1; b += (u64)gridDim.x * 256u) {
+    unsigned long long tied_total = 0;           // (thread 0: added to cnt[1] once, when the workgroup is done)
+    for (u64 b = i0 + (u64)blockIdx.x * (256u * UPD_K); b < i1; b += (u64)gridDim.x * (256u * UPD_K)) {
         if (threadIdx.x == 0) { s_cnt = 0; s_tied = 0; }
         __syncthreads();
-        const u64 i = b + threadIdx.x;
-        bool chg = false, tied = false;
-        u32 g = 0, r = 0;
-        if (i < i1) {
-            r = act ? act[i] : (u32)i;
-            g = grp[r];
-            chg = g != prev[i];
-            tied = g != r || ((u64)r + 1 < rows && grp[r + 1] == r);
+        u32 g[UPD_K], r[UPD_K];
+        u32 mchg = 0, mtied = 0;                 // bit k: row k of this thread changed its head / is still tied
+        u32 wc = 0, wt = 0;                      // what this wave writes, and where this lane's entries start inside it
+        u32 oc[UPD_K], ot[UPD_K];
+#pragma unroll
+        for (int k = 0; k < UPD_K; ++k) {
+            const u64 i = b + (u64)k * 256u + threadIdx.x;
+            bool chg = false, tied = false;
+            g[k] = 0; r[k] = 0;
+            if (i < i1) {
+                r[k] = act ? act[i] : (u32)i;
+                g[k] = grp[r[k]];
+                chg = g[k] != prev[i];
+                tied = g[k] != r[k] || ((u64)r[k] + 1 < rows && grp[r[k] + 1] == r[k]);
+            }
+            const u64 mc = __ballot(chg), mt = __ballot(tied);
+            oc[k] = wc + (u32)__popcll(mc & lt_mask); ot[k] = wt + (u32)__popcll(mt & lt_mask);
+            wc += (u32)__popcll(mc); wt += (u32)__popcll(mt);
+            mchg |= (u32)chg << k; mtied |= (u32)tied << k;
         }
-        const u64 mc = __ballot(chg), mt = __ballot(tied);
         u32 wbase = 0, tbase = 0;
-        if (lane_id() == 0) { if (mc) wbase = atomicAdd(&s_cnt, (u32)__popcll(mc)); if (mt) tbase = atomicAdd(&s_tied, (u32)__popcll(mt)); }
+        if (lane_id() == 0) { if (wc) wbase = atomicAdd(&s_cnt, wc); if (wt) tbase = atomicAdd(&s_tied, wt); }
         wbase = __shfl(wbase, 0, 64); tbase = __shfl(tbase, 0, 64);
         __syncthreads();
         if (threadIdx.x == 0) {
             s_base = s_cnt ? atomicAdd(&cnt[0], (unsigned long long)s_cnt) : 0ull;
             s_abase = 0;
-            if (s_tied) { atomicAdd(&cnt[1], (unsigned long long)s_tied); if (act_next) s_abase = atomicAdd(&cnt[2], (unsigned long long)s_tied); }
+            if (s_tied) { tied_total += s_tied; if (act_next) s_abase = atomicAdd(&cnt[2], (unsigned long long)s_tied); }
         }
         __syncthreads();
-        if (chg) {
-            const u64 o = s_base + wbase + (u32)__popcll(mc & lt_mask);
-            if (o < cap) {
-                if constexpr (W) { out[2 * o] = sa_rows[r]; out[2 * o + 1] = slice_lo + g; }
-                else out[o] = ((slice_lo + g) << 32) | (u64)sa_rows[r];
+#pragma unroll
+        for (int k = 0; k < UPD_K; ++k) {
+            if ((mchg >> k) & 1u) {
+                const u64 o = s_base + wbase + oc[k];
+                if (o < cap) {
+                    if constexpr (W) { out[2 * o] = sa_rows[r[k]]; out[2 * o + 1] = slice_lo + g[k]; }
+                    else out[o] = ((slice_lo + g[k]) << 32) | (u64)sa_rows[r[k]];
+                }
             }
-        }
-        if (tied && act_next) {
-            const u64 o = s_abase + tbase + (u32)__popcll(mt & lt_mask);
-            if (o < act_cap) act_next[o] = r; else cnt[3] = 1ull;
+            if (((mtied >> k) & 1u) && act_next) {
+                const u64 o = s_abase + tbase + ot[k];
+                if (o < act_cap) act_next[o] = r[k]; else cnt[3] = 1ull;
+            }
         }
         __syncthreads();
     }
+    if (threadIdx.x == 0 && tied_total) atomicAdd(&cnt[1], tied_total);
 }
 
 // list of the tied rows of a slice (any order): lets the very first doubling step run on the list instead of on all rows.
@@ -2414,23 +2433,32 @@ __global__ __launch_bounds__(256) void k_list_tied(const u32* __restrict__ grp, 
     __shared__ u32 s_tied;
     __shared__ unsigned long long s_base;
     const u64 lt_mask = lane_id() ? (~0ull >> (64 - lane_id())) : 0ull;
-    for (u64 b = (u64)blockIdx.x * 256u; b < rows; b += (u64)gridDim.x * 256u) {
+    for (u64 b = (u64)blockIdx.x * (256u * UPD_K); b < rows; b += (u64)gridDim.x * (256u * UPD_K)) {
         if (threadIdx.x == 0) s_tied = 0;
         __syncthreads();
-        const u64 r = b + threadIdx.x;
-        bool tied = false;
-        if (r < rows) { const u32 g = grp[r]; tied = g != (u32)r || (r + 1 < rows && grp[r + 1] == (u32)r); }
-        const u64 mt = __ballot(tied);
+        u32 mtied = 0, wt = 0, ot[UPD_K];
+#pragma unroll
+        for (int k = 0; k < UPD_K; ++k) {
+            const u64 r = b + (u64)k * 256u + threadIdx.x;
+            bool tied = false;
+            if (r < rows) { const u32 g = grp[r]; tied = g != (u32)r || (r + 1 < rows && grp[r + 1] == (u32)r); }
+            const u64 mt = __ballot(tied);
+            ot[k] = wt + (u32)__popcll(mt & lt_mask);
+            wt += (u32)__popcll(mt);
+            mtied |= (u32)tied << k;
+        }
         u32 tbase = 0;
-        if (lane_id() == 0 && mt) tbase = atomicAdd(&s_tied, (u32)__popcll(mt));
+        if (lane_id() == 0 && wt) tbase = atomicAdd(&s_tied, wt);
         tbase = __shfl(tbase, 0, 64);
         __syncthreads();
         if (threadIdx.x == 0) s_base = s_tied ? atomicAdd(&cnt[2], (unsigned long long)s_tied) : 0ull;
         __syncthreads();
-        if (tied) {
-            const u64 o = s_base + tbase + (u32)__popcll(mt & lt_mask);
-            if (o < act_cap) act[o] = (u32)r; else cnt[3] = 1ull;
-        }
+#pragma unroll
+        for (int k = 0; k < UPD_K; ++k)
+            if ((mtied >> k) & 1u) {
+                const u64 o = s_base + tbase + ot[k];
+                if (o < act_cap) act[o] = (u32)(b + (u64)k * 256u + threadIdx.x); else cnt[3] = 1ull;
+            }
         __syncthreads();
     }
 }
