@@ -2361,11 +2361,11 @@ __global__ __launch_bounds__(256) void k_import_groups(const typename Wd<W>::sa_
 // head row}: one u64 (row << 32 | suffix) in narrow builds, two u64 in wide builds.
 // cnt[0] = updates written (the caller sizes the window so that it cannot overflow), cnt[1] += rows still tied,
 // cnt[2] = length of next step's active list act_next (tied rows, unordered), cnt[3] = 1 if it did not fit act_cap.
-template <bool W>
 // (Both kernels below reserve their output room with returning atomics on ONE global counter, which the chip serves at ~90 per
 // microsecond: a workgroup therefore takes UPD_K x 256 rows per reservation - with one per 256 rows the 2^33-byte config-5 stream
 // spent half of its doubling time here, k_list_tied 44 ms per 268 M-row shard.)
 #define UPD_K 16
+template <bool W>
 __global__ __launch_bounds__(256) void k_emit_updates(const typename Wd<W>::sa_t* __restrict__ sa_rows, const u32* __restrict__ grp, const u32* __restrict__ prev,
                                                       const u32* __restrict__ act, u64 rows, u64 i0, u64 i1, u64 slice_lo, u64* __restrict__ out, u64 cap,
                                                       u32* __restrict__ act_next, u64 act_cap, unsigned long long* __restrict__ cnt)
