@@ -122,6 +122,90 @@ def check_golden(entry, d_sa=None, d_bwt=None, sentinel=None, d_lcp=None):
     return ok, checked
 
 
+def pcie_floor(torch, dev, n):
+    """What the PCIe link alone needs for the drop-in's buffers, measured here with pinned memory: the text (n bytes) to the
+    device, the suffix array (4(n+1) bytes) back.  Nothing else is in these numbers - no page faults, no sort."""
+    import time as _t
+    h_text = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    h_sa = torch.empty(n + 1, dtype=torch.int32, pin_memory=True)
+    h_text.zero_(); h_sa.zero_()
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    d_sa = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    best = [1e9, 1e9]
+    for _ in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = _t.perf_counter(); d_text.copy_(h_text, non_blocking=True); torch.cuda.synchronize(dev); t1 = _t.perf_counter()
+        h_sa.copy_(d_sa, non_blocking=True); torch.cuda.synchronize(dev); t2 = _t.perf_counter()
+        best = [min(best[0], (t1 - t0) * 1e3), min(best[1], (t2 - t1) * 1e3)]
+    del h_text, h_sa, d_text, d_sa
+    return {"h2d_text_ms": round(best[0], 2), "d2h_sa_ms": round(best[1], 2), "h2d_GBps": round(n / best[0] / 1e6, 1), "d2h_GBps": round(4 * (n + 1) / best[1] / 1e6, 1),
+            "sa_floor_ms": round(best[0] + best[1], 2), "bwt_floor_ms": round(best[0] * 2, 2),
+            "note": "pinned-memory copies measured in this run: text to the device + result back (SA: 4(n+1) bytes; BWT / inverse: n bytes each way)"}
+
+
+def host_bench_path():
+    return os.path.join(ROOT, "build", "host_bench")
+
+
+def end_to_end_host(torch, dev, workload, seed, n, floor, golden=None, reps=3):
+    """The drop-in as a caller sees it (reference main.cpp:386,440-442): pageable host
+    text in, FRESHLY allocated host result out, clock around the call.  Two legs: the C-ABI entry point through ctypes
+    (msufsort_hip_make_sa_multi into np.empty) and the C++ header (examples/host_bench.cpp: maniscalco::msufsort::
+    make_suffix_array incl. the construction of its std::vector, forward and inverse transform in place)."""
+    import ctypes as C
+    import subprocess
+    import numpy as np
+    from msufsort_amd import _lib, gen
+    from msufsort_amd.api import _opts
+    out = {"workload": f"{workload} (seed {seed}), n={n}", "pcie_floor": floor}
+    t = gen.GENERATORS[workload](n, seed)
+    L = _lib.lib()
+    ms = []
+    chk = None
+    for r in range(reps + 1):
+        sa = np.empty(n + 1, dtype=np.int32)                  # fresh, untouched memory every time
+        o = _opts()
+        dv = (C.c_int32 * 1)(dev.index or 0)
+        t0 = time.perf_counter()
+        _lib.check(L.msufsort_hip_make_sa_multi(dv, 1, t.ctypes.data, n, sa.ctypes.data, 4, C.byref(o), None), "make_sa_multi")
+        dt = (time.perf_counter() - t0) * 1e3
+        if r:
+            ms.append(round(dt, 2))
+        chk = (int(sa[0]), int(sa[1]), int(sa[n]))
+        if r == reps and golden is not None and "sa_fnv" in golden:
+            import oracle
+            out["c_abi_valid"] = ("%016x" % oracle.fnv1a64(sa)) == golden["sa_fnv"]
+        del sa
+    out["c_abi"] = {"entry": "msufsort_hip_make_sa_multi (ctypes; numpy pageable text -> np.empty(n+1))", "sa_ms": ms, "sa_best_ms": min(ms),
+                    "sa_MBps": round(n / min(ms) / 1e3, 1), "ratio_to_pcie_floor": round(min(ms) / floor["sa_floor_ms"], 3), "sa_0_1_n": chk}
+    exe = host_bench_path()
+    if os.path.exists(exe):
+        path = f"/dev/shm/msufsort_bench_{os.getpid()}_{workload}.bin"
+        try:
+            t.tofile(path)
+            r = subprocess.run([exe, path, str(reps)], capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            hb = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:]}
+        except Exception as e:  # noqa: BLE001
+            hb = {"error": repr(e)}
+        finally:
+            if os.path.exists(path):
+                os.remove(path)
+        if "sa_ms" in hb and hb["sa_ms"]:
+            hb["sa_best_ms"] = min(hb["sa_ms"]); hb["sa_MBps"] = round(n / min(hb["sa_ms"]) / 1e3, 1)
+            hb["sa_ratio_to_pcie_floor"] = round(min(hb["sa_ms"]) / floor["sa_floor_ms"], 3)
+            hb["forward_bwt_best_ms"] = min(hb["forward_bwt_ms"]); hb["inverse_bwt_best_ms"] = min(hb["inverse_bwt_ms"])
+            hb["forward_bwt_MBps"] = round(n / min(hb["forward_bwt_ms"]) / 1e3, 1); hb["inverse_bwt_MBps"] = round(n / min(hb["inverse_bwt_ms"]) / 1e3, 1)
+            if golden is not None and "sa_fnv" in golden:
+                hb["valid"] = hb.get("sa_fnv") == golden["sa_fnv"] and bool(hb.get("round_trip")) and (golden.get("sentinel") in (None, hb.get("sentinel")))
+        hb["entry"] = "include/library/msufsort.h: maniscalco::msufsort::make_suffix_array (result vector constructed inside the timed call), forward_burrows_wheeler_transform, reverse_burrows_wheeler_transform; examples/host_bench.cpp"
+        out["cpp_header"] = hb
+    else:
+        out["cpp_header"] = {"error": "build/host_bench is missing (python -c 'import __graft_entry__ as g; g.build()')"}
+    del t
+    return out
+
+
 def launch_ranks(n_ranks):
     """`python bench.py --gpus N` run directly: start the N ranks as a CHILD (torch.distributed.run, one rank per GPU) and
     hand its exit code back - the library's own fan-out over its workers is msufsort.cpp:1652-1683.  Nothing in this
@@ -339,6 +423,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="bytes of the stream the CPU baseline sorts (0: the whole input)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip the config 3 / 4 lines")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (PCIe inclusive) legs")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -397,12 +482,25 @@ def main():
                                "walk_sector_GBps": round(64 * n / (S.ibwt_us[0] / K / 1e6) / 1e9, 1) if S.ibwt_us[0] else None}
         del S
         torch.cuda.empty_cache()
+        if not args.no_host:
+            # the drop-in's own numbers: host pointers in and out, result allocated inside the timed call (never `value`)
+            try:
+                floor = pcie_floor(torch, dev, n)
+                out["end_to_end_host"] = end_to_end_host(torch, dev, args.workload, args.seed, n, floor, golden_entry(args.workload, args.seed, n))
+            except Exception as e:  # noqa: BLE001
+                out["end_to_end_host"] = {"error": repr(e)}
         if headline and n == (1 << 30) - 1 and not args.no_configs:
             try:
                 out["configs"], cok = config_lines(M, torch, ctx, dev, 3, args.no_cpu)
                 ok = ok and cok
             except Exception as e:  # noqa: BLE001
                 out["configs"] = {"error": repr(e)}
+            if not args.no_host and "error" not in out["configs"]:
+                try:
+                    floor = out.get("end_to_end_host", {}).get("pcie_floor") or pcie_floor(torch, dev, (1 << 30) - 1)
+                    out["configs"]["end_to_end_host"] = end_to_end_host(torch, dev, "text", 3, (1 << 30) - 1, floor, golden_entry("text", 3, (1 << 30) - 1))
+                except Exception as e:  # noqa: BLE001
+                    out["configs"]["end_to_end_host"] = {"error": repr(e)}
         if not args.no_cpu:
             try:
                 sample = args.cpu_sample or n

@@ -1,0 +1,106 @@
+// End-to-end timing of the drop-in C++ API (include/library/msufsort.h) the way the reference's demo times its calls
+// (reference src/executable/msufsort/main.cpp:386,440-442: the clock runs around the API call, so it includes the allocation
+// of the result and everything the call does to fill it; input generation is outside).  Host buffers are plain pageable
+// std::vectors.  Prints ONE JSON object; bench.py runs this as a child process for its "end_to_end_host" entries.
+//   g++ -std=c++17 -O2 -Iinclude examples/host_bench.cpp -Lmsufsort_amd/lib -lmsufsort_hip -Wl,-rpath,... -o build/host_bench
+//   host_bench <input file> [reps]
+#include <library/msufsort.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static std::uint64_t fnv1a64(void const * p, std::size_t bytes)      // the checker's hash (oracle/msufsort_oracle.c), restated
+{
+    auto b = static_cast<unsigned char const *>(p);
+    std::uint64_t h = 0xcbf29ce484222325ull;
+    for (std::size_t i = 0; i < bytes; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+static void print_list(char const * name, std::vector<double> const & v)
+{
+    std::printf("\"%s\": [", name);
+    for (std::size_t i = 0; i < v.size(); ++i) std::printf("%s%.3f", i ? ", " : "", v[i]);
+    std::printf("]");
+}
+
+int main(int argc, char ** argv)
+{
+    if (argc < 2) { std::fprintf(stderr, "usage: host_bench <input file> [reps]\n"); return 2; }
+    int const reps = argc > 2 ? std::atoi(argv[2]) : 3;
+    std::vector<std::uint8_t> input;
+    {
+        std::FILE * f = std::fopen(argv[1], "rb");
+        if (!f) { std::perror(argv[1]); return 2; }
+        std::fseek(f, 0, SEEK_END);
+        long const sz = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        input.resize(static_cast<std::size_t>(sz));
+        if (std::fread(input.data(), 1, input.size(), f) != input.size()) { std::perror("read"); return 2; }
+        std::fclose(f);
+    }
+    std::size_t const n = input.size();
+    try
+    {
+        // first call of the process through the free template (the reference's demo path): pays the context, the workspace
+        // and the pinned ring once
+        double t0 = now_ms();
+        std::uint64_t sa_hash = 0;
+        std::int32_t sa1 = 0, san = 0;
+        {
+            auto sa = maniscalco::make_suffix_array(input.begin(), input.end(), 1);
+            double const first = now_ms() - t0;
+            sa_hash = fnv1a64(sa.data(), sa.size() * sizeof(std::int32_t));
+            sa1 = sa.size() > 1 ? sa[1] : -1; san = sa[n];
+            std::printf("{\"n\": %zu, \"sa_first_call_ms\": %.3f, \"sa_fnv\": \"%016llx\", \"sa_1\": %d, \"sa_n\": %d, ", n, first, (unsigned long long)sa_hash, sa1, san);
+        }
+        // steady state: one long-lived instance, as an application that builds many arrays holds one
+        maniscalco::msufsort m(1);
+        std::vector<double> sa_ms, fb_ms, ib_ms;
+        bool same = true;
+        for (int r = 0; r < reps + 1; ++r)
+        {
+            t0 = now_ms();
+            auto sa = m.make_suffix_array(input.data(), input.data() + n);       // allocates the result (fresh memory every call)
+            double const dt = now_ms() - t0;
+            if (r) sa_ms.push_back(dt);      // (r = 0: warm-up of this instance)
+            same = same && sa.size() == n + 1 && sa[0] == static_cast<std::int32_t>(n) && (n == 0 || (sa[1] == sa1 && sa[n] == san));
+        }
+        bool round_trip = true;
+        std::int32_t sentinel = 0;
+        for (int r = 0; r < reps + 1; ++r)
+        {
+            auto buf = input;
+            t0 = now_ms();
+            sentinel = m.forward_burrows_wheeler_transform(buf.data(), buf.data() + n);
+            double const t1 = now_ms();
+            maniscalco::msufsort::reverse_burrows_wheeler_transform(buf.data(), buf.data() + n, sentinel, 1);
+            double const t2 = now_ms();
+            if (r) { fb_ms.push_back(t1 - t0); ib_ms.push_back(t2 - t1); }
+            round_trip = round_trip && buf == input;
+        }
+        print_list("sa_ms", sa_ms); std::printf(", ");
+        print_list("forward_bwt_ms", fb_ms); std::printf(", ");
+        print_list("inverse_bwt_ms", ib_ms);
+        std::printf(", \"sentinel\": %d, \"sa_stable\": %s, \"round_trip\": %s, \"uninitialized_result\": %s}\n", sentinel, same ? "true" : "false", round_trip ? "true" : "false",
+#ifdef MSUFSORT_UNINITIALIZED_RESIZE
+                    "true"
+#else
+                    "false"
+#endif
+        );
+        return same && round_trip ? 0 : 1;
+    }
+    catch (std::exception const & e)
+    {
+        std::printf("{\"error\": \"%s\"}\n", e.what());
+        return 1;
+    }
+}

@@ -27,6 +27,45 @@
 namespace maniscalco
 {
 
+    namespace msufsort_detail
+    {
+        // The reference value-initialises its result (`suffix_array sa(n + 1)` + a zero-fill, msufsort.cpp:1754-1758): one thread
+        // writing 4 GiB of fresh memory costs 0.7 s on the GPU box's host - seven times the whole GPU build including the
+        // PCIe copies.  Every entry is overwritten by the device-to-host copy, so the vector is grown WITHOUT touching its
+        // storage: reserve(), then the end pointer is moved (the idea of folly's UninitializedMemoryHacks.h); standard libraries
+        // other than libstdc++ / libc++, debug and sanitizer builds fall back to the value-initialising resize.
+#if defined(__GLIBCXX__) && !defined(_GLIBCXX_DEBUG) && !defined(__SANITIZE_ADDRESS__)
+#define MSUFSORT_UNINITIALIZED_RESIZE 1
+        // libstdc++: the storage pointers live in the protected base's _M_impl; a class derived from the vector may form the
+        // pointer to that member and apply it to any vector
+        struct vec_access : std::vector<std::int32_t>
+        {
+            static void set_size(std::vector<std::int32_t> & v, std::size_t n)
+            {
+                auto & impl = v.*(&vec_access::_M_impl);
+                impl._M_finish = impl._M_start + n;
+            }
+        };
+        inline void grow_uninitialized(std::vector<std::int32_t> & v, std::size_t n)
+        {
+            v.reserve(n);
+            vec_access::set_size(v, n);
+        }
+#elif defined(_LIBCPP_VERSION) && !defined(__SANITIZE_ADDRESS__)
+#define MSUFSORT_UNINITIALIZED_RESIZE 1
+        template <typename Tag, typename Tag::type M> struct rob { friend typename Tag::type get(Tag) { return M; } };
+        struct vec_end_tag { using vec = std::vector<std::int32_t>; using type = std::int32_t * vec::*; friend type get(vec_end_tag); };
+        template struct rob<vec_end_tag, &std::vector<std::int32_t>::__end_>;
+        inline void grow_uninitialized(std::vector<std::int32_t> & v, std::size_t n)
+        {
+            v.reserve(n);
+            v.*get(vec_end_tag()) = v.data() + n;
+        }
+#else
+        inline void grow_uninitialized(std::vector<std::int32_t> & v, std::size_t n) { v.resize(n); }
+#endif
+    }
+
     class msufsort
     {
     public:
@@ -51,7 +90,8 @@ namespace maniscalco
         suffix_array make_suffix_array(std::uint8_t const * inputBegin, std::uint8_t const * inputEnd)
         {
             auto n = static_cast<std::int64_t>(inputEnd - inputBegin);
-            suffix_array sa(static_cast<std::size_t>(n) + 1);
+            suffix_array sa;
+            msufsort_detail::grow_uninitialized(sa, static_cast<std::size_t>(n) + 1);       // (filled by the library; see above)
             // large inputs: the streaming entry point - finished slices leave for the host while the rest is sorted - on this
             // instance's device; several GPUs only when the caller asks for them (MSUFSORT_DEVICES="0,1,..."): a library that
             // allocates on every visible GPU of a shared node by default is a bad neighbour.  Small inputs: this instance's
@@ -59,7 +99,8 @@ namespace maniscalco
             if (n >= (std::int64_t(32) << 20))
             {
                 std::int32_t const own = 0;
-                bool const listed = std::getenv("MSUFSORT_DEVICES") != nullptr;
+                char const * const env = std::getenv("MSUFSORT_DEVICES");
+                bool const listed = env != nullptr && *env != '\0';      // (empty counts as unset: device 0)
                 pooled() = true;
                 check(::msufsort_hip_make_sa_multi(listed ? nullptr : &own, listed ? 0 : 1, inputBegin, n, sa.data(), 4, nullptr, nullptr), "make_suffix_array");
             }
@@ -88,7 +129,8 @@ namespace maniscalco
         std::vector<std::int32_t> make_lcp_array(std::uint8_t const * inputBegin, std::uint8_t const * inputEnd, suffix_array const & sa)
         {
             auto n = static_cast<std::int64_t>(inputEnd - inputBegin);
-            std::vector<std::int32_t> lcp(static_cast<std::size_t>(n));
+            std::vector<std::int32_t> lcp;
+            msufsort_detail::grow_uninitialized(lcp, static_cast<std::size_t>(n));
             check(::msufsort_hip_lcp_i32_ctx(ctx(), inputBegin, n, sa.data(), lcp.data()), "make_lcp_array");
             return lcp;
         }

@@ -95,8 +95,16 @@ typedef struct msufsort_hip_timings {
                                   in-place doubling of the last build */
     int64_t bucket_sort_handed_back; /* round 0: segments the fast bucket sort (k_sort_bits / k_sort_fast2) gave to k_sort_mid (length,
                                   key bits or skew outside its shapes); a handful of 65,536 on uniform random bytes up to the class-C limit */
-    int64_t reserved[4];
+    double hist17_ms;          /* 17-bit histogram of random-like inputs above the class-C limit (part of hist16_ms) */
+    int64_t radix_bits;        /* bits of the two scatter levels of the last build: 16, or 17 (level 1 splits 512 ways) */
+    int64_t reserved[2];
 } msufsort_hip_timings;
+/* The struct's size is part of the ABI (callers pass timings_out buffers): new fields only ever take reserved slots. */
+#ifdef __cplusplus
+static_assert(sizeof(msufsort_hip_timings) == 216, "msufsort_hip_timings changed size");
+#else
+_Static_assert(sizeof(msufsort_hip_timings) == 216, "msufsort_hip_timings changed size");
+#endif
 
 int msufsort_hip_device_count(void);
 const char* msufsort_hip_strerror(int status);

@@ -29,7 +29,8 @@ class Timings(C.Structure):
                 ("stop_depth", C.c_int64), ("logical_shards", C.c_int64), ("gathered_records", C.c_int64),
                 ("ibwt_walk_us", C.c_int64), ("ibwt_total_us", C.c_int64), ("bstar_suffixes", C.c_int64),
                 ("induction_launches", C.c_int64), ("b_suffixes", C.c_int64), ("front_ms", C.c_double), ("fallbacks", C.c_int64),
-                ("progression_suffixes", C.c_int64), ("bucket_sort_handed_back", C.c_int64), ("reserved", C.c_int64 * 4)]
+                ("progression_suffixes", C.c_int64), ("bucket_sort_handed_back", C.c_int64), ("hist17_ms", C.c_double), ("radix_bits", C.c_int64),
+                ("reserved", C.c_int64 * 2)]
 
 
 # every symbol include/msufsort_hip.h declares (checked by tests/test_cabi.py)

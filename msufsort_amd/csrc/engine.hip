@@ -8,6 +8,8 @@
 #include "induce_kernels.hip.h"
 #include "../../include/msufsort_hip.h"
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -70,7 +72,42 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+struct HostRing;      // pinned bounce ring for device-to-host copies into pageable memory (host_xfer.inc)
+
 }  // namespace
+
+// Diagnostic switches of the environment, read ONCE per entry-point call (Switches::load at the top of a
+// build, not in its rounds) - they are test hooks and A/B levers, not part of the C-ABI.
+struct Switches {
+    bool no_refine = false, safe_rank = false, bucket_fast2 = false, no_fast = false, force_fast = false, no_chains = false;
+    bool force_retry = false, no_pack = false, no_fuse = false, ind_classic = false, no_ring = false;
+    int text_rounds = 0;         // MSUFSORT_HIP_TEXT_ROUNDS (0: unset)
+    int digit_bits = 24;         // MSUFSORT_HIP_DIGIT_BITS
+    int two_stage = 0; bool two_stage_set = false;      // MSUFSORT_HIP_TWO_STAGE overrides opts->two_stage
+    int lcp_cap = 512;           // MSUFSORT_HIP_LCP_CAP
+    int ind_spin = 1 << 22;      // MSUFSORT_HIP_IND_SPIN: bound of the induction's look-back spins
+    int radix17 = 0;             // MSUFSORT_HIP_RADIX17: -1 never, 0 when the two-byte buckets of a random-like input outgrow class C, 1 always (tests)
+    int sync_debug = 0;          // MSUFSORT_HIP_SYNC_DEBUG
+    bool host_trace = false;     // MSUFSORT_HIP_HOST_TRACE: timeline of the host-pointer entry points on stderr
+    void load()
+    {
+        auto on = [](const char* k) { return getenv(k) != nullptr; };
+        auto num = [](const char* k, int dflt) { const char* e = getenv(k); return e ? atoi(e) : dflt; };
+        no_refine = on("MSUFSORT_HIP_NO_REFINE"); safe_rank = on("MSUFSORT_HIP_SAFE_RANK");
+        { const char* e = getenv("MSUFSORT_HIP_BUCKET_SORT"); bucket_fast2 = e && !strcmp(e, "fast2"); }
+        no_fast = on("MSUFSORT_HIP_NO_FAST"); force_fast = on("MSUFSORT_HIP_FORCE_FAST"); no_chains = on("MSUFSORT_HIP_NO_CHAINS");
+        force_retry = on("MSUFSORT_HIP_FORCE_RETRY"); no_pack = on("MSUFSORT_HIP_NO_PACK"); no_fuse = on("MSUFSORT_HIP_NO_FUSE");
+        ind_classic = on("MSUFSORT_HIP_IND_CLASSIC"); no_ring = on("MSUFSORT_HIP_NO_RING");
+        text_rounds = std::max(0, num("MSUFSORT_HIP_TEXT_ROUNDS", 0));
+        digit_bits = std::min(24, std::max(2, num("MSUFSORT_HIP_DIGIT_BITS", 24)));
+        two_stage_set = on("MSUFSORT_HIP_TWO_STAGE"); two_stage = num("MSUFSORT_HIP_TWO_STAGE", 0);
+        lcp_cap = std::max(8, num("MSUFSORT_HIP_LCP_CAP", 512));
+        ind_spin = std::max(1, num("MSUFSORT_HIP_IND_SPIN", 1 << 22));
+        radix17 = num("MSUFSORT_HIP_RADIX17", 0);
+        sync_debug = num("MSUFSORT_HIP_SYNC_DEBUG", 0);
+        host_trace = on("MSUFSORT_HIP_HOST_TRACE");
+    }
+};
 
 // Tied rows of one slice between doubling steps (unordered list of local rows), so that a step costs time in
 // proportion to what is still tied, not to the slice.  A list holds at most rows / 16 entries; slices with more tied
@@ -93,6 +130,7 @@ struct msufsort_hip_ctx {
     DevBuf lists[2][3], large_round[2], lvl[2], seg0;
     DevBuf alpha, seg0_base, stripe_sums, hist_partial, hist, hist_clip, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
     DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, aux3, doneB, doneC;
+    DevBuf h17_partial, h17, child_start17, child_cnt17, cursor17;      // 17-bit radix front end (random-like inputs above the class-C limit)
     std::vector<ActiveSet> active;                // per logical shard (index 0: the per-shard C-ABI pieces)
     // two-stage build (B* sort + induction, induce_host.inc): suffix-type bitmaps, histograms of the B / B* suffixes, sorted
     // B* suffixes, preceding characters of the rows, per-tile counts and the state of the induction passes
@@ -113,8 +151,10 @@ struct msufsort_hip_ctx {
     u64 cap_m = 0;               // records capacity
     u64 cap_for_m = 0;           // largest m the workspace was sized for
     msufsort_hip_timings tm{};
-    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int sync_debug = 0;          // MSUFSORT_HIP_SYNC_DEBUG, read once when the context is created
+    hipEvent_t ev[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    Switches sw;                 // environment switches, reloaded by every entry point
+    HostRing* ring = nullptr;    // created by the first large device-to-host copy of a host-pointer entry point
+    std::mutex ring_mu, ring_use;
 
     template <bool W> int set_mid_attrs()
     {
@@ -134,6 +174,7 @@ struct msufsort_hip_ctx {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan16), hipFuncAttributeMaxDynamicSharedMemorySize, SCAN16_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist17), hipFuncAttributeMaxDynamicSharedMemorySize, H17_LDS_BYTES));
         TRY(set_mid_attrs<false>());
         TRY(set_mid_attrs<true>());
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fast2<CLS_C_THREADS, FAST2_C_ITEMS, FAST_BITS_C, FAST2_TL_C>),
@@ -204,6 +245,7 @@ struct msufsort_hip_ctx {
         for (int s = 0; s < 2; ++s) { for (int c = 0; c < 3; ++c) lists[s][c].release(); large_round[s].release(); lvl[s].release(); }
         alpha.release(); seg0.release(); seg0_base.release(); stripe_sums.release(); hist_partial.release(); hist.release(); hist_clip.release(); bstart.release(); child_start.release(); child_cnt.release();
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
+        h17_partial.release(); h17.release(); child_start17.release(); child_cnt17.release(); cursor17.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
         grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release();
         sub_partial.release(); sub_hist.release(); sub_saved.release(); sub_key = -1;
@@ -223,7 +265,7 @@ struct msufsort_hip_ctx {
         for (int s = 0; s < 2; ++s) { for (int k = 0; k < 3; ++k) b += lists[s][k].bytes; b += large_round[s].bytes + lvl[s].bytes; }
         b += isa.bytes + grp_full.bytes + grp_prev.bytes + upd.bytes + sub_partial.bytes + hist_partial.bytes + seg_hist.bytes + child_start.bytes + cursor.bytes;
         b += doneB.bytes + doneC.bytes + aux0.bytes + aux1.bytes + aux2.bytes + aux3.bytes + sa_own.bytes + text_own.bytes;
-        b += ind_sbits.bytes + sel_partial.bytes + ind_sstar.bytes + ind_pc.bytes + ind_tiles.bytes;
+        b += ind_sbits.bytes + sel_partial.bytes + ind_sstar.bytes + ind_pc.bytes + ind_tiles.bytes + h17_partial.bytes;
         for (auto& a : active) b += a.act[0].bytes + a.act[1].bytes + a.prev.bytes;
         return b;
     }
@@ -250,6 +292,8 @@ struct msufsort_hip_ctx {
 };
 
 namespace {
+
+#include "host_xfer.inc"
 
 __global__ void k_dbg_check_descs(const Desc* list, u32 n, u32 cap, u32 ms, u32* out)
 {
@@ -318,11 +362,11 @@ int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out,
 // MSUFSORT_HIP_SYNC_DEBUG=1: synchronise and check after every phase so a faulting kernel is named
 #define DBG(label)                                                                                   \
     do {                                                                                             \
-        if (c->sync_debug) {                                                                         \
+        if (c->sw.sync_debug) {                                                                         \
             hipError_t e_ = hipStreamSynchronize(c->stream);                                         \
             if (e_ == hipSuccess) e_ = hipGetLastError();                                            \
             if (e_ != hipSuccess) { set_error("after %s: %s", label, hipGetErrorString(e_)); return MSUFSORT_HIP_ERR_HIP; } \
-            if (c->sync_debug > 1) fprintf(stderr, "[dbg] %s ok\n", label);                          \
+            if (c->sw.sync_debug > 1) fprintf(stderr, "[dbg] %s ok\n", label);                          \
         }                                                                                            \
     } while (0)
 
@@ -413,6 +457,29 @@ int run_scan(msufsort_hip_ctx* c, const u8* d_text, u64 m, u64 lo32, u64 hi32, u
     return MSUFSORT_HIP_OK;
 }
 
+// 17-bit histogram + offsets of the 131,072 buckets of an UNSHARDED narrow build (k_hist17, k_reduce17, k_scan17): the
+// level-1 partition then splits every first-byte segment 512 ways.  Flags (overflow of an 8-bit LDS counter, disagreement
+// with the 16-bit histogram) and the largest 17-bit bucket land in counters[C_H17FLAG], counters[C_H17MAX].
+int run_hist17(msufsort_hip_ctx* c, const u8* d_text, u64 m)
+{
+    const u32 nch = cdiv(m, H17_CHUNK);
+    TRY(c->h17_partial.ensure((size_t)nch * 131072));
+    TRY(c->h17.ensure(131072 * 4));
+    TRY(c->child_start17.ensure(131072 * 4));
+    TRY(c->child_cnt17.ensure(131072 * 4));
+    TRY(c->cursor17.ensure(131072 * 4));
+    u32* counters = c->counters.as<u32>();
+    HIP_TRY(hipMemsetAsync(c->h17.p, 0, 131072 * 4, c->stream));
+    hipLaunchKernelGGL(k_hist17, dim3(nch), dim3(1024), H17_LDS_BYTES, c->stream, d_text, m, nch, c->h17_partial.as<u32>(), counters + C_H17FLAG);
+    const u32 groups = std::max<u32>(1, std::min<u32>(16, nch / 32));
+    const u32 per_group = cdiv(nch, groups);
+    hipLaunchKernelGGL(k_reduce17, dim3(128, groups), dim3(256), 0, c->stream, c->h17_partial.as<u32>(), nch, per_group, c->h17.as<u32>());
+    hipLaunchKernelGGL(k_scan17, dim3(1), dim3(1024), 0, c->stream, c->h17.as<u32>(), c->hist_clip.as<u32>(), c->child_start17.as<u32>(), c->child_cnt17.as<u32>(),
+                       c->cursor17.as<u32>(), counters + C_H17FLAG, counters + C_H17MAX);
+    HIP_TRY(hipGetLastError());
+    return MSUFSORT_HIP_OK;
+}
+
 // Host-only: split the 16-bit key space into n_shards count-balanced contiguous ranges.
 // bstart[65537] = exclusive prefix of the 16-bit histogram over the m = n - z radix-sorted suffixes.
 void plan_cuts64(const u64* bstart, u64 n, u64 z, int n_shards, u32* cuts, u64* rows)
@@ -444,6 +511,7 @@ template <bool W>
 int plan_shards(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64 z, int n_shards, ShardCuts& sc)
 {
     const u64 m = n - z;
+    c->sw.load();
     sc.cuts.assign(n_shards + 1, 0); sc.rows.assign(n_shards + 1, 0); sc.rank0.assign(n_shards + 1, z);
     sc.cuts[n_shards] = 1ull << 32; sc.rows[n_shards] = n + 1;
     if (m == 0) { for (int g = 1; g < n_shards; ++g) { sc.cuts[g] = 1ull << 32; sc.rows[g] = n + 1; } return MSUFSORT_HIP_OK; }
@@ -453,7 +521,7 @@ int plan_shards(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64 z, int n_shard
     std::vector<u64> bs(65537);
     bs[0] = 0;
     for (u32 k = 0; k < 65536; ++k) bs[k + 1] = bs[k] + (W ? c->h_hist[k] : (u64)reinterpret_cast<const u32*>(c->h_hist)[k]);
-    const bool refine = getenv("MSUFSORT_HIP_NO_REFINE") == nullptr;
+    const bool refine = !c->sw.no_refine;
     const u64 tol = std::max<u64>(m / ((u64)n_shards * 16), 1);
     std::vector<u64> sp;             // prefix of the deeper histogram of key `sp_key`
     int64_t sp_key = -1;
@@ -511,9 +579,15 @@ struct Rounds {
     u32 cpk = W ? 3u : 4u;
     int verbose = 0;
     bool exact_sticky = false, fast_gave_up = false, force_retry = false, no_pack = false;
-    bool safe_rank = getenv("MSUFSORT_HIP_SAFE_RANK") != nullptr;
-    bool bucket_sort_bits = !(getenv("MSUFSORT_HIP_BUCKET_SORT") && !strcmp(getenv("MSUFSORT_HIP_BUCKET_SORT"), "fast2"));
+    bool safe_rank = false, bucket_sort_bits = true;      // (set from c->sw by init())
+    void init(msufsort_hip_ctx* ctx, hipStream_t stream, u32* cnt)
+    {
+        c = ctx; st = stream; counters = cnt;
+        safe_rank = c->sw.safe_rank; bucket_sort_bits = !c->sw.bucket_fast2;
+        force_retry = c->sw.force_retry; no_pack = c->sw.no_pack;
+    }
     u32 nA = 0, nB = 0, nC = 0, nP = 0;
+    u32 round0_max = 0;                  // largest bucket the level-1 partition produced (two-byte buckets, or 17-bit ones)
     u32 deep_cap = 0;                    // != 0: k_sort_tiny finishes its runs by comparing the suffixes themselves (two-stage builds)
     GatherSpec gather{nullptr, 0, {}};   // text rounds: the sorts (and the first partition level) gather the keys themselves
     const u8* code = nullptr;            // dense alphabet code (device)
@@ -539,14 +613,14 @@ struct Rounds {
         const bool dense_uniform = round >= 1 && cpk >= 8u &&
                                    (u64)c->h_counters[C_HMAX] * (u64)std::max<u32>(c->h_counters[C_HNZ], 1u) <= 2ull * std::max<u64>(ms_shard, 1);
         // (k_sort_fast2 exists for narrow records and text keys only)
-        return !W && mode == MODE_TEXT && getenv("MSUFSORT_HIP_NO_FAST") == nullptr &&
-               (keys_spread() || (dense_uniform && !fast_gave_up) || getenv("MSUFSORT_HIP_FORCE_FAST"));
+        return !W && mode == MODE_TEXT && !c->sw.no_fast &&
+               (keys_spread() || (dense_uniform && !fast_gave_up) || c->sw.force_fast);
     }
 
     // tandem repeats (k_chain_resolve): the class lists of `slot` in a doubling round at offset h
     void chain_resolve(int slot, const u32 (&cnt)[3], sa_t* rows, sa_t* isa_rw, const sa_t* isa_ro, u64 n, u64 h)
     {
-        if (getenv("MSUFSORT_HIP_NO_CHAINS")) return;
+        if (c->sw.no_chains) return;
         if (cnt[0]) k_chain_resolve<CLS_A_THREADS, CLS_A_ITEMS, W><<<dim3(std::min<u32>(cnt[0], 8192u)), dim3(CLS_A_THREADS), 0, st>>>(
                         bufs, c->lists[slot][0].template as<Desc>(), cnt[0], rows, isa_rw, isa_ro, grp_out, mode, n, h, counters);
         if (cnt[1]) k_chain_resolve<CLS_B_THREADS, CLS_B_ITEMS, W><<<dim3(std::min<u32>(cnt[1], 2048u)), dim3(CLS_B_THREADS), 0, st>>>(
@@ -565,14 +639,17 @@ struct Rounds {
     u32 cap32() const { return (u32)std::min<u64>(c->cap_m, 0xffffffffu); }
 
     // children of the 65,536 two-byte buckets (after the level-1 partition of round 0)
-    int children_level1()
+    int children_level1(bool radix17 = false)
     {
-        hipLaunchKernelGGL(k_children<W>, dim3(256), dim3(256), 0, st, bufs, c->seg0.template as<Desc>(), 256u, c->child_start.template as<u32>(), c->child_cnt.template as<u32>(),
-                           (const u32*)nullptr, 1u, 0u, 2u, 24u, sa_local, (u32*)nullptr, (u32*)nullptr, (u32)MODE_TEXT,
+        hipLaunchKernelGGL(k_children<W>, dim3(radix17 ? 512 : 256), dim3(256), 0, st, bufs, c->seg0.template as<Desc>(), 256u,
+                           radix17 ? c->child_start17.template as<u32>() : c->child_start.template as<u32>(), radix17 ? c->child_cnt17.template as<u32>() : c->child_cnt.template as<u32>(),
+                           (const u32*)nullptr, 1u, 0u, 2u, radix17 ? 23u : 24u, sa_local, (u32*)nullptr, (u32*)nullptr, (u32)MODE_TEXT,
                            c->pool_rec[cur].template as<u64>(), c->pool_hdr[cur].template as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), cap32(),
-                           make_lists(cur), c->lvl[0].template as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters);
+                           make_lists(cur), c->lvl[0].template as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters, radix17 ? 9u : 8u);
         DBG("k_children L1");
-        return c->read_counters();
+        TRY(c->read_counters());
+        round0_max = radix17 ? c->h_counters[C_H17MAX] : c->h_counters[C_HMAX];
+        return MSUFSORT_HIP_OK;
     }
 
     int levels_and_sorts()
@@ -617,7 +694,7 @@ struct Rounds {
                 DBG("k_count");
                 hipLaunchKernelGGL(k_segscan, dim3(nl), dim3(256), 0, st, src_list, nl, c->seg_hist.template as<u32>(), c->child_start.template as<u32>(), c->cursor.template as<u32>(), c->trivial.template as<u32>());
                 DBG("k_segscan");
-                hipLaunchKernelGGL(k_partition, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.template as<u32>(), shift,
+                hipLaunchKernelGGL(k_partition<256>, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.template as<u32>(), shift,
                                    c->cursor.template as<u32>(), c->trivial.template as<u32>(), a[0], a[1], a[2]);
                 DBG("k_partition level");
                 hipLaunchKernelGGL(k_children<W>, dim3(nl), dim3(256), 0, st, bufs, src_list, nl, c->child_start.template as<u32>(), c->seg_hist.template as<u32>(),
@@ -692,7 +769,14 @@ struct Rounds {
             if (nC) {
                 const u32* ids = nullptr;
                 if constexpr (!W) {
-                    if (use_fast && use_bits) {
+                    if (use_fast && use_bits && round == 0 && round0_max != 0 && round0_max <= 8704u) {
+                        // every bucket of this (random-like) input fits the half-size shape: two workgroups per CU, half the
+                        // words to clear and scan per segment (the 285 -> 296 MiB step of round 3: 4.7 K-record buckets in the 18 K shape)
+                        k_sort_bits<BITS_M_SHAPE><<<dim3(std::min<u32>(nC, 256u * 2u)), dim3(512), 0, st>>>(
+                            bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, em, counters, c->doneC.template as<u32>(), (u32)C_FBC);
+                        DBG("k_sort_bits M");
+                        ids = c->doneC.template as<u32>();
+                    } else if (use_fast && use_bits) {
                         k_sort_bits<BITS_C_SHAPE><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), 0, st>>>(
                             bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, em, counters, c->doneC.template as<u32>(), (u32)C_FBC);
                         DBG("k_sort_bits C");
@@ -732,7 +816,7 @@ struct Rounds {
                     bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, emC, counters, ids, (u32)C_FBC, gather, code);
                 DBG("k_sort_mid C");
             }
-            if (c->sync_debug) {
+            if (c->sw.sync_debug) {
                 for (int k = 0; k < 3; ++k) {
                     const u32 cnt = c->h_counters[base + k];
                     if (!cnt) continue;
@@ -839,10 +923,11 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     const int verbose = opts ? opts->verbose : 0;
     const bool selected = c->sel_bits != nullptr;      // two-stage build: B* suffixes only; deep ties make the caller fall back
     const bool sharded = W || (opts && opts->n_shards > 1) || selected;
-    const bool auto_switch = !(opts && opts->text_rounds > 0) && !getenv("MSUFSORT_HIP_TEXT_ROUNDS");
+    c->sw.load();
+    const bool auto_switch = !(opts && opts->text_rounds > 0) && c->sw.text_rounds == 0;
     int text_rounds = (opts && opts->text_rounds > 0) ? opts->text_rounds : 24;
     u64 prev_active = 0;
-    if (const char* e = getenv("MSUFSORT_HIP_TEXT_ROUNDS")) text_rounds = std::max(1, atoi(e));
+    if (c->sw.text_rounds > 0) text_rounds = c->sw.text_rounds;
     const u64 m = n - z;
     hipStream_t st = c->stream;
     auto& tm = c->tm;
@@ -861,10 +946,8 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     TRY(c->ensure_workspace(ms));           // (before anything points into it; growing it reallocates buffers the scan fills)
     u32* counters = c->counters.as<u32>();
     Rounds<W> R;
-    R.c = c; R.st = st; R.counters = counters;
+    R.init(c, st, counters);            // (incl. the test hooks: force_retry throws every round's first sort attempt away)
     R.klo = klo; R.khi = khi; R.verbose = verbose;
-    R.force_retry = getenv("MSUFSORT_HIP_FORCE_RETRY") != nullptr;   // test hook: every round's first sort attempt is thrown away
-    R.no_pack = getenv("MSUFSORT_HIP_NO_PACK") != nullptr;
 
     // ---- round 0: 16-bit histogram, offsets, two 8-bit scatter levels ----
     if (!hist_done) TRY(run_hist<W>(c, d_text, m));
@@ -875,19 +958,52 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     RecBufs& bufs = R.bufs;
     sa_t* sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
     R.sa_local = sa_local;
+    // Random-like inputs whose two-byte buckets outgrow the largest LDS sort (uniform bytes from 1.15 GiB): 17 radix bits instead
+    // of 16 - a 17-bit histogram of the text (k_hist17) lets the level-1 partition split 512 ways, so that the children
+    // fit the bucket sort again instead of passing a third partition level (k_count + k_partition: 24 bytes per suffix more).
+    // Unsharded narrow builds only; anything k_hist17 cannot count in its 8-bit LDS counters takes the three-level path.
+    bool radix17 = false;
+    if constexpr (!W) {
+        const bool cand = !selected && !(opts && opts->n_shards > 1) && lo32 == 0 && hi32 == (1ull << 32) && c->sw.radix17 >= 0 &&
+                          (c->sw.radix17 > 0 || (m >> 16) * 10 > (u64)CAP_C * 9);
+        // (switch when about a tenth of the two-byte buckets would pass the class-C limit - uniform counts scatter by sqrt(mean);
+        // a few oversized buckets are cheaper through one more level of their own than 17 bits for everybody: +20 % at 1120 MiB)
+        if (cand) {
+            TRY(c->read_counters());
+            const u64 hmax = c->h_counters[C_HMAX], mean = std::max<u64>(m >> 16, 1);
+            if (c->sw.radix17 > 0 || ((double)mean + 1.3 * std::sqrt((double)mean) > (double)CAP_C && hmax > (u64)CAP_C && hmax <= 2 * mean && hmax <= 2ull * CAP_C)) {
+                HIP_TRY(hipEventRecord(c->ev[10], st));
+                TRY(run_hist17(c, d_text, m));
+                HIP_TRY(hipEventRecord(c->ev[11], st));
+                radix17 = true;
+            }
+        }
+    }
     hipLaunchKernelGGL(k_scatter0<W>, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, m, lo32, hi32, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0], c->alpha.as<u8>(), counters, R.no_pack ? 0u : 1u, c->sel_bits);
     HIP_TRY(hipEventRecord(c->ev[2], st));
     DBG("k_scatter0");
-    hipLaunchKernelGGL(k_partition, dim3(cdiv(cdiv(ms, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
-                       c->tile_start.as<u32>(), 24u, c->cursor.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u);
+    if (radix17) {
+        TRY(c->read_counters());
+        if (c->h_counters[C_H17FLAG]) {
+            if (verbose) fprintf(stderr, "[msufsort_hip] 17-bit histogram declined (flags 0x%x): three-level path\n", c->h_counters[C_H17FLAG]);
+            radix17 = false;
+        }
+    }
+    if (radix17)
+        hipLaunchKernelGGL(k_partition<512>, dim3(cdiv(cdiv(ms, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
+                           c->tile_start.as<u32>(), 23u, c->cursor17.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u);
+    else
+        hipLaunchKernelGGL(k_partition<256>, dim3(cdiv(cdiv(ms, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
+                           c->tile_start.as<u32>(), 24u, c->cursor.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u);
     HIP_TRY(hipEventRecord(c->ev[3], st));
     DBG("k_partition L1");
+    tm.radix_bits = radix17 ? 17 : 16;
 
     u64 depth = 5;               // text bytes consumed after round 0 (narrow: bucket bytes 0,1 + key bytes 2,3,4); set below for wide
     KeySpec ks{};                // dense alphabet code of the gather rounds (k_alphabet; known after round 0)
     ks.sigma = 256; ks.cpk = W ? 3u : 4u; ks.zlow = 0; ks.dig_shift = 0; ks.dig_mask = 0xffffffu;
 
-    TRY(R.children_level1());
+    TRY(R.children_level1(radix17));
     if ((u64)c->h_counters[C_MS] != ms && slice_rows) { set_error("slice bounds disagree with the histogram (%u suffixes on the device, %llu planned)", c->h_counters[C_MS], (unsigned long long)ms); return MSUFSORT_HIP_ERR_INTERNAL; }
 
     if (selected && auto_switch) text_rounds = 64;       // (late rounds of a two-stage build hold a handful of large tie groups: cheap)
@@ -994,7 +1110,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         const sa_t* isa_any = nullptr;
         if constexpr (!W) isa_any = R.isa32;
         R.round = round + 1;              // (wants_fast looks at the round that is about to run)
-        const bool fuse = R.mode == MODE_TEXT && !R.wants_fast() && getenv("MSUFSORT_HIP_NO_FUSE") == nullptr;
+        const bool fuse = R.mode == MODE_TEXT && !R.wants_fast() && !c->sw.no_fuse;
         R.round = round;
         R.code = c->alpha.as<u8>();
         R.gather = GatherSpec{fuse ? d_text : nullptr, n, ks};
@@ -1026,6 +1142,10 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     (void)hipEventElapsedTime(&ms_, c->ev[2], c->ev[3]); tm.scatter1_ms = ms_;
     (void)hipEventElapsedTime(&ms_, c->ev[3], c->ev[4]); tm.bucket_sort_ms = ms_;
     (void)hipEventElapsedTime(&ms_, c->ev[4], c->ev[5]); tm.refine_ms = ms_;
+    if (tm.radix_bits == 17) {      // the 17-bit histogram ran between ev[1] and the level-0 scatter: bill it to the histograms
+        (void)hipEventElapsedTime(&ms_, c->ev[10], c->ev[11]); tm.hist17_ms = ms_;
+        tm.scatter0_ms -= ms_; tm.hist16_ms += ms_;
+    }
     return MSUFSORT_HIP_OK;
 }
 
@@ -1036,12 +1156,11 @@ struct Digits { u32 npass; u32 shift[2], mask[2]; };
 
 // narrow: the rank is the key.  wide: 24 key bits per pass; ranks up to n need bit_length(n) bits.
 template <bool W>
-Digits plan_digits(u64 n)
+Digits plan_digits(u64 n, int digit_bits)
 {
     Digits d{1, {0, 0}, {0xffffffffu, 0}};
     if (!W) return d;
-    u32 kb = 24;
-    if (const char* e = getenv("MSUFSORT_HIP_DIGIT_BITS")) kb = (u32)std::min(24, std::max(2, atoi(e)));   // test hook: narrower passes
+    const u32 kb = (u32)digit_bits;                      // (24; test hook MSUFSORT_HIP_DIGIT_BITS: narrower passes)
     u32 B = 0;
     while (B < 63 && (n >> B) != 0) ++B;
     if (B <= kb) { d.mask[0] = 0xffffffu; return d; }
@@ -1070,7 +1189,7 @@ int double_pass(msufsort_hip_ctx* c, u64 n, typename Wd<W>::sa_t* d_sa_slice, u3
     const u32 hv[2] = {m, 0u};
     HIP_TRY(hipMemcpyAsync(counters + C_MS, hv, 8, hipMemcpyHostToDevice, st));      // C_MS, C_RANK0
     Rounds<W> R;
-    R.c = c; R.st = st; R.counters = counters;
+    R.init(c, st, counters);
     R.bufs = RecBufs{{c->rec[0].as<u64>(), c->rec[1].as<u64>(), c->rec[2].as<u64>()}};
     R.sa_local = d_sa_slice; R.grp_out = d_grp_slice;
     R.cur = 0; R.sb = 2; R.nb = 0; R.mode = MODE_DEFER; R.round = 1; R.discard = 1; R.verbose = verbose;
@@ -1110,7 +1229,8 @@ template <bool W>
 int double_sort(msufsort_hip_ctx* c, ActiveSet& as, u64 n, typename Wd<W>::sa_t* d_sa_slice, u32* d_grp_slice, u32* d_grp_prev_slice, u64 rows,
                 const typename Wd<W>::sa_t* d_isa, u64 h, int verbose, u64* tied_in, u64* items)
 {
-    const Digits dg = plan_digits<W>(n);
+    c->sw.load();
+    const Digits dg = plan_digits<W>(n, c->sw.digit_bits);
     hipStream_t st = c->stream;
     if (as.key_sa != (const void*)d_sa_slice || as.key_rows != rows) { as.valid = false; as.tried_list = false; as.key_sa = d_sa_slice; as.key_rows = rows; }
     if (!as.cap) {
@@ -1409,7 +1529,7 @@ int msufsort_hip_ctx_create(msufsort_hip_ctx** out, int32_t device, int64_t max_
     HIP_TRY(hipSetDevice(device));
     auto* c = new msufsort_hip_ctx();
     c->device = device;
-    if (const char* dbg = getenv("MSUFSORT_HIP_SYNC_DEBUG")) c->sync_debug = atoi(dbg);
+    c->sw.load();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return MSUFSORT_HIP_ERR_HIP; }
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
@@ -1430,6 +1550,7 @@ void msufsort_hip_ctx_destroy(msufsort_hip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    delete c->ring; c->ring = nullptr;
     c->release_all();
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -1486,8 +1607,9 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     // The default policy first looks at what is on the host anyway (length; the byte values among the last 4 KiB, which
     // trailing_zeros fetched, and three 1 KiB samples of the body that came with them): inputs that cannot qualify - short ones,
     // random bytes - do not pay for the typing passes.
+    c->sw.load();
     int two_stage = o.two_stage;
-    if (const char* e = getenv("MSUFSORT_HIP_TWO_STAGE")) two_stage = atoi(e);
+    if (c->sw.two_stage_set) two_stage = c->sw.two_stage;
     bool hist_done = false;
     int why = 0;                 // why a two-stage attempt was handed back (IND_WHY_*; 0: not tried / nothing spent)
     if (two_stage > 0 || (two_stage == 0 && (u64)n >= (48ull << 20) && tail_values <= 128u)) {
@@ -1665,13 +1787,21 @@ int msufsort_hip_make_sa_i32_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64
     TRY(check_n(n));
     if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
     HIP_TRY(hipSetDevice(c->device));
+    c->sw.load();
+    HostTrace tr(c->sw.host_trace, "make_sa_i32_ctx");
+    Prefault pf;
+    pf.start(sa_out, ((size_t)n + 1) * 4);           // the result is usually fresh memory: first touch while the text travels and is sorted
     TRY(c->text_own.ensure((size_t)n + MSUFSORT_HIP_TEXT_PAD));
     TRY(c->sa_own.ensure(((size_t)n + 1) * 4));
     HIP_TRY(hipMemcpyAsync(c->text_own.p, text, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    tr.mark("H2D issued");
     TRY(msufsort_hip_make_sa_i32_dev(c, c->text_own.as<u8>(), n, c->sa_own.as<int32_t>(), opts));
-    HIP_TRY(hipMemcpyAsync(sa_out, c->sa_own.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return MSUFSORT_HIP_OK;
+    tr.mark("built");
+    const int r = copy_out(c, c->stream, sa_out, c->sa_own.p, ((size_t)n + 1) * 4);
+    tr.mark("copied out");
+    pf.wait();
+    tr.mark("first touch joined");
+    return r;
 }
 
 int msufsort_hip_make_sa_i32(const uint8_t* text, int64_t n, int32_t* sa_out, const msufsort_hip_opts* opts)
@@ -1713,13 +1843,13 @@ int msufsort_hip_make_sa_i64_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64
     TRY(check_n64(n));
     if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
     HIP_TRY(hipSetDevice(c->device));
+    Prefault pf;
+    pf.start(sa_out, ((size_t)n + 1) * 8);
     TRY(c->text_own.ensure((size_t)n + MSUFSORT_HIP_TEXT_PAD));
     TRY(c->aux2.ensure(((size_t)n + 1) * 8));
     HIP_TRY(hipMemcpyAsync(c->text_own.p, text, (size_t)n, hipMemcpyHostToDevice, c->stream));
     TRY(msufsort_hip_make_sa_i64_dev(c, c->text_own.as<u8>(), n, c->aux2.as<int64_t>(), opts));
-    HIP_TRY(hipMemcpyAsync(sa_out, c->aux2.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return MSUFSORT_HIP_OK;
+    return copy_out(c, c->stream, sa_out, c->aux2.p, ((size_t)n + 1) * 8);
 }
 
 int msufsort_hip_make_sa_i64(const uint8_t* text, int64_t n, int64_t* sa_out, const msufsort_hip_opts* opts)

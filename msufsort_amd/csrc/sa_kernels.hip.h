@@ -94,6 +94,8 @@ enum {
     C_CARRY = 28,                     // records k_carry_alloc placed in NEXT round's segment array during this round (a repeated
                                       // sort attempt restarts that array behind them, not at 0)
     C_CHAIN = 29,                     // suffixes k_chain_resolve finished (tie groups that are one arithmetic progression of positions)
+    C_H17FLAG = 30,                   // k_hist17 / k_scan17: bit 0 an 8-bit LDS counter wrapped, bit 1 the 17-bit counts disagree with the 16-bit ones
+    C_H17MAX = 31,                    // largest 17-bit bucket
     C_NCOUNTERS = 32
 };
 
@@ -232,6 +234,24 @@ __device__ __forceinline__ u32 scan256_first_wave(const u32* in, u32* out)
         u32 t0 = in[4 * l], t1 = in[4 * l + 1], t2 = in[4 * l + 2], t3 = in[4 * l + 3];
         u32 e = wave_excl_scan(t0 + t1 + t2 + t3, total);
         out[4 * l] = e; out[4 * l + 1] = e + t0; out[4 * l + 2] = e + t0 + t1; out[4 * l + 3] = e + t0 + t1 + t2;
+    }
+    return total;   // valid in wave 0 only
+}
+
+// the same for NB = 256 or 512 values (NB / 64 per lane)
+template <int NB>
+__device__ __forceinline__ u32 scanN_first_wave(const u32* in, u32* out)
+{
+    constexpr int PER = NB / 64;
+    u32 total = 0;
+    if (threadIdx.x < 64) {
+        const u32 l = threadIdx.x;
+        u32 v[PER], sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { v[i] = in[PER * l + i]; sum += v[i]; }
+        u32 e = wave_excl_scan(sum, total);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { out[PER * l + i] = e; e += v[i]; }
     }
     return total;   // valid in wave 0 only
 }
@@ -458,6 +478,123 @@ __global__ __launch_bounds__(256) void k_reduce16(const u32* __restrict__ partia
     }
     for (; c < nchunks; ++c) s0 += partial[(u64)c * 65536u + kle];
     hist[((kle & 255u) << 8) | (kle >> 8)] = s0 + s1 + s2 + s3;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 17-bit histogram for random-like inputs whose two-byte buckets outgrow the largest LDS sort (more than CAP_C records:
+// uniform bytes from 1.15 GiB): key17 = the first 17 bits of the suffix.  With it the level-1 partition splits every
+// first-byte segment 512 ways (k_partition<512>) and the children fit the bucket sort again - instead of a third pass
+// over the records (k_count + k_partition: 24 bytes per suffix more, the 2x cliff of round 3).
+// One workgroup per text chunk of H17_CHUNK bytes keeps all 131,072 bins in LDS as 8-BIT counters, four per word
+// (128 KiB): the path is only taken for spread-out keys, where a bin sees ~H17_CHUNK / 2^17 = 8 keys per chunk.  A byte that
+// wraps changes the sum of all bytes (by -256, or by -255 when it carries into its neighbour), so "sum of the bytes ==
+// keys of the chunk" is an exact no-overflow test; a chunk that fails it raises `flag` and the build takes the
+// three-level path.  partial[chunk] = the raw LDS words; k_reduce17 adds the bytes up.
+// ------------------------------------------------------------------------------------------------
+#define H17_CHUNK (1u << 20)
+#define H17_LDS_BYTES 131072u
+__global__ __launch_bounds__(1024) void k_hist17(const u8* __restrict__ text, u64 m, u32 nchunks, u32* __restrict__ partial, u32* __restrict__ flag)
+{
+    extern __shared__ u32 h_lds[];
+    const u32 chunk = blockIdx.x, t = threadIdx.x;
+    if (chunk >= nchunks) return;
+    uint4* h4 = reinterpret_cast<uint4*>(h_lds);
+    for (u32 i = t; i < 8192u; i += 1024u) h4[i] = make_uint4(0, 0, 0, 0);
+    __shared__ u32 s_sum;
+    if (t == 0) s_sum = 0;
+    __syncthreads();
+    const u64 cbeg = (u64)chunk * H17_CHUNK;
+    const u64 cend = cbeg + H17_CHUNK < m ? cbeg + H17_CHUNK : m;
+    u64 base = cbeg + (u64)t * 16u;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    u32 nx = 0;
+    if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = *reinterpret_cast<const u32*>(text + base + 16); }   // (the text is padded)
+#pragma unroll 1
+    for (; base < cend;) {
+        const uint4 cv = v;
+        const u32 cn = nx;
+        const u64 cb = base;
+        base += 16384u;
+        if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = *reinterpret_cast<const u32*>(text + base + 16); }   // prefetch
+        const u32 w[5] = {cv.x, cv.y, cv.z, cv.w, cn};
+        const u32 lim = cend - cb >= 16 ? 16u : (u32)(cend - cb);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u32 x = (j & 3) ? __builtin_amdgcn_alignbyte(w[(j >> 2) + 1], w[j >> 2], j & 3) : w[j >> 2];     // bytes j, j+1, j+2 (, j+3)
+            const u32 k = ((x & 255u) << 9) | ((x >> 7) & 0x1feu) | ((x >> 23) & 1u);
+            if ((u32)j < lim) atomicAdd(&h_lds[k >> 2], 1u << ((k & 3u) * 8u));
+        }
+    }
+    __syncthreads();
+    u32 sum = 0;
+    uint4* out4 = reinterpret_cast<uint4*>(partial + (u64)chunk * 32768u);
+    for (u32 i = t; i < 8192u; i += 1024u) {
+        const uint4 q = h4[i];
+        out4[i] = q;
+        // bytes of four words summed pairwise: (q & 0x00ff00ff) + ((q >> 8) & 0x00ff00ff) holds two 16-bit sums per word
+        const u32 a = (q.x & 0x00ff00ffu) + ((q.x >> 8) & 0x00ff00ffu), b = (q.y & 0x00ff00ffu) + ((q.y >> 8) & 0x00ff00ffu);
+        const u32 c2 = (q.z & 0x00ff00ffu) + ((q.z >> 8) & 0x00ff00ffu), d = (q.w & 0x00ff00ffu) + ((q.w >> 8) & 0x00ff00ffu);
+        const u32 e = a + b + c2 + d;
+        sum += (e & 0xffffu) + (e >> 16);
+    }
+    sum = wave_sum(sum);
+    if (lane_id() == 0) atomicAdd(&s_sum, sum);
+    __syncthreads();
+    if (t == 0 && s_sum != (u32)(cend - cbeg)) atomicOr(flag, 1u);
+}
+
+// hist17[k] = sum over the chunks of byte k of partial[chunk] (hist17 zeroed by the caller); blockIdx.y = group of chunks
+__global__ __launch_bounds__(256) void k_reduce17(const u32* __restrict__ partial, u32 nchunks, u32 per_group, u32* __restrict__ hist17)
+{
+    const u32 word = blockIdx.x * 256u + threadIdx.x;        // 32768 words of four bins
+    const u32 c0 = blockIdx.y * per_group;
+    const u32 c1 = c0 + per_group < nchunks ? c0 + per_group : nchunks;
+    u32 lo = 0, hi = 0;                                       // bins 0, 2 | bins 1, 3 as 16-bit sums (per_group <= 256 chunks x 255)
+    u32 s[4] = {0, 0, 0, 0};
+    for (u32 c = c0; c < c1; ++c) {
+        const u32 q = partial[(u64)c * 32768u + word];
+        lo += q & 0x00ff00ffu; hi += (q >> 8) & 0x00ff00ffu;
+        if (((c - c0) & 255u) == 255u) { s[0] += lo & 0xffffu; s[2] += lo >> 16; s[1] += hi & 0xffffu; s[3] += hi >> 16; lo = 0; hi = 0; }
+    }
+    s[0] += lo & 0xffffu; s[2] += lo >> 16; s[1] += hi & 0xffffu; s[3] += hi >> 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (s[i]) atomicAdd(&hist17[word * 4u + i], s[i]);
+}
+
+// exclusive scan of the 131,072 counts -> start, cursor and count of every 17-bit bucket (record offsets of an unsharded
+// build).  Cross-check against the 16-bit histogram the level-0 scatter was set up with: a mismatch raises `flag`.
+__global__ __launch_bounds__(1024) void k_scan17(const u32* __restrict__ hist17, const u32* __restrict__ hist16,
+                                                 u32* __restrict__ child_start, u32* __restrict__ child_cnt, u32* __restrict__ cursor1,
+                                                 u32* __restrict__ flag, u32* __restrict__ hmax17)
+{
+    __shared__ u32 wsum[16];
+    const u32 t = threadIdx.x;
+    const uint4* h4 = reinterpret_cast<const uint4*>(hist17) + (u64)t * 32u;      // 128 consecutive bins per thread
+    u32 loc = 0, mx = 0, bad = 0;
+    for (u32 i = 0; i < 32u; ++i) {
+        const uint4 q = h4[i];
+        loc += q.x + q.y + q.z + q.w;
+        mx = max(max(mx, max(q.x, q.y)), max(q.z, q.w));
+        const u32 k16 = t * 64u + i * 2u;
+        bad |= (q.x + q.y != hist16[k16]) | (q.z + q.w != hist16[k16 + 1]);
+    }
+    u32 wtot;
+    const u32 e = wave_excl_scan(loc, wtot);
+    if (lane_id() == 63) wsum[t >> 6] = wtot;
+    __syncthreads();
+    u32 run = e;
+    for (u32 k = 0; k < (t >> 6); ++k) run += wsum[k];
+    for (u32 i = 0; i < 32u; ++i) {
+        const uint4 q = h4[i];
+        const uint4 st = make_uint4(run, run + q.x, run + q.x + q.y, run + q.x + q.y + q.z);
+        reinterpret_cast<uint4*>(child_start)[(u64)t * 32u + i] = st;
+        reinterpret_cast<uint4*>(cursor1)[(u64)t * 32u + i] = st;
+        reinterpret_cast<uint4*>(child_cnt)[(u64)t * 32u + i] = q;
+        run += q.x + q.y + q.z + q.w;
+    }
+    if (bad) atomicOr(flag, 2u);
+    for (int s2 = 32; s2 >= 1; s2 >>= 1) { const u32 o = __shfl_xor(mx, s2, 64); mx = o > mx ? o : mx; }
+    if (lane_id() == 0) atomicMax(hmax17, mx);
 }
 
 // A shard works on its own key range: everything outside [klo, khi) reads as 0 (wide builds: the global counts are 64-bit,
@@ -889,19 +1026,20 @@ __global__ __launch_bounds__(256) void k_segscan(const Desc* __restrict__ list, 
     if (t == 0 && d.len == 0) trivial[s] = 1u;
 }
 
+template <int NB>
 __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                           const u32* __restrict__ tile_start, u32 shift,
                                                           u32* __restrict__ cursor, const u32* __restrict__ trivial,
                                                           u32 alt0, u32 alt1, u32 alt2)
 {
     __shared__ __attribute__((aligned(16))) u64 stage[P1_TILE];
-    __shared__ u32 hist[256], lstart[256], gbase[256];
+    __shared__ u32 hist[NB], lstart[NB], gbase[NB];
     __shared__ u32 s_seg, s_total;
     const u32 t = threadIdx.x;
     const u32 tile = xcd_tile(blockIdx.x, 512u);
     if (tile >= tile_start[nseg]) return;
     if (t == 0) s_seg = find_seg(tile_start, nseg, tile);
-    if (t < 256) hist[t] = 0;
+    if (t < NB) hist[t] = 0;
     __syncthreads();
     const u32 s = s_seg;
     if (trivial && trivial[s]) return;
@@ -920,30 +1058,30 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
         if (p < d.len) {
             const Rec2 v = *reinterpret_cast<const Rec2*>(src + p);      // (may read one record past the segment)
             rec[j] = v.a; rec[j + 1] = v.b;
-            rank[j] = atomicAdd(&hist[(u32)(rec[j] >> (32 + shift)) & 255u], 1u);
-            if (p + 1 < d.len) rank[j + 1] = atomicAdd(&hist[(u32)(rec[j + 1] >> (32 + shift)) & 255u], 1u);
+            rank[j] = atomicAdd(&hist[(u32)(rec[j] >> (32 + shift)) & (u32)(NB - 1)], 1u);
+            if (p + 1 < d.len) rank[j + 1] = atomicAdd(&hist[(u32)(rec[j + 1] >> (32 + shift)) & (u32)(NB - 1)], 1u);
         }
     }
     __syncthreads();
     u32 claim = 0;
-    if (t < 256) { const u32 c = hist[t]; if (c) claim = atomicAdd(&cursor[(u64)s * 256u + t], c); }
-    const u32 total = scan256_first_wave(hist, lstart);
+    if (t < NB) { const u32 c = hist[t]; if (c) claim = atomicAdd(&cursor[(u64)s * (u32)NB + t], c); }
+    const u32 total = scanN_first_wave<NB>(hist, lstart);
     if (t == 0) s_total = total;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < P1_ITEMS; ++j) {
         if (rank[j] != 0xffffffffu) {
-            const u32 b = (u32)(rec[j] >> (32 + shift)) & 255u;
+            const u32 b = (u32)(rec[j] >> (32 + shift)) & (u32)(NB - 1);
             const u32 slot = lstart[b] + rank[j];
             stage[slot] = rec[j];
         }
     }
-    if (t < 256) gbase[t] = claim - lstart[t];            // slot -> output index is one add: dst[gbase[bin] + slot]
+    if (t < NB) gbase[t] = claim - lstart[t];            // slot -> output index is one add: dst[gbase[bin] + slot]
     __syncthreads();
     const u32 tot = s_total;
     for (u32 q = t; q < tot; q += P1_THREADS) {
         const u64 r = stage[q];
-        dst[gbase[(u32)(r >> (32 + shift)) & 255u] + q] = r;      // the bin is in the record itself
+        dst[gbase[(u32)(r >> (32 + shift)) & (u32)(NB - 1)] + q] = r;      // the bin is in the record itself
     }
 }
 
@@ -957,11 +1095,11 @@ __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __re
                                                   typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32* __restrict__ grp_out, u32 mode,
                                                   u64* __restrict__ pool_rec, u64* __restrict__ pool_hdr, u32 pool_cnt_idx, u32 pool_cap,
                                                   Lists lists, Desc* __restrict__ lvl_dst, u32 lvl_cap, u32 lvl_cnt_idx, u32 lvl_tiles_idx,
-                                                  u32* __restrict__ counters)
+                                                  u32* __restrict__ counters, u32 cbits = 8u /* log2(children per segment) */)
 {
     const u64 c = (u64)blockIdx.x * 256u + threadIdx.x;
-    const bool live = c < (u64)nseg * 256u;
-    const u32 s = live ? (u32)(c >> 8) : 0u;
+    const bool live = c < ((u64)nseg << cbits);
+    const u32 s = live ? (u32)(c >> cbits) : 0u;
     const u32 cnt = live ? child_cnt[c] : 0u;
     Desc par = {0, 0, 0, 0};
     u32 start = 0, buf = 0, sa = 0;

@@ -802,3 +802,63 @@ def test_two_stage_fixed_tile_assignment(M, oracle_mod, monkeypatch):
     monkeypatch.setenv("MSUFSORT_HIP_IND_FIXED", "1")
     _two_stage(M, oracle_mod, gen.text_bytes((2 << 20) + 9, 53))
     _two_stage(M, oracle_mod, gen.dna_bytes(1 << 20, 54))
+
+
+@pytest.mark.parametrize("kind,n", [("random", 1 << 16), ("random", 300007), ("random", (3 << 20) + 11), ("zeros_tail", 1 << 18), ("text", 1 << 19), ("dna", 1 << 19),
+                                    ("two_values", 1 << 17)])
+def test_radix17_forced(M, oracle_mod, monkeypatch, kind, n):
+    """The 17-bit front end (k_hist17 + k_scan17 + k_partition<512>; default only for random-like inputs whose two-byte buckets
+    outgrow the largest LDS sort, i.e. above 1.15 GiB) forced on small inputs: same rows as the reference.  Skewed inputs make
+    its 8-bit LDS counters wrap - the build must notice and take the 16-bit path (radix_bits says which one ran)."""
+    import torch
+    if kind == "random":
+        t = gen.random_bytes(n, 17)
+    elif kind == "zeros_tail":
+        t = gen.random_bytes(n, 18).copy(); t[-5000:] = 0
+    elif kind == "text":
+        t = gen.text_bytes(n, 19)
+    elif kind == "dna":
+        t = gen.dna_bytes(n, 20)
+    else:
+        t = (gen.random_bytes(n, 21) & 1).astype(np.uint8) + 65
+    want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+    monkeypatch.setenv("MSUFSORT_HIP_RADIX17", "1")
+    ctx = M.DeviceContext(0)                      # (the policy is read when the context is created)
+    d = _dev(M, t)
+    sa = torch.empty(t.size + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, t.size, sa, two_stage=-1)
+    tm = ctx.timings()
+    assert (sa.cpu().numpy() == want).all()
+    if kind == "random":
+        assert tm.radix_bits == 17
+    assert tm.radix_bits in (16, 17)
+    ctx.make_sa(d, t.size, sa, two_stage=-1, logical_shards=3)          # sharded builds keep the 16-bit levels
+    assert (sa.cpu().numpy() == want).all()
+
+
+def test_host_entry_points_fresh_result(M, oracle_mod):
+    """Host-pointer entry points above the ring threshold (64 MiB of result): pageable text in, a FRESH numpy array out -
+    first touch by the library's own threads, device-to-host through the pinned ring - equal to the rows a device-resident
+    build returns, for the streamed shards of random bytes and for the one-build path of a text; LCP and BWT likewise."""
+    import torch
+    n = (20 << 20) + 12345                       # 80 MiB of rows
+    for kind in ("random", "text"):
+        t = gen.GENERATORS[kind](n, 31)
+        ctx = M.DeviceContext(0)
+        d = _dev(M, t)
+        ref = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        ctx.make_sa(d, n, ref)
+        want = ref.cpu().numpy()
+        sa = M.make_suffix_array_multi(t, [0])
+        assert (sa == want).all()
+        assert (M.make_suffix_array(t) == want).all()
+        lcp = M.make_lcp_array(t, want)
+        dl = torch.empty(n, dtype=torch.int32, device="cuda")
+        ctx.lcp(d, n, ref, dl)
+        assert (lcp == dl.cpu().numpy()).all()
+        del ctx, d, ref, dl
+        torch.cuda.empty_cache()
+    n = (70 << 20) + 5                           # BWT bytes above the threshold
+    t = gen.text_bytes(n, 32)
+    b, s = M.forward_burrows_wheeler_transform(t)
+    assert (M.reverse_burrows_wheeler_transform(b, s) == t).all()
