@@ -109,6 +109,7 @@ _Static_assert(sizeof(msufsort_hip_timings) == 216, "msufsort_hip_timings change
 int msufsort_hip_device_count(void);
 const char* msufsort_hip_strerror(int status);
 const char* msufsort_hip_last_error(void);             /* thread-local detail of the last failure */
+const char* msufsort_hip_build_id(void);               /* hash of the sources this library was built from (msufsort_amd/csrc/Makefile) */
 
 /* Context: stream + workspace for inputs up to max_n bytes (grown on demand if exceeded). */
 int msufsort_hip_ctx_create(msufsort_hip_ctx** out, int32_t device, int64_t max_n);

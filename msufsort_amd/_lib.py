@@ -35,7 +35,7 @@ class Timings(C.Structure):
 
 # every symbol include/msufsort_hip.h declares (checked by tests/test_cabi.py)
 SYMBOLS = [
-    "msufsort_hip_device_count", "msufsort_hip_strerror", "msufsort_hip_last_error",
+    "msufsort_hip_device_count", "msufsort_hip_strerror", "msufsort_hip_last_error", "msufsort_hip_build_id",
     "msufsort_hip_ctx_create", "msufsort_hip_ctx_destroy", "msufsort_hip_ctx_stream", "msufsort_hip_ctx_sync",
     "msufsort_hip_last_timings", "msufsort_hip_make_sa_i32", "msufsort_hip_make_sa_i32_dev",
     "msufsort_hip_make_sa_shard_dev", "msufsort_hip_shard_bounds_dev", "msufsort_hip_plan_cuts",
@@ -78,6 +78,7 @@ def lib():
     L.msufsort_hip_strerror.restype = C.c_char_p
     L.msufsort_hip_strerror.argtypes = [C.c_int]
     L.msufsort_hip_last_error.restype = C.c_char_p
+    L.msufsort_hip_build_id.restype = C.c_char_p
     L.msufsort_hip_ctx_create.argtypes = [C.POINTER(vp), i32, i64]
     L.msufsort_hip_ctx_destroy.argtypes = [vp]
     L.msufsort_hip_ctx_destroy.restype = None

@@ -33,11 +33,6 @@
 
 // class C: 1024 threads x 18 records = every class-C segment (18,432), 2560 dirty-list entries (a full segment: 2030 +- 80)
 #define BITS_C_SHAPE 1024, 18, 18432, 2560, 128
-// between them: 512 threads, segments up to 8704 records, 1152 dirty-list entries (a full segment: 960 +- 55); 78,160 B of LDS: two
-// workgroups per CU (9216 records + 1280 entries = 81,232 B did not leave room for two: measured 4.0 ms per GiB of records against
-// 2.8 for the large shape).  Not a size class of its own: round 0 of a random-like input whose buckets ALL fit it runs this shape
-// over the class-C list
-#define BITS_M_SHAPE 512, 18, 8704, 1152, 64
 // class B: 256 threads x 18 records = every class-B segment (4608), 640 dirty-list entries; 40,912 B of LDS: four workgroups per CU
 #define BITS_B_SHAPE 256, 18, 4608, 640, 32
 

@@ -462,7 +462,10 @@ int run_scan(msufsort_hip_ctx* c, const u8* d_text, u64 m, u64 lo32, u64 hi32, u
 // with the 16-bit histogram) and the largest 17-bit bucket land in counters[C_H17FLAG], counters[C_H17MAX].
 int run_hist17(msufsort_hip_ctx* c, const u8* d_text, u64 m)
 {
-    const u32 nch = cdiv(m, H17_CHUNK);
+    // a multiple of 256 chunks of at most H17_CHUNK bytes each (multiples of 16 KiB: a workgroup reads 16 KiB per iteration)
+    const u32 rounds = std::max<u32>(1, cdiv(m, (u64)256 * H17_CHUNK));
+    const u32 chunk_len = (u32)((cdiv(m, 256u * rounds) + 16383u) & ~16383u);
+    const u32 nch = cdiv(m, chunk_len);
     TRY(c->h17_partial.ensure((size_t)nch * 131072));
     TRY(c->h17.ensure(131072 * 4));
     TRY(c->child_start17.ensure(131072 * 4));
@@ -470,7 +473,7 @@ int run_hist17(msufsort_hip_ctx* c, const u8* d_text, u64 m)
     TRY(c->cursor17.ensure(131072 * 4));
     u32* counters = c->counters.as<u32>();
     HIP_TRY(hipMemsetAsync(c->h17.p, 0, 131072 * 4, c->stream));
-    hipLaunchKernelGGL(k_hist17, dim3(nch), dim3(1024), H17_LDS_BYTES, c->stream, d_text, m, nch, c->h17_partial.as<u32>(), counters + C_H17FLAG);
+    hipLaunchKernelGGL(k_hist17, dim3(nch), dim3(1024), H17_LDS_BYTES, c->stream, d_text, m, chunk_len, nch, c->h17_partial.as<u32>(), counters + C_H17FLAG);
     const u32 groups = std::max<u32>(1, std::min<u32>(16, nch / 32));
     const u32 per_group = cdiv(nch, groups);
     hipLaunchKernelGGL(k_reduce17, dim3(128, groups), dim3(256), 0, c->stream, c->h17_partial.as<u32>(), nch, per_group, c->h17.as<u32>());
@@ -587,7 +590,6 @@ struct Rounds {
         force_retry = c->sw.force_retry; no_pack = c->sw.no_pack;
     }
     u32 nA = 0, nB = 0, nC = 0, nP = 0;
-    u32 round0_max = 0;                  // largest bucket the level-1 partition produced (two-byte buckets, or 17-bit ones)
     u32 deep_cap = 0;                    // != 0: k_sort_tiny finishes its runs by comparing the suffixes themselves (two-stage builds)
     GatherSpec gather{nullptr, 0, {}};   // text rounds: the sorts (and the first partition level) gather the keys themselves
     const u8* code = nullptr;            // dense alphabet code (device)
@@ -647,9 +649,7 @@ struct Rounds {
                            c->pool_rec[cur].template as<u64>(), c->pool_hdr[cur].template as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), cap32(),
                            make_lists(cur), c->lvl[0].template as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters, radix17 ? 9u : 8u);
         DBG("k_children L1");
-        TRY(c->read_counters());
-        round0_max = radix17 ? c->h_counters[C_H17MAX] : c->h_counters[C_HMAX];
-        return MSUFSORT_HIP_OK;
+        return c->read_counters();
     }
 
     int levels_and_sorts()
@@ -769,14 +769,7 @@ struct Rounds {
             if (nC) {
                 const u32* ids = nullptr;
                 if constexpr (!W) {
-                    if (use_fast && use_bits && round == 0 && round0_max != 0 && round0_max <= 8704u) {
-                        // every bucket of this (random-like) input fits the half-size shape: two workgroups per CU, half the
-                        // words to clear and scan per segment (the 285 -> 296 MiB step of round 3: 4.7 K-record buckets in the 18 K shape)
-                        k_sort_bits<BITS_M_SHAPE><<<dim3(std::min<u32>(nC, 256u * 2u)), dim3(512), 0, st>>>(
-                            bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, em, counters, c->doneC.template as<u32>(), (u32)C_FBC);
-                        DBG("k_sort_bits M");
-                        ids = c->doneC.template as<u32>();
-                    } else if (use_fast && use_bits) {
+                    if (use_fast && use_bits) {
                         k_sort_bits<BITS_C_SHAPE><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), 0, st>>>(
                             bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, em, counters, c->doneC.template as<u32>(), (u32)C_FBC);
                         DBG("k_sort_bits C");
@@ -964,14 +957,20 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     // Unsharded narrow builds only; anything k_hist17 cannot count in its 8-bit LDS counters takes the three-level path.
     bool radix17 = false;
     if constexpr (!W) {
+        // ... and inputs whose two-byte buckets are just too large for the 4608-record shape (uniform bytes of 290 - 560 MiB): their
+        // 17-bit children fill it, where the 18,432-record shape would run a quarter to half empty (3.28 against 3.88 ms at 296 MiB)
+        const u64 mean16 = m >> 16;
         const bool cand = !selected && !(opts && opts->n_shards > 1) && lo32 == 0 && hi32 == (1ull << 32) && c->sw.radix17 >= 0 &&
-                          (c->sw.radix17 > 0 || (m >> 16) * 10 > (u64)CAP_C * 9);
+                          (c->sw.radix17 > 0 || mean16 * 10 > (u64)CAP_C * 9 || (mean16 > (u64)CAP_B && mean16 <= 8900));
         // (switch when about a tenth of the two-byte buckets would pass the class-C limit - uniform counts scatter by sqrt(mean);
         // a few oversized buckets are cheaper through one more level of their own than 17 bits for everybody: +20 % at 1120 MiB)
         if (cand) {
             TRY(c->read_counters());
             const u64 hmax = c->h_counters[C_HMAX], mean = std::max<u64>(m >> 16, 1);
-            if (c->sw.radix17 > 0 || ((double)mean + 1.3 * std::sqrt((double)mean) > (double)CAP_C && hmax > (u64)CAP_C && hmax <= 2 * mean && hmax <= 2ull * CAP_C)) {
+            const bool over_c = (double)mean + 1.3 * std::sqrt((double)mean) > (double)CAP_C && hmax > (u64)CAP_C && hmax <= 2ull * CAP_C;
+            // (buckets just over the 4608-record shape simply take the large one: 17 bits pay once most of them are over)
+            const bool over_b = mean > (u64)CAP_B && mean <= 8900;
+            if (c->sw.radix17 > 0 || ((over_c || over_b) && hmax <= 2 * mean)) {
                 HIP_TRY(hipEventRecord(c->ev[10], st));
                 TRY(run_hist17(c, d_text, m));
                 HIP_TRY(hipEventRecord(c->ev[11], st));
@@ -1520,6 +1519,11 @@ const char* msufsort_hip_strerror(int status)
 }
 
 const char* msufsort_hip_last_error(void) { return g_last_error.c_str(); }
+
+#ifndef MSUFSORT_HIP_BUILD_ID
+#define MSUFSORT_HIP_BUILD_ID "unknown"
+#endif
+const char* msufsort_hip_build_id(void) { return MSUFSORT_HIP_BUILD_ID; }
 
 int msufsort_hip_ctx_create(msufsort_hip_ctx** out, int32_t device, int64_t max_n)
 {

@@ -491,9 +491,10 @@ __global__ __launch_bounds__(256) void k_reduce16(const u32* __restrict__ partia
 // keys of the chunk" is an exact no-overflow test; a chunk that fails it raises `flag` and the build takes the
 // three-level path.  partial[chunk] = the raw LDS words; k_reduce17 adds the bytes up.
 // ------------------------------------------------------------------------------------------------
-#define H17_CHUNK (1u << 20)
+#define H17_CHUNK (1u << 20)       // upper bound of a chunk; the host cuts the text into a multiple of 256 chunks (one wave of workgroups
+                                   // per CU and no ragged last round: 296 one-MiB chunks took two rounds, the second 16 % full)
 #define H17_LDS_BYTES 131072u
-__global__ __launch_bounds__(1024) void k_hist17(const u8* __restrict__ text, u64 m, u32 nchunks, u32* __restrict__ partial, u32* __restrict__ flag)
+__global__ __launch_bounds__(1024) void k_hist17(const u8* __restrict__ text, u64 m, u32 chunk_len, u32 nchunks, u32* __restrict__ partial, u32* __restrict__ flag)
 {
     extern __shared__ u32 h_lds[];
     const u32 chunk = blockIdx.x, t = threadIdx.x;
@@ -503,8 +504,8 @@ __global__ __launch_bounds__(1024) void k_hist17(const u8* __restrict__ text, u6
     __shared__ u32 s_sum;
     if (t == 0) s_sum = 0;
     __syncthreads();
-    const u64 cbeg = (u64)chunk * H17_CHUNK;
-    const u64 cend = cbeg + H17_CHUNK < m ? cbeg + H17_CHUNK : m;
+    const u64 cbeg = (u64)chunk * chunk_len < m ? (u64)chunk * chunk_len : m;
+    const u64 cend = cbeg + chunk_len < m ? cbeg + chunk_len : m;
     u64 base = cbeg + (u64)t * 16u;
     uint4 v = make_uint4(0, 0, 0, 0);
     u32 nx = 0;

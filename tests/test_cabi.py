@@ -80,3 +80,31 @@ def test_bench_refuses_ranks_without_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_size_limits_reported_not_corrupted(L):
+    """The reference corrupts its output silently from n = 2^30 on.  Here every entry point states its
+    limit: the int32 rows, the inverse BWT and the LCP stop at 2^31 - 2 bytes (the forward BWT and the int64 rows go on to
+    2^40 - 2 through the wide engine).  The checks sit in front of any device work, so they hold on a box without a GPU."""
+    import ctypes as C
+    buf = (C.c_uint8 * 16)()
+    out = (C.c_int32 * 16)()
+    too_large = -3
+    big = (1 << 31) - 1
+    assert L.msufsort_hip_make_sa_i32(buf, big, out, None) == too_large
+    assert L.msufsort_hip_inverse_bwt(buf, big, 1, None) == too_large and b"2^31-2" in L.msufsort_hip_last_error()
+    assert L.msufsort_hip_lcp_i32(buf, big, out, out, None) == too_large
+    assert L.msufsort_hip_make_sa_i64(buf, 1 << 40, out, None) == too_large
+    sent = C.c_int64(0)
+    assert L.msufsort_hip_forward_bwt(buf, 1 << 40, C.byref(sent), None) == too_large
+    assert L.msufsort_hip_make_sa_i32(buf, -1, out, None) == -2          # bad argument
+
+
+def test_timings_struct_size_is_frozen():
+    """msufsort_hip_timings is written into caller memory (timings_out): its size is part of the ABI (round-3 advisor finding;
+    the header static_asserts the same number)."""
+    import ctypes as C
+    from msufsort_amd import _lib
+    assert C.sizeof(_lib.Timings) == 216
+    hdr = open(os.path.join(ROOT, "include", "msufsort_hip.h")).read()
+    assert "sizeof(msufsort_hip_timings) == 216" in hdr

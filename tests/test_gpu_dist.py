@@ -24,6 +24,31 @@ def test_bench_two_ranks_one_gpu():
     assert d["n_gpus"] == 2 and d["valid"] is True and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["rccl_ranks"] == 2 and d["latency_ms"] > 0 and d["exchange_ms"] >= 0
     assert len(d["per_rank"]["sort_ms"]) == 2 and sum(d["per_rank"]["rows"]) == (1 << 24) + 1
+    # `value` is the latency of complete builds (sort + exchange, nothing overlapped); the pipelined rate is a secondary field
+    assert d["config"]["pipelined"] is False and d["pipelined"]["MBps"] > 0 and d["ms_per_step"] >= 0.5 * d["latency_ms"]
+
+
+@pytest.mark.parametrize("world,workload", [(4, "random"), (4, "dna"), (4, "dna_tandem"), (8, "random"), (8, "dna"), (8, "dna_tandem")])
+def test_bench_four_and_eight_ranks_one_gpu(world, workload):
+    """First-contact hardening of the 4- and 8-rank flows (the driver's 8-GPU node is the first place they meet RCCL): every rank
+    of `python bench.py --gpus N` shares cuda:0 over gloo.  random: eight even key ranges; dna: 16 two-byte keys in all, so the
+    cuts fall INSIDE heavy keys (deeper histogram, 4-byte-prefix ranges); dna_tandem: the shards stop unresolved and finish with
+    the distributed prefix doubling.  The assembled array is checked on the device by rank 0 (`valid`)."""
+    env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    n = 1 << 22 if workload == "dna_tandem" else 1 << 24          # (a dozen doubling steps through 4 - 8 python ranks: 80 s at 16 MiB)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0",
+           "--size", str(n), "--workload", workload, "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == world and d["config"]["rccl_ranks"] == world and d["valid"] is True
+    rows = d["per_rank"]["rows"]
+    assert len(rows) == world and sum(rows) == n + 1
+    if workload in ("random", "dna"):
+        assert max(rows) <= 1.25 * (n / world) + 2, rows          # balanced, also where two-byte keys are heavier than a shard
+    if workload == "dna_tandem":
+        assert d["doubling"]["doubling_steps"] >= 1 and d["doubling"]["updates"] > 0
 
 
 def test_bench_refuses_more_ranks_than_gpus():

@@ -13,7 +13,7 @@ t = gen.GENERATORS[workload](n, 12345)
 L = _lib.lib()
 for r in range(reps):
     sa = np.empty(n + 1, dtype=np.int32)
-    o = _opts(); dv = (C.c_int32 * 1)(0)
+    o = _opts(n_shards=int(os.environ.get("SHARDS", "0"))); dv = (C.c_int32 * 1)(0)
     t0 = time.perf_counter()
     _lib.check(L.msufsort_hip_make_sa_multi(dv, 1, t.ctypes.data, n, sa.ctypes.data, 4, C.byref(o), None), "make_sa_multi")
     dt = time.perf_counter() - t0
