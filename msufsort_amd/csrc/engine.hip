@@ -86,6 +86,8 @@ struct Switches {
     int two_stage = 0; bool two_stage_set = false;      // MSUFSORT_HIP_TWO_STAGE overrides opts->two_stage
     int lcp_cap = 512;           // MSUFSORT_HIP_LCP_CAP
     int ind_spin = 1 << 22;      // MSUFSORT_HIP_IND_SPIN: bound of the induction's look-back spins
+    int ind_grid = 0;            // MSUFSORT_HIP_IND_GRID: workgroups per induction level launch (0: what the chip holds at once; tests: a small grid,
+                                 // or one larger than the chip holds so that the launch settles on the ticket counter)
     int radix17 = 0;             // MSUFSORT_HIP_RADIX17: -1 never, 0 when the two-byte buckets of a random-like input outgrow class C, 1 always (tests)
     int sync_debug = 0;          // MSUFSORT_HIP_SYNC_DEBUG
     bool host_trace = false;     // MSUFSORT_HIP_HOST_TRACE: timeline of the host-pointer entry points on stderr
@@ -103,6 +105,7 @@ struct Switches {
         two_stage_set = on("MSUFSORT_HIP_TWO_STAGE"); two_stage = num("MSUFSORT_HIP_TWO_STAGE", 0);
         lcp_cap = std::max(8, num("MSUFSORT_HIP_LCP_CAP", 512));
         ind_spin = std::max(1, num("MSUFSORT_HIP_IND_SPIN", 1 << 22));
+        ind_grid = std::max(0, num("MSUFSORT_HIP_IND_GRID", 0));
         radix17 = num("MSUFSORT_HIP_RADIX17", 0);
         sync_debug = num("MSUFSORT_HIP_SYNC_DEBUG", 0);
         host_trace = on("MSUFSORT_HIP_HOST_TRACE");
@@ -124,6 +127,7 @@ struct ActiveSet {
 struct msufsort_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;            // second stream of the streaming host path (slices leave while the next shard is sorted)
     bool attrs_set = false;
     // workspace
     DevBuf rec[3], pool_rec[2], pool_hdr[2];
@@ -137,6 +141,7 @@ struct msufsort_hip_ctx {
     DevBuf ind_sbits, sel_partial, sel_hist, ind_sstar, ind_pc, ind_tiles, ind_state, ind_tables;
     const u8* sel_bits = nullptr;                 // != nullptr: build_sa sorts only the positions whose bit is set
     u32* h_ind = nullptr;                         // pinned staging for the induction tables
+    u32 ind_resident = 0;                         // workgroups of k_ind_fused the device holds at once (occupancy x CUs), asked once
     DevBuf sub_partial, sub_hist, sub_saved;      // deeper histogram of ONE two-byte key (shard boundaries inside heavy keys)
     int64_t sub_key = -1;                         // which key sub_partial describes (-1: none); valid for the current text only
     DevBuf grp_full, grp_prev, upd, upd_cnt;      // single-process sharded builds: tie-group heads (all rows), their copy at the
@@ -1561,6 +1566,7 @@ void msufsort_hip_ctx_destroy(msufsort_hip_ctx* c)
     if (c->h_hist) (void)hipHostFree(c->h_hist);
     if (c->h_upd) (void)hipHostFree(c->h_upd);
     if (c->h_ind) (void)hipHostFree(c->h_ind);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

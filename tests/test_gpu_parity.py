@@ -796,10 +796,13 @@ def test_two_stage_three_kernel_levels(M, oracle_mod, monkeypatch):
     _two_stage(M, oracle_mod, gen.dna_bytes(1 << 20, 52))
 
 
-def test_two_stage_fixed_tile_assignment(M, oracle_mod, monkeypatch):
-    """MSUFSORT_HIP_IND_FIXED=1: induction tiles assigned by workgroup index instead of drawn from the ticket counter (opt-in:
-    it needs every workgroup of a launch resident - trivially true at these sizes) give the same rows."""
-    monkeypatch.setenv("MSUFSORT_HIP_IND_FIXED", "1")
+@pytest.mark.parametrize("grid", [3, 64, 100000])
+def test_two_stage_tile_handout_modes(M, oracle_mod, monkeypatch, grid):
+    """How an induction level hands out its tiles is settled per launch (k_ind_fused: every workgroup draws one ticket; when all
+    workgroups of the launch are seen running, the rest is fixed stride, else the ticket counter).  MSUFSORT_HIP_IND_GRID sets
+    the launch size: a few workgroups with hundreds of tiles each (fixed stride), a launch of the chip's size, and one far
+    larger than the chip holds - the same rows as the reference every time."""
+    monkeypatch.setenv("MSUFSORT_HIP_IND_GRID", str(grid))
     _two_stage(M, oracle_mod, gen.text_bytes((2 << 20) + 9, 53))
     _two_stage(M, oracle_mod, gen.dna_bytes(1 << 20, 54))
 
