@@ -190,6 +190,25 @@ int msufsort_hip_emit_updates_dev(msufsort_hip_ctx* ctx, const void* d_sa_slice,
                                   int64_t* count, int64_t* tied_rows);
 int msufsort_hip_apply_updates_dev(msufsort_hip_ctx* ctx, const void* d_updates, int64_t count, void* d_isa,
                                    int32_t index_bytes);
+/* Two-stage build with a SHARDED first stage (text-like inputs over several GPUs; the reference's own structure, msufsort.cpp:1559-1726
+ * + 646-1057, with its first stage - the only part that sorts - split by key range like its partitions, cpp:1652-1683).
+ * Every rank calls this with its shard number: the front end (suffix types, histograms) runs on every rank, rank g sorts the B*
+ * suffixes of its range of two-byte keys into its slice of d_bstar (ALL sorted B* suffixes, at most n / 2 entries), then
+ * `exchange` is called ONCE on every rank - bounds[n_shards + 1] = slice bounds in d_bstar, my_status = 0 (sorted) or 1 (my
+ * shard's ties run too deep) - and must (a) agree on one status over all ranks (max), (b) if it is 0, all-gatherv the slices
+ * in place (complete on return), (c) return the agreed status (negative: failure).  Then every rank induces the rest from the
+ * complete array: d_sa_out holds the WHOLE suffix array on every rank, 4 |B*| = 1.33 n bytes were exchanged instead of 4 n.
+ * opts->shard = -1 with exchange = NULL: all shards one after the other on this GPU (logical shards).  opts->two_stage > 0: also
+ * below the size / alphabet policy of msufsort_hip_opts.two_stage.
+ * Returns 0, MSUFSORT_HIP_TWO_STAGE_DECLINED (every rank alike - the input does not suit the path or some shard's ties ran too
+ * deep: take the sharded sort-all path, msufsort_hip_make_sa_shard_groups_dev), MSUFSORT_HIP_TWO_STAGE_FAILED_LOCALLY (this rank
+ * only, after the exchange: build the array on this rank alone, msufsort_hip_make_sa_i32_dev with two_stage = -1), or an error. */
+#define MSUFSORT_HIP_TWO_STAGE_DECLINED 1
+#define MSUFSORT_HIP_TWO_STAGE_FAILED_LOCALLY 2
+typedef int (*msufsort_hip_exchange_fn)(void* user, const int64_t* bounds, int32_t n_shards, int32_t my_status);
+int msufsort_hip_make_sa_two_stage_sharded_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n, int32_t* d_sa_out /* n+1 */,
+                                               uint32_t* d_bstar, int64_t bstar_capacity, msufsort_hip_exchange_fn exchange, void* user,
+                                               const msufsort_hip_opts* opts);
 /* Slice bounds only (all shards), without sorting: bounds[n_shards + 1], in SA rows. */
 int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
                                   int32_t n_shards, int64_t* bounds);

@@ -182,6 +182,26 @@ class DeviceContext:
         o = _opts(self.device, verbose, text_rounds, 0, n_shards, force_wide)
         _lib.check(self._L.msufsort_hip_make_sa_i64_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa64), C.byref(o)), "make_sa_i64_dev")
 
+    def make_sa_two_stage_sharded(self, d_text, n: int, d_sa, d_bstar, shard: int, n_shards: int, exchange=None, *, two_stage=0, verbose=0):
+        """msufsort_hip_make_sa_two_stage_sharded_dev: B* suffixes sorted by key-range shards (shard = -1: all of them here), the rest
+        induced from the complete sorted-B* array on every rank.  exchange(bounds: list, my_status: int) -> agreed status is the
+        caller's collective.  Returns 0 (d_sa complete), 1 (declined on every rank), 2 (failed on this rank after the exchange)."""
+        o = _opts(self.device, verbose, 0, shard, n_shards, two_stage=two_stage)
+
+        def _cb(user, bounds, ns, status):
+            try:
+                return int(exchange([int(bounds[i]) for i in range(ns + 1)], int(status)))
+            except Exception:  # noqa: BLE001  (an exception must not unwind through the C caller)
+                import traceback
+                traceback.print_exc()
+                return -1
+        cb = _lib.EXCHANGE_FN(_cb) if exchange is not None else C.cast(None, _lib.EXCHANGE_FN)
+        r = self._L.msufsort_hip_make_sa_two_stage_sharded_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa), self._ptr(d_bstar), int(d_bstar.numel()),
+                                                               cb, None, C.byref(o))
+        if r not in (0, 1, 2):
+            _lib.check(r, "make_sa_two_stage_sharded")
+        return r
+
     def trim(self):
         _lib.check(self._L.msufsort_hip_ctx_trim(self._h), "ctx_trim")
 

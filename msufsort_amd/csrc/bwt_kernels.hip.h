@@ -446,16 +446,27 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const u32* __restrict__ link,
 #if defined(IBWT_EXP) && (IBWT_EXP & 1)      // experiment: no byte stores
 #define IBWT_FLUSH(c, at) do { if (acc[c][0] == 0x123456789abcull) segbuf[my[c]] = 1; _Pragma("unroll") for (u32 w_ = 0; w_ < PW; ++w_) acc[c][w_] = 0; } while (0)
 #else
-#define IBWT_FLUSH(c, at) do { uint4* o_ = reinterpret_cast<uint4*>(segbuf + (u64)my[c] * IBWT_CW + (at)); \
+#if defined(IBWT_NT) && (IBWT_NT & 1)        // experiment: the pieces leave as non-temporal stores
+#define IBWT_STORE(p_, v_) __builtin_nontemporal_store(v_, p_)
+#else
+#define IBWT_STORE(p_, v_) (*(p_) = (v_))
+#endif
+#define IBWT_FLUSH(c, at) do { u64* o_ = reinterpret_cast<u64*>(segbuf + (u64)my[c] * IBWT_CW + (at)); \
+        typedef u64 v2u64 __attribute__((ext_vector_type(2))); \
         _Pragma("unroll") for (u32 w_ = 0; w_ < PW; w_ += 2) { \
-            o_[w_ >> 1] = make_uint4((u32)acc[c][w_], (u32)(acc[c][w_] >> 32), (u32)acc[c][w_ + 1], (u32)(acc[c][w_ + 1] >> 32)); \
+            v2u64 q_; q_.x = acc[c][w_]; q_.y = acc[c][w_ + 1]; \
+            IBWT_STORE(reinterpret_cast<v2u64*>(o_ + w_), q_); \
             acc[c][w_] = acc[c][w_ + 1] = 0; } } while (0)
 #endif
     for (;;) {
         bool any = false;
         u32 nx[IBWT_NCH];
 #pragma unroll
+#if defined(IBWT_NT) && (IBWT_NT & 2)        // experiment: every link is read exactly once - non-temporal loads
+        for (int c = 0; c < IBWT_NCH; ++c) { nx[c] = 0; if (id[c] < K) { nx[c] = __builtin_nontemporal_load(link + cur[c]); any = true; } }
+#else
         for (int c = 0; c < IBWT_NCH; ++c) { nx[c] = 0; if (id[c] < K) { nx[c] = link[cur[c]]; any = true; } }     // the dependent loads, all in flight together
+#endif
         if (!any) break;
 #pragma unroll
         for (int c = 0; c < IBWT_NCH; ++c) {
@@ -496,6 +507,7 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const u32* __restrict__ link,
     }
 #undef IBWT_PULL
 #undef IBWT_FLUSH
+#undef IBWT_STORE
 }
 
 // out[pos .. pos + len) = segment buffer; one wave per segment, 64 contiguous bytes per store instruction

@@ -88,7 +88,8 @@ struct Switches {
     int ind_spin = 1 << 22;      // MSUFSORT_HIP_IND_SPIN: bound of the induction's look-back spins
     int ind_grid = 0;            // MSUFSORT_HIP_IND_GRID: workgroups per induction level launch (0: what the chip holds at once; tests: a small grid,
                                  // or one larger than the chip holds so that the launch settles on the ticket counter)
-    int radix17 = 0;             // MSUFSORT_HIP_RADIX17: -1 never, 0 when the two-byte buckets of a random-like input outgrow class C, 1 always (tests)
+    int radix17 = 0;             // MSUFSORT_HIP_RADIX17: -1 never, 0 by size and spread (build_sa), 1 always, after the 16-bit histogram, 2 always, 17-bit
+                                 // histogram first (1, 2: test hooks)
     int sync_debug = 0;          // MSUFSORT_HIP_SYNC_DEBUG
     bool host_trace = false;     // MSUFSORT_HIP_HOST_TRACE: timeline of the host-pointer entry points on stderr
     void load()
@@ -134,7 +135,8 @@ struct msufsort_hip_ctx {
     DevBuf lists[2][3], large_round[2], lvl[2], seg0;
     DevBuf alpha, seg0_base, stripe_sums, hist_partial, hist, hist_clip, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
     DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, aux3, doneB, doneC;
-    DevBuf h17_partial, h17, child_start17, child_cnt17, cursor17;      // 17-bit radix front end (random-like inputs above the class-C limit)
+    DevBuf h17_partial, h17_fb, h17, child_start17, child_cnt17, cursor17;      // 17-bit radix front end (random-like inputs above the class-C limit)
+    u32 h17_q = 1;                                // chunks of k_hist17 per scatter stripe
     std::vector<ActiveSet> active;                // per logical shard (index 0: the per-shard C-ABI pieces)
     // two-stage build (B* sort + induction, induce_host.inc): suffix-type bitmaps, histograms of the B / B* suffixes, sorted
     // B* suffixes, preceding characters of the rows, per-tile counts and the state of the induction passes
@@ -250,7 +252,7 @@ struct msufsort_hip_ctx {
         for (int s = 0; s < 2; ++s) { for (int c = 0; c < 3; ++c) lists[s][c].release(); large_round[s].release(); lvl[s].release(); }
         alpha.release(); seg0.release(); seg0_base.release(); stripe_sums.release(); hist_partial.release(); hist.release(); hist_clip.release(); bstart.release(); child_start.release(); child_cnt.release();
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
-        h17_partial.release(); h17.release(); child_start17.release(); child_cnt17.release(); cursor17.release();
+        h17_partial.release(); h17_fb.release(); h17.release(); child_start17.release(); child_cnt17.release(); cursor17.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
         grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release();
         sub_partial.release(); sub_hist.release(); sub_saved.release(); sub_key = -1;
@@ -376,12 +378,11 @@ int trailing_zeros(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64* z_out,
     } while (0)
 
 // hist16 + reduce.  Leaves the global 16-bit histogram (u32 narrow / u64 wide) in c->hist.
-template <bool W>
-int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
+// scatter stripes: at most 128, each a multiple of 32 KiB; chunks of the 16-bit histogram: a power of two per stripe, so that
+// large inputs give every CU a workgroup (one workgroup per chunk, 136 KiB of LDS each) and no chunk exceeds 16 MiB
+// (capacity of k_hist16's overflow list)
+int plan_stripes(msufsort_hip_ctx* c, u64 m, u32* hchunks_out)
 {
-    // scatter stripes: at most 128, each a multiple of 32 KiB; histogram chunks: a power of two per stripe, so that
-    // large inputs give every CU a workgroup (one workgroup per chunk, 136 KiB of LDS each) and no chunk exceeds 16 MiB
-    // (capacity of k_hist16's overflow list)
     u32 nchunks = (u32)std::min<u64>(128, std::max<u64>(1, (m + 65535) / 65536));
     u64 chunk_len = (m + nchunks - 1) / nchunks;
     chunk_len = (chunk_len + 32767) / 32768 * 32768;
@@ -393,6 +394,17 @@ int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
     TRY(c->ensure_fixed(hchunks));
     c->nchunks = nchunks; c->chunk_len = (u32)chunk_len; c->hist_per = per;
     c->sub_key = -1;
+    *hchunks_out = hchunks;
+    return MSUFSORT_HIP_OK;
+}
+
+template <bool W>
+int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
+{
+    u32 hchunks = 0;
+    TRY(plan_stripes(c, m, &hchunks));
+    const u32 per = c->hist_per;
+    const u64 chunk_len = c->chunk_len;
     hipLaunchKernelGGL(k_hist16<0>, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>(), 0u, (const unsigned short*)nullptr);
     hipLaunchKernelGGL(k_reduce16<W>, dim3(256), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), hchunks, c->hist.as<typename Wd<W>::hist_t>());
     HIP_TRY(hipGetLastError());
@@ -418,7 +430,7 @@ int run_subhist(msufsort_hip_ctx* c, const u8* d_text, u64 m, u32 key)
 
 // offsets and scatter set-up for the shard that owns the 4-byte prefixes [lo32, hi32)
 template <bool W>
-int run_scan(msufsort_hip_ctx* c, const u8* d_text, u64 m, u64 lo32, u64 hi32, u64 z)
+int run_scan(msufsort_hip_ctx* c, const u8* d_text, u64 m, u64 lo32, u64 hi32, u64 z, bool from17 = false /* the histograms came from k_hist17 (run_hist17, first) */)
 {
     const u32 klo = (u32)(lo32 >> 16), khi = (u32)((hi32 + 0xffffull) >> 16);
     const u32 hchunks = c->nchunks * c->hist_per;
@@ -453,7 +465,8 @@ int run_scan(msufsort_hip_ctx* c, const u8* d_text, u64 m, u64 lo32, u64 hi32, u
                        c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->counters.as<u32>());
     hipLaunchKernelGGL(k_alphabet<W>, dim3(1), dim3(256), 0, c->stream, c->hist.as<typename Wd<W>::hist_t>(), c->alpha.as<u8>(), c->counters.as<u32>());
     (void)hipMemsetAsync(c->stripe_sums.p, 0, (size_t)c->nchunks * 256 * 4, c->stream);
-    hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks * 4), dim3(256), 0, c->stream, partial_counts, c->hist_per, klo, khi, c->stripe_sums.as<u32>());
+    if (from17) hipLaunchKernelGGL(k_stripe_sums17, dim3(c->nchunks), dim3(256), 0, c->stream, c->h17_fb.as<u32>(), c->h17_q, c->stripe_sums.as<u32>());
+    else hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks * 4), dim3(256), 0, c->stream, partial_counts, c->hist_per, klo, khi, c->stripe_sums.as<u32>());
     hipLaunchKernelGGL(k_stripes, dim3(256), dim3(128), 0, c->stream, c->stripe_sums.as<u32>(), c->nchunks,
                        c->seg0_base.as<u32>(), c->cursor0.as<u32>());
     for (u32 f = 0; f < nfix; ++f)      // the per-chunk partials serve every shard of this text: put the full counts back
@@ -465,25 +478,35 @@ int run_scan(msufsort_hip_ctx* c, const u8* d_text, u64 m, u64 lo32, u64 hi32, u
 // 17-bit histogram + offsets of the 131,072 buckets of an UNSHARDED narrow build (k_hist17, k_reduce17, k_scan17): the
 // level-1 partition then splits every first-byte segment 512 ways.  Flags (overflow of an 8-bit LDS counter, disagreement
 // with the 16-bit histogram) and the largest 17-bit bucket land in counters[C_H17FLAG], counters[C_H17MAX].
-int run_hist17(msufsort_hip_ctx* c, const u8* d_text, u64 m)
+// first = true: the 17-bit histogram runs INSTEAD of the 16-bit one (sizes where the 17-bit levels are expected): it also leaves the
+// 16-bit histogram (pair sums) in c->hist and the first-byte sums per chunk for the scatter's stripe cursors; the caller has
+// planned the stripes (plan_stripes).  first = false: after a 16-bit histogram, cross-checked against it.
+int run_hist17(msufsort_hip_ctx* c, const u8* d_text, u64 m, bool first)
 {
-    // a multiple of 256 chunks of at most H17_CHUNK bytes each (multiples of 16 KiB: a workgroup reads 16 KiB per iteration)
-    const u32 rounds = std::max<u32>(1, cdiv(m, (u64)256 * H17_CHUNK));
-    const u32 chunk_len = (u32)((cdiv(m, 256u * rounds) + 16383u) & ~16383u);
-    const u32 nch = cdiv(m, chunk_len);
+    // chunks = the stripes of the level-0 scatter cut into q pieces of at most H17_CHUNK bytes (multiples of 16 KiB: a workgroup reads
+    // 16 KiB per iteration); q even, so that 128 stripes give a multiple of 256 chunks: whole rounds of one workgroup per CU
+    const u32 stripe_len = c->chunk_len;
+    u32 q = std::max<u32>(1, cdiv(stripe_len, H17_CHUNK));
+    if (q > 1 && (q & 1u)) ++q;
+    const u32 sub_len = (cdiv(stripe_len, q) + 16383u) & ~16383u;
+    const u32 nch = c->nchunks * q;
+    c->h17_q = q;
     TRY(c->h17_partial.ensure((size_t)nch * 131072));
+    TRY(c->h17_fb.ensure((size_t)nch * 256 * 4));
     TRY(c->h17.ensure(131072 * 4));
     TRY(c->child_start17.ensure(131072 * 4));
     TRY(c->child_cnt17.ensure(131072 * 4));
     TRY(c->cursor17.ensure(131072 * 4));
     u32* counters = c->counters.as<u32>();
     HIP_TRY(hipMemsetAsync(c->h17.p, 0, 131072 * 4, c->stream));
-    hipLaunchKernelGGL(k_hist17, dim3(nch), dim3(1024), H17_LDS_BYTES, c->stream, d_text, m, chunk_len, nch, c->h17_partial.as<u32>(), counters + C_H17FLAG);
+    hipLaunchKernelGGL(k_hist17, dim3(nch), dim3(1024), H17_LDS_BYTES, c->stream, d_text, m, stripe_len, q, sub_len, nch, c->h17_partial.as<u32>(), c->h17_fb.as<u32>(),
+                       counters + C_H17FLAG);
     const u32 groups = std::max<u32>(1, std::min<u32>(16, nch / 32));
     const u32 per_group = cdiv(nch, groups);
     hipLaunchKernelGGL(k_reduce17, dim3(128, groups), dim3(256), 0, c->stream, c->h17_partial.as<u32>(), nch, per_group, c->h17.as<u32>());
-    hipLaunchKernelGGL(k_scan17, dim3(1), dim3(1024), 0, c->stream, c->h17.as<u32>(), c->hist_clip.as<u32>(), c->child_start17.as<u32>(), c->child_cnt17.as<u32>(),
-                       c->cursor17.as<u32>(), counters + C_H17FLAG, counters + C_H17MAX);
+    if (first) hipLaunchKernelGGL(k_pair16, dim3(256), dim3(256), 0, c->stream, c->h17.as<u32>(), c->hist.as<u32>());
+    hipLaunchKernelGGL(k_scan17, dim3(1), dim3(1024), 0, c->stream, c->h17.as<u32>(), first ? (const u32*)nullptr : c->hist_clip.as<u32>(), c->child_start17.as<u32>(),
+                       c->child_cnt17.as<u32>(), c->cursor17.as<u32>(), counters + C_H17FLAG, counters + C_H17MAX);
     HIP_TRY(hipGetLastError());
     return MSUFSORT_HIP_OK;
 }
@@ -948,45 +971,64 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     R.klo = klo; R.khi = khi; R.verbose = verbose;
 
     // ---- round 0: 16-bit histogram, offsets, two 8-bit scatter levels ----
-    if (!hist_done) TRY(run_hist<W>(c, d_text, m));
+    // Random-like inputs whose two-byte buckets outgrow the largest LDS sort (uniform bytes from 1.15 GiB): 17 radix bits instead
+    // of 16 - a 17-bit histogram of the text (k_hist17) lets the level-1 partition split 512 ways, so that the children
+    // fit the bucket sort again instead of passing a third partition level (k_count + k_partition: 24 bytes per suffix more).
+    // ... and inputs whose two-byte buckets are just too large for the 4608-record shape (uniform bytes of 290 - 560 MiB): their
+    // 17-bit children fill it, where the 18,432-record shape would run a quarter to half empty (3.28 against 3.88 ms at 296 MiB).
+    // Unsharded narrow builds only.  At those sizes the 17-bit histogram runs FIRST and yields the 16-bit one as well (its pair
+    // sums); whether the keys really are spread out shows afterwards - if not (text, DNA, anything k_hist17 cannot count in its
+    // 8-bit LDS counters), the 16-bit histogram runs after all and the build takes the 16-bit levels.
+    const u64 mean16 = m >> 16;
+    bool radix17 = false, spec17 = false;
+    bool cand17 = false;
+    if constexpr (!W)
+        cand17 = !selected && !(opts && opts->n_shards > 1) && lo32 == 0 && hi32 == (1ull << 32) && c->sw.radix17 >= 0;
+    const bool size17 = (double)mean16 + 1.3 * std::sqrt((double)mean16) > (double)CAP_C || (mean16 > (u64)CAP_B && mean16 <= 8900);
     HIP_TRY(hipMemsetAsync(counters, 0, C_NCOUNTERS * 4, st));
+    if (cand17 && !hist_done && ((size17 && c->sw.radix17 == 0) || c->sw.radix17 == 2)) {      // (2: test hook - 17 bits first at any size)
+        u32 hchunks = 0;
+        TRY(plan_stripes(c, m, &hchunks));
+        TRY(run_hist17(c, d_text, m, true));
+        spec17 = true;
+    }
+    else if (!hist_done) TRY(run_hist<W>(c, d_text, m));
     HIP_TRY(hipEventRecord(c->ev[1], st));
-    TRY(run_scan<W>(c, d_text, m, lo32, hi32, z));
+    TRY(run_scan<W>(c, d_text, m, lo32, hi32, z, spec17));
     R.bufs = RecBufs{{c->rec[0].as<u64>(), c->rec[1].as<u64>(), c->rec[2].as<u64>()}};
     RecBufs& bufs = R.bufs;
     sa_t* sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
     R.sa_local = sa_local;
-    // Random-like inputs whose two-byte buckets outgrow the largest LDS sort (uniform bytes from 1.15 GiB): 17 radix bits instead
-    // of 16 - a 17-bit histogram of the text (k_hist17) lets the level-1 partition split 512 ways, so that the children
-    // fit the bucket sort again instead of passing a third partition level (k_count + k_partition: 24 bytes per suffix more).
-    // Unsharded narrow builds only; anything k_hist17 cannot count in its 8-bit LDS counters takes the three-level path.
-    bool radix17 = false;
-    if constexpr (!W) {
-        // ... and inputs whose two-byte buckets are just too large for the 4608-record shape (uniform bytes of 290 - 560 MiB): their
-        // 17-bit children fill it, where the 18,432-record shape would run a quarter to half empty (3.28 against 3.88 ms at 296 MiB)
-        const u64 mean16 = m >> 16;
-        const bool cand = !selected && !(opts && opts->n_shards > 1) && lo32 == 0 && hi32 == (1ull << 32) && c->sw.radix17 >= 0 &&
-                          (c->sw.radix17 > 0 || mean16 * 10 > (u64)CAP_C * 9 || (mean16 > (u64)CAP_B && mean16 <= 8900));
-        // (switch when about a tenth of the two-byte buckets would pass the class-C limit - uniform counts scatter by sqrt(mean);
-        // a few oversized buckets are cheaper through one more level of their own than 17 bits for everybody: +20 % at 1120 MiB)
-        if (cand) {
-            TRY(c->read_counters());
-            const u64 hmax = c->h_counters[C_HMAX], mean = std::max<u64>(m >> 16, 1);
-            const bool over_c = (double)mean + 1.3 * std::sqrt((double)mean) > (double)CAP_C && hmax > (u64)CAP_C && hmax <= 2ull * CAP_C;
-            // (buckets just over the 4608-record shape simply take the large one: 17 bits pay once most of them are over)
-            const bool over_b = mean > (u64)CAP_B && mean <= 8900;
-            if (c->sw.radix17 > 0 || ((over_c || over_b) && hmax <= 2 * mean)) {
-                HIP_TRY(hipEventRecord(c->ev[10], st));
-                TRY(run_hist17(c, d_text, m));
-                HIP_TRY(hipEventRecord(c->ev[11], st));
-                radix17 = true;
+    if (spec17 || (cand17 && (size17 || c->sw.radix17 > 0))) {
+        TRY(c->read_counters());
+        const u64 hmax = c->h_counters[C_HMAX], mean = std::max<u64>(mean16, 1);
+        // switch when about a tenth of the two-byte buckets would pass the class-C limit (uniform counts scatter by sqrt(mean): a
+        // few oversized buckets are cheaper through one more level of their own than 17 bits for everybody: +20 % at 1120 MiB);
+        // buckets just over the 4608-record shape simply take the large one: 17 bits pay once most of them are over
+        const bool over_c = hmax > (u64)CAP_C && hmax <= 2ull * CAP_C;
+        const bool over_b = mean > (u64)CAP_B && mean <= 8900;
+        const bool want = c->sw.radix17 > 0 || ((over_c || over_b) && hmax <= 2 * mean);
+        if (spec17) {
+            radix17 = want && c->h_counters[C_H17FLAG] == 0;
+            if (!radix17) {      // not the input the size promised: the 16-bit histogram after all (k_scatter0's stripes come from its partials)
+                if (verbose) fprintf(stderr, "[msufsort_hip] 17-bit histogram first, but the keys are not spread out (flags 0x%x, largest bucket %llu): 16-bit levels\n",
+                                     c->h_counters[C_H17FLAG], (unsigned long long)hmax);
+                HIP_TRY(hipMemsetAsync(counters, 0, C_NCOUNTERS * 4, st));
+                TRY(run_hist<W>(c, d_text, m));
+                TRY(run_scan<W>(c, d_text, m, lo32, hi32, z));
+                spec17 = false;
             }
+        } else if (want) {
+            HIP_TRY(hipEventRecord(c->ev[10], st));
+            TRY(run_hist17(c, d_text, m, false));
+            HIP_TRY(hipEventRecord(c->ev[11], st));
+            radix17 = true;
         }
     }
     hipLaunchKernelGGL(k_scatter0<W>, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, m, lo32, hi32, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0], c->alpha.as<u8>(), counters, R.no_pack ? 0u : 1u, c->sel_bits);
     HIP_TRY(hipEventRecord(c->ev[2], st));
     DBG("k_scatter0");
-    if (radix17) {
+    if (radix17 && !spec17) {
         TRY(c->read_counters());
         if (c->h_counters[C_H17FLAG]) {
             if (verbose) fprintf(stderr, "[msufsort_hip] 17-bit histogram declined (flags 0x%x): three-level path\n", c->h_counters[C_H17FLAG]);
@@ -1146,7 +1188,8 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     (void)hipEventElapsedTime(&ms_, c->ev[2], c->ev[3]); tm.scatter1_ms = ms_;
     (void)hipEventElapsedTime(&ms_, c->ev[3], c->ev[4]); tm.bucket_sort_ms = ms_;
     (void)hipEventElapsedTime(&ms_, c->ev[4], c->ev[5]); tm.refine_ms = ms_;
-    if (tm.radix_bits == 17) {      // the 17-bit histogram ran between ev[1] and the level-0 scatter: bill it to the histograms
+    if (spec17) tm.hist17_ms = tm.hist16_ms;      // the 17-bit histogram ran INSTEAD of the 16-bit one
+    else if (tm.radix_bits == 17) {             // ... or between ev[1] and the level-0 scatter: bill it to the histograms
         (void)hipEventElapsedTime(&ms_, c->ev[10], c->ev[11]); tm.hist17_ms = ms_;
         tm.scatter0_ms -= ms_; tm.hist16_ms += ms_;
     }
@@ -1634,6 +1677,28 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
         (void)hipEventElapsedTime(&ms_, c->ev[6], c->ev[8]); c->tm.hist16_ms = ms_;
         (void)hipEventElapsedTime(&ms_, c->ev[6], c->ev[5]); c->tm.total_ms = ms_;
     }
+    return r;
+}
+
+int msufsort_hip_make_sa_two_stage_sharded_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t* d_sa_out, uint32_t* d_bstar, int64_t bstar_capacity,
+                                               msufsort_hip_exchange_fn exchange, void* user, const msufsort_hip_opts* opts)
+{
+    if (!c || !d_sa_out || !d_bstar || !opts || opts->n_shards < 1 || opts->shard < -1 || opts->shard >= opts->n_shards || bstar_capacity < 0 || (n > 0 && !d_text)) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n(n));
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) { HIP_TRY(hipMemsetAsync(d_sa_out, 0, 4, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); return MSUFSORT_HIP_OK; }
+    TRY(zero_pad(c, d_text, (u64)n));
+    u64 z = 0;
+    TRY(trailing_zeros(c, d_text, (u64)n, &z));
+    c->sw.load();
+    TwoStageShards sh;
+    sh.n_shards = opts->n_shards; sh.shard = opts->shard; sh.d_sstar = d_bstar; sh.sstar_capacity = (u64)bstar_capacity; sh.exchange = exchange; sh.user = user;
+    msufsort_hip_opts o = *opts;
+    o.n_shards = 1; o.shard = 0;
+    bool hist_done = false;
+    int why = 0;
+    const int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, opts->two_stage > 0, &hist_done, &why, &sh);
+    if (r == MSUFSORT_HIP_UNRESOLVED) return why == IND_WHY_LOOKBACK ? MSUFSORT_HIP_TWO_STAGE_FAILED_LOCALLY : MSUFSORT_HIP_TWO_STAGE_DECLINED;
     return r;
 }
 

@@ -494,7 +494,11 @@ __global__ __launch_bounds__(256) void k_reduce16(const u32* __restrict__ partia
 #define H17_CHUNK (1u << 20)       // upper bound of a chunk; the host cuts the text into a multiple of 256 chunks (one wave of workgroups
                                    // per CU and no ragged last round: 296 one-MiB chunks took two rounds, the second 16 % full)
 #define H17_LDS_BYTES 131072u
-__global__ __launch_bounds__(1024) void k_hist17(const u8* __restrict__ text, u64 m, u32 chunk_len, u32 nchunks, u32* __restrict__ partial, u32* __restrict__ flag)
+// Chunks are the stripes of the level-0 scatter cut into q pieces (chunk = stripe * q + piece), so that the per-chunk first-byte
+// sums fb[chunk][256] add up to what the scatter's stripe cursors need: when this histogram runs FIRST (sizes where the
+// 17-bit levels are expected) it replaces the 16-bit pass altogether - its pair sums are the 16-bit histogram.
+__global__ __launch_bounds__(1024) void k_hist17(const u8* __restrict__ text, u64 m, u32 stripe_len, u32 q, u32 sub_len, u32 nchunks, u32* __restrict__ partial,
+                                                 u32* __restrict__ fb, u32* __restrict__ flag)
 {
     extern __shared__ u32 h_lds[];
     const u32 chunk = blockIdx.x, t = threadIdx.x;
@@ -504,8 +508,12 @@ __global__ __launch_bounds__(1024) void k_hist17(const u8* __restrict__ text, u6
     __shared__ u32 s_sum;
     if (t == 0) s_sum = 0;
     __syncthreads();
-    const u64 cbeg = (u64)chunk * chunk_len < m ? (u64)chunk * chunk_len : m;
-    const u64 cend = cbeg + chunk_len < m ? cbeg + chunk_len : m;
+    const u32 stripe = chunk / q, piece = chunk - stripe * q;
+    u64 send = (u64)(stripe + 1) * stripe_len;                      // end of my stripe
+    if (send > m) send = m;
+    u64 cbeg = (u64)stripe * stripe_len + (u64)piece * sub_len;
+    if (cbeg > send) cbeg = send;
+    const u64 cend = cbeg + sub_len < send ? cbeg + sub_len : send;
     u64 base = cbeg + (u64)t * 16u;
     uint4 v = make_uint4(0, 0, 0, 0);
     u32 nx = 0;
@@ -536,12 +544,36 @@ __global__ __launch_bounds__(1024) void k_hist17(const u8* __restrict__ text, u6
         const u32 a = (q.x & 0x00ff00ffu) + ((q.x >> 8) & 0x00ff00ffu), b = (q.y & 0x00ff00ffu) + ((q.y >> 8) & 0x00ff00ffu);
         const u32 c2 = (q.z & 0x00ff00ffu) + ((q.z >> 8) & 0x00ff00ffu), d = (q.w & 0x00ff00ffu) + ((q.w >> 8) & 0x00ff00ffu);
         const u32 e = a + b + c2 + d;
-        sum += (e & 0xffffu) + (e >> 16);
+        const u32 quad = (e & 0xffffu) + (e >> 16);                 // keys counted in the 16 bins of this quad of words
+        sum += quad;
+        // first-byte sums: quad i covers bins 16 i .. 16 i + 15, first byte b = i / 32: the 32 lanes of a half wave hold the
+        // 32 quads of ONE first byte (i = t + 1024 k: b = t / 32 + 32 k)
+        u32 fbs = quad;
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) fbs += __shfl_xor(fbs, sft, 64);
+        if ((t & 31u) == 0) fb[(u64)chunk * 256u + (i >> 5)] = fbs;
     }
     sum = wave_sum(sum);
     if (lane_id() == 0) atomicAdd(&s_sum, sum);
     __syncthreads();
     if (t == 0 && s_sum != (u32)(cend - cbeg)) atomicOr(flag, 1u);
+}
+
+// the 16-bit histogram from the 17-bit one (pairs of neighbouring bins)
+__global__ __launch_bounds__(256) void k_pair16(const u32* __restrict__ hist17, u32* __restrict__ hist16)
+{
+    const u32 k = blockIdx.x * 256u + threadIdx.x;
+    const uint2 v = reinterpret_cast<const uint2*>(hist17)[k];
+    hist16[k] = v.x + v.y;
+}
+
+// stripe sums of the level-0 scatter from the first-byte sums of the 17-bit histogram's chunks (unsharded builds: no key range)
+__global__ __launch_bounds__(256) void k_stripe_sums17(const u32* __restrict__ fb, u32 q, u32* __restrict__ sums)
+{
+    const u32 stripe = blockIdx.x, b = threadIdx.x;
+    u32 s = 0;
+    for (u32 p = 0; p < q; ++p) s += fb[((u64)stripe * q + p) * 256u + b];
+    sums[stripe * 256u + b] = s;
 }
 
 // hist17[k] = sum over the chunks of byte k of partial[chunk] (hist17 zeroed by the caller); blockIdx.y = group of chunks
@@ -577,7 +609,7 @@ __global__ __launch_bounds__(1024) void k_scan17(const u32* __restrict__ hist17,
         loc += q.x + q.y + q.z + q.w;
         mx = max(max(mx, max(q.x, q.y)), max(q.z, q.w));
         const u32 k16 = t * 64u + i * 2u;
-        bad |= (q.x + q.y != hist16[k16]) | (q.z + q.w != hist16[k16 + 1]);
+        if (hist16) bad |= (q.x + q.y != hist16[k16]) | (q.z + q.w != hist16[k16 + 1]);
     }
     u32 wtot;
     const u32 e = wave_excl_scan(loc, wtot);

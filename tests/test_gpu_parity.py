@@ -807,12 +807,16 @@ def test_two_stage_tile_handout_modes(M, oracle_mod, monkeypatch, grid):
     _two_stage(M, oracle_mod, gen.dna_bytes(1 << 20, 54))
 
 
+@pytest.mark.parametrize("policy", ["1", "2"])
 @pytest.mark.parametrize("kind,n", [("random", 1 << 16), ("random", 300007), ("random", (3 << 20) + 11), ("zeros_tail", 1 << 18), ("text", 1 << 19), ("dna", 1 << 19),
                                     ("two_values", 1 << 17)])
-def test_radix17_forced(M, oracle_mod, monkeypatch, kind, n):
+def test_radix17_forced(M, oracle_mod, monkeypatch, kind, n, policy):
     """The 17-bit front end (k_hist17 + k_scan17 + k_partition<512>; default only for random-like inputs whose two-byte buckets
     outgrow the largest LDS sort, i.e. above 1.15 GiB) forced on small inputs: same rows as the reference.  Skewed inputs make
-    its 8-bit LDS counters wrap - the build must notice and take the 16-bit path (radix_bits says which one ran)."""
+    its 8-bit LDS counters wrap - the build must notice and take the 16-bit path (radix_bits says which one ran).
+    policy 1: after the 16-bit histogram, cross-checked against it; policy 2: the 17-bit histogram FIRST (what sizes with
+    expected 17-bit levels do: it yields the 16-bit histogram and the scatter's stripe sums as well, and falls back to a
+    16-bit pass when the keys turn out not to be spread)."""
     import torch
     if kind == "random":
         t = gen.random_bytes(n, 17)
@@ -825,8 +829,8 @@ def test_radix17_forced(M, oracle_mod, monkeypatch, kind, n):
     else:
         t = (gen.random_bytes(n, 21) & 1).astype(np.uint8) + 65
     want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
-    monkeypatch.setenv("MSUFSORT_HIP_RADIX17", "1")
-    ctx = M.DeviceContext(0)                      # (the policy is read when the context is created)
+    monkeypatch.setenv("MSUFSORT_HIP_RADIX17", policy)
+    ctx = M.DeviceContext(0)
     d = _dev(M, t)
     sa = torch.empty(t.size + 1, dtype=torch.int32, device="cuda")
     ctx.make_sa(d, t.size, sa, two_stage=-1)
