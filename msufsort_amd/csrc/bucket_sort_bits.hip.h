@@ -231,7 +231,12 @@ __global__ __launch_bounds__(THREADS, 1024 / THREADS) void k_sort_bits(RecBufs b
                 u32 base = 0;
                 if (lane == 0) base = atomicAdd(&misc[0], wtot);
                 const u32 wbase = (u32)__builtin_amdgcn_readfirstlane((int)base);
-                if (wbase + wtot > (u32)LCAP) { if (lane == 0) misc[1] = 1u; }
+                // (its own flag: misc[1] is READ right behind barrier (4) - a wave that is still on its way to that read must not see
+                // what a faster wave sets here, or the two take different sides of `ok` and of every barrier that follows.  Round 4:
+                // that race existed since round 3 and showed on inputs that are one text twice at sizes where the 4608-record shape
+                // takes 17-bit children: waves one barrier apart, phase-A adds of the next segment landing in words phase D was
+                // claiming, a 2^32-iteration loop per segment - 6 minutes for 384 MiB)
+                if (wbase + wtot > (u32)LCAP) { if (lane == 0) misc[10] = 1u; }
                 else {
                     u32 pos = wbase + dinc - dc;
 #pragma unroll
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(THREADS, 1024 / THREADS) void k_sort_bits(RecBufs b
 #ifdef BITS_PROF
             if (threadIdx.x == 0) { prof_acc[10] += nl; prof_acc[12] += misc[1]; prof_acc[14] += nl > 1700u; prof_acc[15] += nl > 2048u; if (nl > 2048u && prof_acc[13] == 0) prof_acc[13] = ((unsigned long long)len << 32) | nl; }
 #endif
-            if (misc[1]) ok = false;                             // skewed keys: k_sort_mid takes the segment
+            if (misc[10]) ok = false;                            // skewed keys: k_sort_mid takes the segment (written before barrier (5) only)
         }
         BPROF(3);
         BITS_LOAD(3 * LB, 4 * LB);
@@ -263,6 +268,8 @@ __global__ __launch_bounds__(THREADS, 1024 / THREADS) void k_sort_bits(RecBufs b
                     db[i] = (w0 >> 16) & 0x7fffu;
                     dc[i] = ((w1 >> 16) & 0x7fffu) - db[i];
                     ds[i] = w0 & 0xffffu;
+                    if (dc[i] > (u32)LEN_MAX || ds[i] >= dc[i]) { misc[9] = 1u; dc[i] = 0; ds[i] = 0; db[i] = TRASH_ROW; }      // (belt and braces: a word that is not
+                                                                                                                  // what the scan left must never be looped on)
                     out[db[i] + ds[i]] = dk[i];                  // the word's rows as mailbox
                 }
             }
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(THREADS, 1024 / THREADS) void k_sort_bits(RecBufs b
 #ifdef BITS_PROF
             if (threadIdx.x == 0) { prof_acc[11] += misc[4]; }
 #endif
-            if (misc[1] || misc[4] > (u32)TL) ok = false;
+            if (misc[1] || misc[9] || misc[4] > (u32)TL) ok = false;
         }
         BPROF(7);
         BITS_LOAD(4 * LB, NL);

@@ -2693,7 +2693,16 @@ __global__ __launch_bounds__(THREADS) void k_chain_resolve(RecBufs bufs, Desc* _
         const idx_t i00 = sa_rows[d.sa_off];
         if ((u64)i00 >= n) continue;
         const idx_t g0 = isa[i00];                            // the rank every member holds
-        // 1. the step: the first 64 members look for their next member within wmax positions
+        // Membership test used below: "suffix j is in this group <=> isa[j] == g0".  It rests on two things.  (a) No stale
+        // sibling: DESC_STALE segments (fresh from a partition level of this round, members still holding the PARENT's rank)
+        // were skipped above, so g0 names this group alone.  (b) In MODE_ISA other workgroups rewrite isa[] for THEIR groups
+        // while this one reads it (they finish their own progressions): the values they write are rows inside their own
+        // groups' row ranges, and the row ranges of different groups are disjoint - no rewrite can produce or destroy the
+        // value g0, so a racing read answers the membership question as if it had come before or after.  The direction
+        // test (step 3) reads the rank of a suffix OUTSIDE the group: a rewrite moves it inside its own group's row range,
+        // on the same side of g0.  (MODE_DEFER: the rank array is read-only during a step.)
+        // 1. the step: the first 64 members look for their next member within wmax positions (units longer than 64 - and groups
+        // that are several progressions, tiny or class-L groups - are left to the doubling rounds: correct, log2 more rounds)
         if (t < 64u && t < d.len) {
             const u64 i = idx[0];
             u32 found = 0xffffffffu;

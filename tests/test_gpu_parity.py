@@ -796,6 +796,19 @@ def test_two_stage_three_kernel_levels(M, oracle_mod, monkeypatch):
     _two_stage(M, oracle_mod, gen.dna_bytes(1 << 20, 52))
 
 
+@pytest.mark.parametrize("unit,copies", [(65, 300), (97, 50), (200, 40), (1000, 9)])
+def test_tandem_progression_with_a_long_unit(M, oracle_mod, unit, copies):
+    """k_chain_resolve only looks 64 positions ahead for the period of a tie group (round-3 advisor finding): runs of a unit
+    LONGER than that form groups that are one arithmetic progression too, but must be left to the plain doubling rounds - and
+    still come out right.  Unit lengths just over the window and far beyond it, in random DNA, against the reference."""
+    rng = np.random.default_rng(unit)
+    u = rng.integers(0, 4, unit)
+    body = np.concatenate([gen.dna_bytes(40000, unit), np.frombuffer(b"ACGT", np.uint8)[np.tile(u, copies)], gen.dna_bytes(30000, unit + 1)])
+    want = oracle_mod.ref_make_suffix_array(body, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(body)
+    assert (M.make_suffix_array(body, two_stage=-1) == want).all()
+    assert (M.make_suffix_array_i64(body, force_wide=True, n_shards=2) == want).all()
+
+
 @pytest.mark.parametrize("grid", [3, 64, 100000])
 def test_two_stage_tile_handout_modes(M, oracle_mod, monkeypatch, grid):
     """How an induction level hands out its tiles is settled per launch (k_ind_fused: every workgroup draws one ticket; when all
@@ -902,3 +915,28 @@ def test_two_stage_sharded_first_stage(M, oracle_mod, kind, n, shards):
     r = ctx.make_sa_two_stage_sharded(d, n, sa, bstar, shards - 1, shards, exchange, two_stage=1)
     assert r == 1 and seen["status"] == 0 and len(seen["bounds"]) == shards + 1 and seen["bounds"][0] == 0
     assert all(a <= b for a, b in zip(seen["bounds"], seen["bounds"][1:])) and seen["bounds"][-1] == ctx.timings().bstar_suffixes or True
+
+
+def test_bucket_sort_list_overflow_keeps_the_waves_together(M, monkeypatch):
+    """Round-4 finding: in k_sort_bits a wave whose dirty-list reservation overflowed set the flag that slower waves were still
+    about to read behind the previous barrier - the waves took different sides of `ok`, went one barrier apart, and the adds of
+    the next segment landed in the words the slow waves were claiming (a 2^32-iteration loop per segment: 6 minutes for 384
+    MiB; wrong rows were possible).  One random text twice, with 17 radix bits so that the 4608-record shape gets 1280-record
+    segments in which EVERY word is dirty: must build in well under a minute, three times, and be right."""
+    import time
+    import torch
+    monkeypatch.setenv("MSUFSORT_HIP_RADIX17", "1")
+    base = gen.random_bytes(80 << 20, 77)
+    t = np.concatenate([base, base])
+    n = t.size
+    ctx = M.DeviceContext(0, n)
+    d = _dev(M, t)
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        t0 = time.time()
+        ctx.make_sa(d, n, sa, text_rounds=1)
+        torch.cuda.synchronize()
+        assert time.time() - t0 < 30.0 and ctx.timings().radix_bits == 17
+    assert ctx.validate_sa(d, n, sa) == 0
+    del sa, d
+    ctx.trim(); torch.cuda.empty_cache()

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Copies what tools/gpu_final_r4.sh left in gpurun_out/final/ into profiles/r04_* and rebuilds profiles/pmc_traffic.json (the
+per-launch HBM traffic bench.py quotes) from the PMC passes: FETCH_SIZE x 2 (gfx950 counts 128-byte requests at 64 bytes,
+MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes - keyed by the build id of the library the passes ran with, so that bench.py
+drops the figures as soon as the library is rebuilt from different sources."""
+import json, os, re, shutil
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F, P = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
+for f in sorted(os.listdir(F)):
+    src = os.path.join(F, f)
+    if os.path.isfile(src) and os.path.getsize(src) > 0 and f != "build_id.txt":
+        shutil.copyfile(src, os.path.join(P, "r04_" + f))
+build = open(os.path.join(F, "build_id.txt")).read().strip()
+
+
+def passes(name):
+    """{kernel prefix: {"calls": c, "bytes_per_call": FETCH x 2 + WRITE}} of one PMC file"""
+    acc = {}
+    path = os.path.join(F, name)
+    if not os.path.exists(path):
+        return acc
+    for line in open(path):
+        m = re.match(r"(FETCH_SIZE|WRITE_SIZE) (?:void )?(.+?) calls (\d+) sum_KiB (\S+) per_call_KiB (\S+)", line.strip())
+        if m:
+            e = acc.setdefault(m.group(2), {"calls": int(m.group(3)), "sum": 0.0})
+            e["sum"] += float(m.group(4)) * 1024 * (2 if m.group(1) == "FETCH_SIZE" else 1)
+    return acc
+
+
+def total(acc, *prefixes):
+    return sum(e["sum"] for k, e in acc.items() if any(k.startswith(p) for p in prefixes))
+
+
+rnd = passes("pmc_traffic_random.txt")
+txt = passes("pmc_traffic_text_sa.txt")
+wlk = passes("pmc_traffic_text_ibwt_lcp.txt")
+n = (1 << 30) - 1
+out = {"build_id": build,
+       "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_pmc_traffic.sh: bench.py --steps 1 --warmup 0, ONE build); "
+               "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md); units KiB -> bytes; per launch, or per build for the phases that are many launches",
+       "entries": {}}
+if rnd:
+    out["entries"]["random"] = {"n": n, "source": "profiles/r04_pmc_traffic_random.txt", "kernels": {
+        "k_hist16": int(total(rnd, "k_hist16<0>")), "k_scatter0": int(total(rnd, "k_scatter0<false>")),
+        "k_partition(level 1)": int(total(rnd, "k_partition<256>", "k_partition<512>", "k_partition")),
+        "bucket sort (LDS sorts of the two-byte buckets)": int(total(rnd, "k_sort_bits<1024"))}}
+if txt:
+    ent = {"k_hist16": int(total(txt, "k_hist16<0>")), "k_scatter0": int(total(txt, "k_scatter0<false>")),
+           "induction (k_ind_fused + k_ind_small)": int(total(txt, "k_ind_fused", "k_ind_small")),
+           # everything the rounds behind round 0 run: LDS sorts with their gathers, partition levels, refills (the round-0 share of the
+           # sorts cannot be told apart in a per-kernel sum: this figure is an upper bound for the key rounds)
+           "key rounds (k_refill + k_partition levels + LDS sorts)": int(total(txt, "k_sort_mid", "k_sort_tiny", "k_count", "k_refill", "k_carry_copy"))}
+    out["entries"]["text"] = {"n": n, "source": "profiles/r04_pmc_traffic_text_sa.txt", "kernels": ent}
+if wlk and "text" in out["entries"]:
+    out["entries"]["text"]["kernels"]["k_ibwt_walk"] = int(total(wlk, "k_ibwt_walk"))
+    out["entries"]["text"]["kernels"]["k_lcp"] = int(total(wlk, "k_lcp"))
+json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
