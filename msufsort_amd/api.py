@@ -67,12 +67,12 @@ def make_suffix_array_i64(data, threads: int = 1, *, device: int = 0, force_wide
 
 
 def make_suffix_array_multi(data, devices=None, *, index_bytes: int = 4, n_shards: int = 0, text_rounds: int = 0, force_wide: bool = False,
-                            verbose: int = 0, timings: bool = False):
+                            verbose: int = 0, timings: bool = False, two_stage: int = 0):
     """msufsort_hip_make_sa_multi: one process, several GPUs (default: MSUFSORT_DEVICES, else all visible), host text in,
     host suffix array out; finished slices stream to the host while the remaining key ranges are sorted."""
     t = _u8(data)
     sa = np.empty(t.size + 1, dtype=np.int64 if index_bytes == 8 else np.int32)
-    o = _opts(0, verbose, text_rounds, 0, n_shards, force_wide)
+    o = _opts(0, verbose, text_rounds, 0, n_shards, force_wide, two_stage=two_stage)
     tm = Timings()
     dv = (C.c_int32 * len(devices))(*devices) if devices else None
     _lib.check(_lib.lib().msufsort_hip_make_sa_multi(dv, len(devices) if devices else 0, t.ctypes.data, t.size, sa.ctypes.data, index_bytes,

@@ -940,3 +940,22 @@ def test_bucket_sort_list_overflow_keeps_the_waves_together(M, monkeypatch):
     assert ctx.validate_sa(d, n, sa) == 0
     del sa, d
     ctx.trim(); torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kind,devices", [("text", [0, 0]), ("text", [0, 0, 0, 0]), ("dna", [0, 0, 0]), ("text_copy", [0, 0])])
+def test_single_process_text_over_several_devices(M, oracle_mod, monkeypatch, kind, devices):
+    """msufsort_hip_make_sa_multi with a text-like input and more than one device (the one GPU listed several times): every device
+    sorts the B* suffixes of its key range, the slices are collected on the first device, which induces the rest and answers
+    (round 3 gave such inputs to ONE device).  A text followed by its copy makes the shards decline: the call must fall back
+    to one device's build and still return the reference's rows."""
+    monkeypatch.setenv("MSUFSORT_ALLOW_DUPLICATE_DEVICES", "1")
+    n = (2 << 20) + 31
+    if kind == "text_copy":
+        x = gen.text_bytes(n // 2, 71); t = np.concatenate([x, x])
+    else:
+        t = gen.GENERATORS[kind](n, 70)
+    want = oracle_mod.ref_make_suffix_array(t, 8) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)
+    sa, tm = M.make_suffix_array_multi(t, devices, two_stage=1, timings=True)
+    assert (sa == want).all()
+    if kind != "text_copy":
+        assert tm.logical_shards == len(devices) and tm.bstar_suffixes > 0
