@@ -1865,11 +1865,11 @@ int msufsort_hip_make_sa_i32_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64
     c->sw.load();
     HostTrace tr(c->sw.host_trace, "make_sa_i32_ctx");
     Prefault pf;
-    pf.start(sa_out, ((size_t)n + 1) * 4);           // the result is usually fresh memory: first touch while the text travels and is sorted
     TRY(c->text_own.ensure((size_t)n + MSUFSORT_HIP_TEXT_PAD));
     TRY(c->sa_own.ensure(((size_t)n + 1) * 4));
-    HIP_TRY(hipMemcpyAsync(c->text_own.p, text, (size_t)n, hipMemcpyHostToDevice, c->stream));
-    tr.mark("H2D issued");
+    TRY(copy_in(c, c->text_own.p, text, (size_t)n));
+    tr.mark("H2D done");
+    pf.start(sa_out, ((size_t)n + 1) * 4);           // the result is usually fresh memory: first touch while the text is sorted
     TRY(msufsort_hip_make_sa_i32_dev(c, c->text_own.as<u8>(), n, c->sa_own.as<int32_t>(), opts));
     tr.mark("built");
     const int r = copy_out(c, c->stream, sa_out, c->sa_own.p, ((size_t)n + 1) * 4);
@@ -1919,10 +1919,10 @@ int msufsort_hip_make_sa_i64_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64
     if (n == 0) { sa_out[0] = 0; return MSUFSORT_HIP_OK; }
     HIP_TRY(hipSetDevice(c->device));
     Prefault pf;
-    pf.start(sa_out, ((size_t)n + 1) * 8);
     TRY(c->text_own.ensure((size_t)n + MSUFSORT_HIP_TEXT_PAD));
     TRY(c->aux2.ensure(((size_t)n + 1) * 8));
-    HIP_TRY(hipMemcpyAsync(c->text_own.p, text, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    TRY(copy_in(c, c->text_own.p, text, (size_t)n));
+    pf.start(sa_out, ((size_t)n + 1) * 8);
     TRY(msufsort_hip_make_sa_i64_dev(c, c->text_own.as<u8>(), n, c->aux2.as<int64_t>(), opts));
     return copy_out(c, c->stream, sa_out, c->aux2.p, ((size_t)n + 1) * 8);
 }

@@ -31,4 +31,6 @@ MSUFSORT_HIP_HOST_TRACE=1 timeout 300 python tools/gpu_host_fresh.py 1073741823 
 timeout 300 tools/microbench/bin/exp_host_xfer > $O/microbench_host_xfer.txt 2>&1
 python tools/gpu_verbose_any.py text 1073741823 2>&1 | grep -E "msufsort_hip|errors" > $O/text_rounds.txt
 python tools/gpu_verbose_any.py dna_tandem 268435456 -1 2>&1 | grep -E "msufsort_hip|errors" > $O/tandem_rounds.txt
-ls -la $O | head -60
+timeout 900 python tools/gpu_stress.py 350000000 2>&1 | grep -v amdgpu.ids > $O/stress_350MB.txt; tail -14 $O/stress_350MB.txt
+timeout 120 tools/microbench/bin/exp_h2d_fresh > $O/microbench_h2d_fresh.txt 2>&1
+ls -la $O | head -70
