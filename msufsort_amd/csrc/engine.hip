@@ -505,7 +505,7 @@ int run_hist17(msufsort_hip_ctx* c, const u8* d_text, u64 m, bool first)
     const u32 per_group = cdiv(nch, groups);
     hipLaunchKernelGGL(k_reduce17, dim3(128, groups), dim3(256), 0, c->stream, c->h17_partial.as<u32>(), nch, per_group, c->h17.as<u32>());
     if (first) hipLaunchKernelGGL(k_pair16, dim3(256), dim3(256), 0, c->stream, c->h17.as<u32>(), c->hist.as<u32>());
-    hipLaunchKernelGGL(k_scan17, dim3(1), dim3(1024), 0, c->stream, c->h17.as<u32>(), first ? (const u32*)nullptr : c->hist_clip.as<u32>(), c->child_start17.as<u32>(),
+    hipLaunchKernelGGL(k_scan17, dim3(128), dim3(1024), 0, c->stream, c->h17.as<u32>(), first ? (const u32*)nullptr : c->hist_clip.as<u32>(), c->child_start17.as<u32>(),
                        c->child_cnt17.as<u32>(), c->cursor17.as<u32>(), counters + C_H17FLAG, counters + C_H17MAX);
     HIP_TRY(hipGetLastError());
     return MSUFSORT_HIP_OK;
