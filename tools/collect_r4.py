@@ -37,7 +37,10 @@ wlk = passes("pmc_traffic_text_ibwt_lcp.txt")
 n = (1 << 30) - 1
 out = {"build_id": build,
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_pmc_traffic.sh: bench.py --steps 1 --warmup 0, ONE build); "
-               "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md); units KiB -> bytes; per launch, or per build for the phases that are many launches",
+               "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md); units KiB -> bytes; per launch, or per build for the phases that are many launches.  "
+               "The x2 is calibrated for wide streaming reads only (the guide says so): for the gather-bound kernels of the text entry (k_ibwt_walk, k_lcp, induction, key rounds) "
+               "FETCH_SIZE raw is one 64-byte request per random access (k_ibwt_walk: 68.7 GB raw = 1.07 G requests = n hops), the figure here is that x2 as prescribed - "
+               "read it as an upper bound (128 bytes per touch), raw = half of it",
        "entries": {}}
 if rnd:
     out["entries"]["random"] = {"n": n, "source": "profiles/r04_pmc_traffic_random.txt", "kernels": {
