@@ -230,7 +230,7 @@ int msufsort_hip_make_sa_i64_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t
  * One host thread per device; every device sorts its key ranges and each
  * finished slice leaves for the host while the next one is sorted (with ONE device this is the streaming host path: the
  * D2H of 4(n+1) bytes overlaps the remaining sorts).  Deep ties: distributed prefix doubling, rank updates exchanged with
- * peer-to-peer copies over xGMI.  opts->n_shards: total number of key-range shards (default: 8 per device from 64 MiB on).
+ * peer-to-peer copies over xGMI.  opts->n_shards: total number of key-range shards (default: 8 per device from 64 MiB on, 16 from 512 MiB).
  * Replaces the cost the reference pays at msufsort.cpp:1754-1758 (allocation + first touch of the result). */
 int msufsort_hip_make_sa_multi(const int32_t* devices, int32_t n_dev, const uint8_t* text, int64_t n, void* sa_out,
                                int32_t index_bytes, const msufsort_hip_opts* opts, msufsort_hip_timings* timings_out);
