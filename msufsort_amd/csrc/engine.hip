@@ -1007,7 +1007,12 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         // buckets just over the 4608-record shape simply take the large one: 17 bits pay once most of them are over
         const bool over_c = hmax > (u64)CAP_C && hmax <= 2ull * CAP_C;
         const bool over_b = mean > (u64)CAP_B && mean <= 8900;
-        const bool want = c->sw.radix17 > 0 || ((over_c || over_b) && hmax <= 2 * mean);
+        // (small alphabets: k_scatter0 writes the key symbols as ONE dense base-sigma number below the bucket byte - its top bit is
+        // not the 17th bit of the text.  The automatic policy cannot meet them - at most 84^2 of the 65,536 two-byte buckets are
+        // in use, so the largest is > 9 x the mean - but the forced one could: round-4 fuzz finding at n = 33)
+        const u32 sg17 = c->h_counters[C_ASIGMA];
+        const bool packed17 = !R.no_pack && sg17 >= 2 && sg17 <= 84;
+        const bool want = !packed17 && (c->sw.radix17 > 0 || ((over_c || over_b) && hmax <= 2 * mean));
         if (spec17) {
             radix17 = want && c->h_counters[C_H17FLAG] == 0;
             if (!radix17) {      // not the input the size promised: the 16-bit histogram after all (k_scatter0's stripes come from its partials)

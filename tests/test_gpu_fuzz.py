@@ -73,3 +73,43 @@ def test_fuzz_doubling_forced(oracle_mod):
             t = np.ascontiguousarray(_make(kind, n, n))
             want = o.ref_make_suffix_array(t, 2) if o.have_reference() else o.make_suffix_array(t)
             assert (M.make_suffix_array(t, text_rounds=1) == want).all(), (kind, n)
+
+
+@pytest.mark.parametrize("policy", ["1", "2"])
+def test_fuzz_radix17_forced(oracle_mod, monkeypatch, policy):
+    """The same inputs with the 17-bit front end forced at every size (policy 1: after the 16-bit histogram, 2: instead of it, with
+    the fall-back when the 8-bit counters wrap): k_hist17 / k_scan17 / k_partition<512> / 512 children per segment on
+    degenerate alphabets, runs, periods and near-duplicate halves - bit-exact SA through the one-shot entry point."""
+    import msufsort_amd as M
+    o = oracle_mod
+    monkeypatch.setenv("MSUFSORT_HIP_RADIX17", policy)
+    for kind in ("alpha", "runs", "periodic", "zeros", "dup", "text"):
+        for i, n in enumerate((1, 2, 33, 513, 4609, 18433, 70001, 300000)):
+            t = np.ascontiguousarray(_make(kind, n, 77 * i + sum(kind.encode()) % 89))
+            want = o.ref_make_suffix_array(t, 2) if (o.have_reference() and kind in ("periodic", "runs", "dup")) else o.make_suffix_array(t)
+            assert (M.make_suffix_array(t, two_stage=-1) == want).all(), (kind, n)
+
+
+def test_fuzz_two_stage_sharded_first_stage(oracle_mod):
+    """The two-stage build with its first stage cut into key-range shards (all of them on this GPU), forced on small structured
+    inputs: whenever the call accepts the input (0) the rows are the reference's; periodic and duplicated inputs must be declined
+    (1), never mis-sorted."""
+    import torch
+    import msufsort_amd as M
+    o = oracle_mod
+    ctx = M.DeviceContext(0)
+    accepted = 0
+    for kind in ("alpha", "runs", "periodic", "zeros", "dup", "text"):
+        for i, n in enumerate((4096, 4609, 18433, 70001, 300000)):
+            t = np.ascontiguousarray(_make(kind, n, 31 * i + sum(kind.encode()) % 83))
+            d = torch.zeros(n + 64, dtype=torch.uint8, device="cuda"); d[:n] = torch.from_numpy(t).cuda()
+            sa = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+            bstar = torch.zeros(n // 2 + 2, dtype=torch.int32, device="cuda")
+            for shards in (2, 5):
+                r = ctx.make_sa_two_stage_sharded(d, n, sa, bstar, -1, shards, None, two_stage=1)
+                assert r in (0, 1), (kind, n, shards, r)
+                if r == 0:
+                    want = o.ref_make_suffix_array(t, 2) if (o.have_reference() and kind in ("periodic", "runs", "dup")) else o.make_suffix_array(t)
+                    assert (sa.cpu().numpy() == want).all(), (kind, n, shards)
+                    accepted += 1
+    assert accepted >= 10

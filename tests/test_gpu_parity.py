@@ -882,6 +882,17 @@ def test_host_entry_points_fresh_result(M, oracle_mod):
     t = gen.text_bytes(n, 32)
     b, s = M.forward_burrows_wheeler_transform(t)
     assert (M.reverse_burrows_wheeler_transform(b, s) == t).all()
+    # result bytes = a whole number of ring chunks (4 x 32 MiB), text = exactly two: the last chunk of either ring is a full one
+    n = (32 << 20) - 1
+    t = gen.random_bytes(n, 33)
+    ctx = M.DeviceContext(0)
+    d = _dev(M, t)
+    ref = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, n, ref)
+    assert (M.make_suffix_array_multi(t, [0]) == ref.cpu().numpy()).all()
+    t2 = gen.random_bytes(64 << 20, 34)
+    b, s = M.forward_burrows_wheeler_transform(t2)
+    assert (M.reverse_burrows_wheeler_transform(b, s) == t2).all()
 
 
 @pytest.mark.parametrize("kind,n,shards", [("text", (2 << 20) + 77, 2), ("text", (2 << 20) + 77, 8), ("dna", 1 << 20, 3), ("text_copy", 1 << 19, 4)])
