@@ -146,7 +146,18 @@ def pcie_floor(torch, dev, n):
 
 
 def host_bench_path():
-    return os.path.join(ROOT, "build", "host_bench")
+    """build/host_bench (made by __graft_entry__.build()); compiled here when it did not travel with the tree."""
+    exe = os.path.join(ROOT, "build", "host_bench")
+    if not os.path.exists(exe):
+        import subprocess
+        try:
+            os.makedirs(os.path.dirname(exe), exist_ok=True)
+            subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "host_bench.cpp"),
+                            "-L" + os.path.join(ROOT, "msufsort_amd", "lib"), "-lmsufsort_hip", "-Wl,-rpath,$ORIGIN/../msufsort_amd/lib", "-o", exe],
+                           check=True, capture_output=True, timeout=120)
+        except Exception:  # noqa: BLE001
+            pass
+    return exe
 
 
 CABI_CHILD = r"""
