@@ -16,7 +16,7 @@ for copies, part_mib in ((2, 640), (3, 430), (2, 990)):
     n = part * copies
     d = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
     for k in range(copies):
-        d[k * part:(k + 1) * part] = base
+        d[k * part:(k + 1) * part] = base[:part]
     del base
     sa = torch.empty(n + 1, dtype=torch.int32, device=dev)
     t0 = time.time()
