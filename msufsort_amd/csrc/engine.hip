@@ -73,6 +73,7 @@ struct DevBuf {
 };
 
 struct HostRing;      // pinned bounce ring for device-to-host copies into pageable memory (host_xfer.inc)
+struct Copier;        // thread that sends finished row ranges to the host while the build goes on (host_xfer.inc)
 
 }  // namespace
 
@@ -160,6 +161,11 @@ struct msufsort_hip_ctx {
     msufsort_hip_timings tm{};
     hipEvent_t ev[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Switches sw;                 // environment switches, reloaded by every entry point
+    // rows that are final before the build ends leave for the caller's array at once (msufsort_hip_make_sa_i32_ctx sets the sink;
+    // the two-stage build feeds it bucket by bucket during its last pass): sink_rows = rows 1 .. sink_rows handed over so far
+    Copier* sink = nullptr;
+    int32_t* sink_host = nullptr;
+    u64 sink_rows = 0;
     HostRing* ring = nullptr;    // created by the first large device-to-host copy of a host-pointer entry point
     std::mutex ring_mu, ring_use;
 
@@ -1673,6 +1679,7 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     if (two_stage > 0 || (two_stage == 0 && (u64)n >= (48ull << 20) && tail_values <= 128u)) {
         const int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, two_stage > 0, &hist_done, &why);
         if (r != MSUFSORT_HIP_UNRESOLVED) return r;
+        c->sink_rows = 0;          // (whatever left for the host already is rebuilt and sent again)
     }
     const int r = build_sa<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 1ull << 32, z, true, &o, hist_done);
     if (why) c->tm.fallbacks = 1 | ((int64_t)why << 8);      // an abandoned two-stage attempt: its device time is part of this build
@@ -1875,9 +1882,26 @@ int msufsort_hip_make_sa_i32_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64
     TRY(copy_in(c, c->text_own.p, text, (size_t)n));
     tr.mark("H2D done");
     pf.start(sa_out, ((size_t)n + 1) * 4);           // the result is usually fresh memory: first touch while the text is sorted
-    TRY(msufsort_hip_make_sa_i32_dev(c, c->text_own.as<u8>(), n, c->sa_own.as<int32_t>(), opts));
+    // text-like inputs (two-stage build): the rows of a bucket are final as soon as the last pass has left it - they travel while
+    // the later buckets are still being induced (the pass takes ~13 ms of a 1 GiB text's 75: that much of the 76 ms D2H is hidden)
+    const bool stream_rows = ((size_t)n + 1) * 4 >= ((size_t)64 << 20) && !c->sw.no_ring;
+    Copier copier;
+    if (stream_rows) {
+        if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        copier.start(c->device, c->copy_stream, c);
+        c->sink = &copier; c->sink_host = sa_out; c->sink_rows = 0;
+    }
+    int r = msufsort_hip_make_sa_i32_dev(c, c->text_own.as<u8>(), n, c->sa_own.as<int32_t>(), opts);
+    c->sink = nullptr;
     tr.mark("built");
-    const int r = copy_out(c, c->stream, sa_out, c->sa_own.p, ((size_t)n + 1) * 4);
+    if (stream_rows) {
+        if (r == MSUFSORT_HIP_OK) {
+            if (c->sink_rows == (u64)n) copier.push({sa_out, c->sa_own.p, 4, nullptr});                          // rows 1 .. n are on their way: row 0
+            else copier.push({sa_out, c->sa_own.p, ((size_t)n + 1) * 4, nullptr});                                // nothing (valid) left early: everything
+        }
+        copier.finish();
+        if (r == MSUFSORT_HIP_OK && copier.status) { set_error("D2H of the rows failed"); r = copier.status; }
+    } else if (r == MSUFSORT_HIP_OK) r = copy_out(c, c->stream, sa_out, c->sa_own.p, ((size_t)n + 1) * 4);
     tr.mark("copied out");
     pf.wait();
     tr.mark("first touch joined");
