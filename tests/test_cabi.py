@@ -108,3 +108,27 @@ def test_timings_struct_size_is_frozen():
     assert C.sizeof(_lib.Timings) == 216
     hdr = open(os.path.join(ROOT, "include", "msufsort_hip.h")).read()
     assert "sizeof(msufsort_hip_timings) == 216" in hdr
+
+
+def test_pmc_traffic_is_keyed_by_the_library_build(L, monkeypatch):
+    """bench.py quotes HBM traffic per launch from committed PMC passes (profiles/pmc_traffic.json) - only for the build of the
+    library the passes ran with (round-3 review item 7): the library exports the hash of its sources, the file stores it, and a
+    mismatch drops the figure with the reason instead of printing a stale one."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert isinstance(pt.get("build_id"), str) and "random" in pt["entries"] and "text" in pt["entries"]
+    assert pt["entries"]["random"]["n"] == (1 << 30) - 1 and "k_partition(level 1)" in pt["entries"]["random"]["kernels"]
+    assert {"k_ibwt_walk", "k_lcp", "induction (k_ind_fused + k_ind_small)"} <= set(pt["entries"]["text"]["kernels"])
+    bid = L.msufsort_hip_build_id().decode()
+    assert len(bid) == 16 and bench.build_id() == bid
+    n = (1 << 30) - 1
+    monkeypatch.setattr(bench, "build_id", lambda: pt["build_id"])
+    t, src = bench.traffic_lookup("random", n, "k_partition(level 1)")
+    assert t == pt["entries"]["random"]["kernels"]["k_partition(level 1)"] and "same library build" in src
+    monkeypatch.setattr(bench, "build_id", lambda: "0000000000000000")
+    t, src = bench.traffic_lookup("random", n, "k_partition(level 1)")
+    assert t is None and src.startswith("dropped")
+    assert bench.traffic_lookup("random", n + 1, "k_partition(level 1)") == (None, None)          # another size: no figure, no reason needed
