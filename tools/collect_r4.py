@@ -12,7 +12,7 @@ FILES = ["pytest_gpu.log", "bench.json", "bench_time.txt", "bench_256MiB.json", 
          "kernel_stats_random.txt", "kernel_stats_random.csv", "kernel_stats_text.txt", "kernel_stats_text.csv", "kernel_stats_2GiB.txt", "kernel_stats_2GiB.csv",
          "pmc_traffic_random.txt", "pmc_traffic_text_sa.txt", "pmc_traffic_text_ibwt_lcp.txt", "pmc_sq_text.txt", "pmc_sq_random.txt",
          "induction_level_durations.txt", "host_trace_random.txt", "host_trace_text.txt", "microbench_host_xfer.txt", "microbench_h2d_fresh.txt",
-         "text_rounds.txt", "tandem_rounds.txt", "stress_350MB.txt"]
+         "text_rounds.txt", "tandem_rounds.txt", "stress_350MB.txt", "pmc_traffic_random_2GiB.txt"]
 for f in FILES:
     src = os.path.join(F, f)
     if os.path.isfile(src) and os.path.getsize(src) > 0:

@@ -21,6 +21,7 @@ tools/gpu_prof_bench.sh kernel_stats_random --steps 3 --warmup 1 --no-configs --
 tools/gpu_prof_bench.sh kernel_stats_text --workload text --op sa,fbwt,ibwt,lcp --steps 2 --warmup 1 --no-host > $O/kernel_stats_text.txt 2>&1; cp gpurun_out/prof/kernel_stats_text.csv $O/
 tools/gpu_prof_bench.sh kernel_stats_2GiB --size 2147483646 --steps 2 --warmup 1 --no-host > $O/kernel_stats_2GiB.txt 2>&1; cp gpurun_out/prof/kernel_stats_2GiB.csv $O/
 timeout 900 bash tools/gpu_pmc_traffic.sh $O/pmc_traffic_random.txt --no-configs --no-host > /dev/null 2>&1; cat $O/pmc_traffic_random.txt
+timeout 900 bash tools/gpu_pmc_traffic.sh $O/pmc_traffic_random_2GiB.txt --size 2147483646 --no-configs --no-host > /dev/null 2>&1
 timeout 900 bash tools/gpu_pmc_traffic.sh $O/pmc_traffic_text_sa.txt --workload text --op sa --no-configs --no-host > /dev/null 2>&1; cat $O/pmc_traffic_text_sa.txt
 timeout 900 bash tools/gpu_pmc_traffic.sh $O/pmc_traffic_text_ibwt_lcp.txt --workload text --op sa,bwt,ibwt,lcp --no-configs --no-host > /dev/null 2>&1
 timeout 600 bash tools/gpu_pmc_sq.sh $O/pmc_sq_text.txt --workload text --op sa --no-configs --no-host > /dev/null 2>&1
