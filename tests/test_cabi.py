@@ -132,3 +132,22 @@ def test_pmc_traffic_is_keyed_by_the_library_build(L, monkeypatch):
     t, src = bench.traffic_lookup("random", n, "k_partition(level 1)")
     assert t is None and src.startswith("dropped")
     assert bench.traffic_lookup("random", n + 1, "k_partition(level 1)") == (None, None)          # another size: no figure, no reason needed
+
+
+@pytest.mark.parametrize("flags", [["-O2"], ["-O0", "-fsanitize=address"], ["-O2", "-D_GLIBCXX_DEBUG"]])
+def test_dropin_header_compiles(L, tmp_path, flags):
+    """include/library/msufsort.h against g++ -Wall -Wextra -Werror: the plain build (the result vectors grow without being
+    zero-filled: MSUFSORT_UNINITIALIZED_RESIZE), and the two builds that must fall back to the value-initialising resize
+    (AddressSanitizer would flag the untouched storage, the debug containers check their invariants)."""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text('#include <library/msufsort.h>\n#include <cstdio>\nint main() {\n#ifdef MSUFSORT_UNINITIALIZED_RESIZE\n  std::puts("uninitialized");\n#else\n'
+                   '  std::puts("value-initialised");\n#endif\n  std::vector<std::int32_t> v; maniscalco::msufsort_detail::grow_uninitialized(v, 1000); v[999] = 7; v.push_back(8);\n'
+                   '  return v.size() == 1001 && v[999] == 7 && v[1000] == 8 ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    libdir = os.path.join(ROOT, "msufsort_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", *flags, "-I" + os.path.join(ROOT, "include"), str(src), "-L" + libdir, "-lmsufsort_hip",
+                    "-Wl,-rpath," + libdir, "-o", str(exe)], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0
+    assert r.stdout.strip() == ("uninitialized" if flags == ["-O2"] else "value-initialised")

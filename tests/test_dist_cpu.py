@@ -73,3 +73,36 @@ def test_allgatherv_gloo(world, tmp_path, oracle_mod):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"r{r}").read() == "ok"
+
+
+def _worker_empty(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from msufsort_amd import dist as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # slice bounds as the sharded B* sort of a text produces them: ranks whose key range holds no B* suffix have EMPTY slices
+        bounds = [0, 0, 1000, 1000, 2500][: world + 1] if world == 4 else [0, 700, 700, 1500]
+        total = bounds[-1]
+        full = torch.full((total,), -1, dtype=torch.int32)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        full[lo:hi] = torch.arange(lo, hi, dtype=torch.int32) * 3 + 1
+        D.allgatherv_slices(full, bounds, dist)
+        ok = bool((full == torch.arange(total, dtype=torch.int32) * 3 + 1).all())
+        open(os.path.join(tmp, f"e{rank}"), "w").write("ok" if ok else "bad")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_allgatherv_with_empty_slices_gloo(world, tmp_path):
+    """The all-gatherv of the sorted-B* slices (msufsort_amd/dist.py::build_sa_two_stage_sharded) meets ranks without any B* suffix in
+    their key range: empty slices must neither be sent nor waited for."""
+    import torch.multiprocessing as mp
+    port = 29700 + os.getpid() % 1000 + world
+    mp.spawn(_worker_empty, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"e{r}").read() == "ok"
