@@ -125,7 +125,7 @@ enum {
 #define CUR0_STRIDE 64                       // u32 stride of the 256 first-byte cursors: one 256-B line each,
                                              // so the per-tile claim atomics spread over memory channels
 #ifndef S0_POS
-#define S0_POS 8                             // level-0 scatter: text positions per thread (8 or 16)
+#define S0_POS 16                            // level-0 scatter: text positions per thread (8 or 16)
 #endif
 #ifndef S0_THREADS
 #define S0_THREADS 1024
@@ -855,8 +855,12 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
     const bool tiny = allow_pack != 0u && sigma >= 2u && sigma <= 84u;        // kernel-uniform
     const u32 nsym = tiny ? s0_symbols<W>(sigma) : 3u;
     const u32 dshift = tiny ? 24u - s0_digit_bits<W>(sigma) : 0u;             // (wide: 8 + 16 - bits)
-    __shared__ __attribute__((aligned(16))) u64 stage[S0_TILE];
-    __shared__ __attribute__((aligned(16))) u8 sbin[S0_TILE];
+    // Compact staging: LDS holds the text of the tile and, per kept position, its 2-byte offset in the tile, bin-sorted; the
+    // record (key bytes behind the position + index) is put together at write-out from the LDS copy of the text.  6 bytes of
+    // LDS per position instead of 9, so a 16,384-position tile (runs of 64 records = 512 bytes per bin on uniform bytes) keeps two
+    // workgroups per CU.
+    __shared__ __attribute__((aligned(16))) u32 tile[S0_TILE / 4 + 4];
+    __shared__ __attribute__((aligned(16))) unsigned short spos[S0_TILE];
     __shared__ u32 hist[256], lstart[256], gbase[256];
     __shared__ u32 s_total;
     const u32 t = threadIdx.x;
@@ -868,15 +872,20 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
     u32 w[S0_POS / 4 + 2];
 #pragma unroll
     for (int k = 0; k < S0_POS / 4 + 2; ++k) w[k] = 0;
-    if (base < m) {
+    if (base < m + S0_POS) {                     // (one thread past the end too: its words are the look-ahead of the last positions; the text is padded)
 #pragma unroll
         for (int k = 0; k < S0_POS / 4 + 1; ++k) w[k] = *reinterpret_cast<const u32*>(text + base + 4 * k);
     }
-    u32 rank[S0_POS];
+#pragma unroll
+    for (int k = 0; k < S0_POS / 4; ++k) tile[t * (S0_POS / 4) + k] = w[k];
+    if (t == S0_THREADS - 1) { tile[S0_TILE / 4] = w[S0_POS / 4]; tile[S0_TILE / 4 + 1] = 0; }
+    u32 rank[S0_POS / 2];                       // two 16-bit ranks per word
     u32 validmask = 0;
     static_assert(S0_POS == 8 || S0_POS == 16, "the positions of one thread are one or two bytes of the bitmap");
     u32 selmask = S0_POS == 8 ? 0xffu : 0xffffu;
     if (sel_bits) selmask = base < m ? (S0_POS == 8 ? (u32)sel_bits[base >> 3] : (u32)reinterpret_cast<const u16*>(sel_bits)[base >> 4]) : 0u;
+#pragma unroll
+    for (int k = 0; k < S0_POS / 2; ++k) rank[k] = 0;
 #pragma unroll
     for (int j = 0; j < S0_POS; ++j) {
         const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
@@ -884,8 +893,7 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
         const u32 b2 = (w[(j + 2) >> 2] >> (8 * ((j + 2) & 3))) & 255u, b3 = (w[(j + 3) >> 2] >> (8 * ((j + 3) & 3))) & 255u;
         const u64 k32 = ((u64)b0 << 24) | (b1 << 16) | (b2 << 8) | b3;                 // shard = range of 4-byte prefixes
         const bool valid = (base + j < m) && k32 >= lo32 && k32 < hi32 && ((selmask >> j) & 1u);
-        rank[j] = 0;
-        if (valid) { rank[j] = atomicAdd(&hist[b0], 1u); validmask |= 1u << j; }
+        if (valid) { rank[j >> 1] |= atomicAdd(&hist[b0], 1u) << (16 * (j & 1)); validmask |= 1u << j; }
     }
     __syncthreads();
     // claim the output ranges now, consume the answer after staging (hides the atomic's latency)
@@ -898,27 +906,27 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
     for (int j = 0; j < S0_POS; ++j) {
         if (validmask & (1u << j)) {
             const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
-            u32 key = 0;
-            if (!tiny) {
-#pragma unroll
-                for (int q = 1; q <= 4; ++q)
-                    key = (key << 8) | ((w[(j + q) >> 2] >> (8 * ((j + q) & 3))) & 255u);      // (wide: the 4th byte is dropped by make_rec)
-            } else {
-                u32 dg = 0;
-#pragma unroll
-                for (int q = 2; q <= 4; ++q)
-                    if ((u32)q < 2u + nsym) dg = dg * sigma + (u32)s_code[(w[(j + q) >> 2] >> (8 * ((j + q) & 3))) & 255u];
-                key = (((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u) << 24) | (dg << dshift);
-            }
-            const u32 slot = lstart[b0] + rank[j];
-            stage[slot] = make_rec<W>(key, (typename Wd<W>::sa_t)(base + j));
-            sbin[slot] = (u8)b0;
+            spos[lstart[b0] + ((rank[j >> 1] >> (16 * (j & 1))) & 0xffffu)] = (unsigned short)(t * S0_POS + j);
         }
     }
     if (t < 256) gbase[t] = claim - lstart[t];            // slot -> output index is one add: out[gbase[bin] + slot]
     __syncthreads();
     const u32 tot = s_total;
-    for (u32 s = t; s < tot; s += S0_THREADS) out[gbase[sbin[s]] + s] = stage[s];
+    for (u32 s = t; s < tot; s += S0_THREADS) {
+        const u32 l = spos[s];
+        const u64 v = (((u64)tile[(l >> 2) + 1] << 32) | tile[l >> 2]) >> (8u * (l & 3u));      // text bytes l .. l + 4 (and more)
+        const u32 b0 = (u32)v & 255u;
+        u32 key;
+        if (!tiny) key = __builtin_bswap32((u32)(v >> 8));                                       // (wide: the 4th byte is dropped by make_rec)
+        else {
+            u32 dg = 0;
+#pragma unroll
+            for (int q = 2; q <= 4; ++q)
+                if ((u32)q < 2u + nsym) dg = dg * sigma + (u32)s_code[(u32)(v >> (8 * q)) & 255u];
+            key = (((u32)(v >> 8) & 255u) << 24) | (dg << dshift);
+        }
+        out[gbase[b0] + s] = make_rec<W>(key, (typename Wd<W>::sa_t)(base0 + l));
+    }
 }
 
 // Prefix-doubling keys.  narrow: the rank itself (32 bits).  wide: ranks have up to 40 bits but a record only 24 key bits,

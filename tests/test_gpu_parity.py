@@ -970,3 +970,29 @@ def test_single_process_text_over_several_devices(M, oracle_mod, monkeypatch, ki
     assert (sa == want).all()
     if kind != "text_copy":
         assert tm.logical_shards == len(devices) and tm.bstar_suffixes > 0
+
+
+@pytest.mark.parametrize("kind", ["random", "sigma4", "sigma90", "text", "ff_tail"])
+def test_scatter0_tile_edges(M, oracle_mod, kind):
+    """k_scatter0 stages the text of its 16,384-position tile in LDS and builds the records from it at write-out: the key of a
+    position reaches up to four bytes past the tile (look-ahead word of the last thread) and, at the end of the text, into the
+    zero pad.  Sizes around one, two and three tiles, every alphabet class (plain keys, dense base-sigma keys up to 84 codes,
+    just above), sort-all and the two-stage build (bitmap-selected positions)."""
+    o = oracle_mod
+    for n in (16368, 16383, 16384, 16385, 16387, 16388, 16400, 32767, 32768, 32771, 49152 + 15, 49152 + 16):
+        r = np.random.default_rng(n)
+        if kind == "random":
+            t = r.integers(0, 256, n, dtype=np.uint8)
+        elif kind == "sigma4":
+            t = r.integers(0, 4, n, dtype=np.uint8) + 65
+        elif kind == "sigma90":
+            t = r.integers(0, 90, n, dtype=np.uint8) + 33
+        elif kind == "text":
+            t = gen.text_bytes(n, n)
+        else:                                    # 0xff up to the end: the keys of the last positions are 0xff.. then pad zeros
+            t = r.integers(0, 256, n, dtype=np.uint8); t[-9:] = 255
+        t = np.ascontiguousarray(t)
+        want = o.make_suffix_array(t)
+        assert (M.make_suffix_array(t, two_stage=-1) == want).all(), (kind, n)
+        if kind in ("text", "sigma4", "sigma90"):
+            assert (M.make_suffix_array(t, two_stage=1) == want).all(), (kind, n, "two-stage")
