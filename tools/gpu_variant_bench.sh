@@ -17,7 +17,7 @@ for line in sys.stdin:
     if not line.startswith('{'): continue
     j = json.loads(line)
     ph = j.get('phases_ms') or j.get('config', {}).get('phases_ms') or {}
-    print('  ', '$args' or 'random 1 GiB', 'ms/step', j.get('ms_per_step'), {k: ph[k] for k in ph if k in ('k_hist16', 'k_scatter0', 'k_partition', 'k_sort_bits', 'device_total')}, 'valid', j.get('valid'))
+    print('  ', '$args' or 'random 1 GiB', 'ms/step', j.get('ms_per_step'), {k: ph[k] for k in ph if k.startswith(('k_hist16', 'k_scatter0', 'k_partition', 'bucket', 'key rounds', 'induction', 'device_total'))}, 'valid', j.get('valid'))
 "
     done
 done 2>&1 | tee gpurun_out/variants/variant_bench.txt
