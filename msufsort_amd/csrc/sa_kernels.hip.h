@@ -856,9 +856,9 @@ __global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ 
     const u32 nsym = tiny ? s0_symbols<W>(sigma) : 3u;
     const u32 dshift = tiny ? 24u - s0_digit_bits<W>(sigma) : 0u;             // (wide: 8 + 16 - bits)
     // Compact staging: LDS holds the text of the tile and, per kept position, its 2-byte offset in the tile, bin-sorted; the
-    // record (key bytes behind the position + index) is put together at write-out from the LDS copy of the text.  6 bytes of
+    // record (key bytes behind the position + index) is put together at write-out from the LDS copy of the text.  3 bytes of
     // LDS per position instead of 9, so a 16,384-position tile (runs of 64 records = 512 bytes per bin on uniform bytes) keeps two
-    // workgroups per CU.
+    // workgroups per CU (52 KB each; runs beyond 512 bytes buy nothing at 256 bins: tools/microbench/exp_write_runs.hip).
     __shared__ __attribute__((aligned(16))) u32 tile[S0_TILE / 4 + 4];
     __shared__ __attribute__((aligned(16))) unsigned short spos[S0_TILE];
     __shared__ u32 hist[256], lstart[256], gbase[256];
