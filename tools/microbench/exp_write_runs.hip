@@ -11,7 +11,7 @@ __device__ __forceinline__ u64 mix(u64 z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4
 
 // ALIGN: 0 = runs abut (as the kernels do), 1 = every claim rounded up to a whole 64-byte sector (8 records; wastes space, shows the cost of partial sectors)
 // READ: the tile's records are read from memory too (sequentially, as k_partition reads them) instead of made up
-template <int NB, int ALIGN, int READ>
+template <int NB, int ALIGN, int READ, int NT = 0>
 __global__ __launch_bounds__(1024) void k(u64* out, u32* cursors, u32 T, u32 tiles_per_stripe, u64 bin_cap, const u64* in)
 {
     __shared__ u32 cnt[NB], lstart[NB + 1], gbase[NB];
@@ -30,11 +30,13 @@ __global__ __launch_bounds__(1024) void k(u64* out, u32* cursors, u32 T, u32 til
     for (u32 s = t; s < total; s += 1024u) {
         u32 lo = 0, hi = NB;                       // bin of slot s
         while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (lstart[mid] <= s) lo = mid; else hi = mid; }
-        out[(u64)lo * bin_cap + (u32)(gbase[lo] + s)] = READ ? in[(u64)tile * T + s] : (((u64)tile << 32) | s);
+        const u64 val = READ ? in[(u64)tile * T + s] : (((u64)tile << 32) | s);
+        if (NT) __builtin_nontemporal_store(val, &out[(u64)lo * bin_cap + (u32)(gbase[lo] + s)]);
+        else out[(u64)lo * bin_cap + (u32)(gbase[lo] + s)] = val;
     }
 }
 
-template <int NB, int ALIGN, int READ = 0> void run(u64* out, u32* cur, u32 T, u64 total_records, const u64* in = nullptr)
+template <int NB, int ALIGN, int READ = 0, int NT = 0> void run(u64* out, u32* cur, u32 T, u64 total_records, const u64* in = nullptr)
 {
     const u32 stripes = 128;
     const u32 tiles = (u32)(total_records / T);
@@ -48,12 +50,12 @@ template <int NB, int ALIGN, int READ = 0> void run(u64* out, u32* cur, u32 T, u
         for (u32 s = 0; s < stripes; ++s) for (u32 b = 0; b < NB; ++b) h[s * NB + b] = (u32)(s * (bin_cap / stripes));
         hipMemcpy(cur, h, sizeof(u32) * stripes * NB, hipMemcpyHostToDevice);
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<NB, ALIGN, READ>), dim3(tiles), dim3(1024), 0, 0, out, cur, T, tps, bin_cap, in);
+        hipLaunchKernelGGL((k<NB, ALIGN, READ, NT>), dim3(tiles), dim3(1024), 0, 0, out, cur, T, tps, bin_cap, in);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
     printf("tile %6u records, %4d bins (runs of %4u records = %5u B on average), %s: %7.3f ms  %6.0f GB/s moved\n", T, NB, T / NB, T / NB * 8,
-           READ ? "records read sequentially + written" : (ALIGN ? "claims rounded to whole sectors" : "runs abut at 8-byte positions  "), best, (double)tiles * T * 8 * (READ ? 2 : 1) / best / 1e6);
+           NT ? (READ ? "read + NON-TEMPORAL stores          " : "NON-TEMPORAL stores                 ") : READ ? "records read sequentially + written" : (ALIGN ? "claims rounded to whole sectors" : "runs abut at 8-byte positions  "), best, (double)tiles * T * 8 * (READ ? 2 : 1) / best / 1e6);
 }
 
 int main()
@@ -70,5 +72,7 @@ int main()
     for (u32 T : {4096u, 8192u, 16384u, 32768u}) run<256, 0, 1>(out, cur, T, total, in);
     for (u32 T : {8192u, 16384u, 32768u}) run<512, 0, 1>(out, cur, T, total, in);
     run<64, 0, 1>(out, cur, 16384u, total, in);
+    // non-temporal stores (the runs of neighbouring tiles meet in L2: does bypassing it cost or pay?)
+    for (u32 T : {8192u, 16384u}) { run<256, 0, 0, 1>(out, cur, T, total); run<256, 0, 1, 1>(out, cur, T, total, in); }
     return 0;
 }
