@@ -977,7 +977,7 @@ def test_scatter0_tile_edges(M, oracle_mod, kind):
     """k_scatter0 stages the text of its 16,384-position tile in LDS and builds the records from it at write-out: the key of a
     position reaches up to four bytes past the tile (look-ahead word of the last thread) and, at the end of the text, into the
     zero pad.  Sizes around one, two and three tiles, every alphabet class (plain keys, dense base-sigma keys up to 84 codes,
-    just above), sort-all and the two-stage build (bitmap-selected positions)."""
+    just above), sort-all, the two-stage build (bitmap-selected positions) and the wide engine (key-range shards)."""
     o = oracle_mod
     for n in (16368, 16383, 16384, 16385, 16387, 16388, 16400, 32767, 32768, 32771, 49152 + 15, 49152 + 16):
         r = np.random.default_rng(n)
@@ -996,3 +996,6 @@ def test_scatter0_tile_edges(M, oracle_mod, kind):
         assert (M.make_suffix_array(t, two_stage=-1) == want).all(), (kind, n)
         if kind in ("text", "sigma4", "sigma90"):
             assert (M.make_suffix_array(t, two_stage=1) == want).all(), (kind, n, "two-stage")
+        if n in (16384, 16387, 32771):           # the wide engine's instance of the kernel (40-bit indices, 24 key bits per record)
+            assert (M.make_suffix_array_i64(t, force_wide=True) == want).all(), (kind, n, "wide")
+            assert (M.make_suffix_array_i64(t, force_wide=True, n_shards=3) == want).all(), (kind, n, "wide, 3 shards")
