@@ -15,6 +15,8 @@ template <int NB, int ALIGN, int READ, int NT = 0>
 __global__ __launch_bounds__(1024) void k(u64* out, u32* cursors, u32 T, u32 tiles_per_stripe, u64 bin_cap, const u64* in)
 {
     __shared__ u32 cnt[NB], lstart[NB + 1], gbase[NB];
+    extern __shared__ u32 pad[];                             // (only there to pin the number of workgroups per CU)
+    if (T == 1u) pad[threadIdx.x] = 0;
     const u32 t = threadIdx.x, tile = blockIdx.x, stripe = tile / tiles_per_stripe;
     // counts: T / NB with a jitter of +- 50 %, made to sum to T
     if (t < NB) { const u64 h = mix((u64)tile * NB + t); cnt[t] = (u32)((T / NB) / 2 + h % (T / NB + 1)); }
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(1024) void k(u64* out, u32* cursors, u32 T, u32 til
         gbase[t] = atomicAdd(&cursors[(u64)stripe * NB + t], c) - lstart[t];
     }
     __syncthreads();
-    for (u32 s = t; s < total; s += 1024u) {
+    for (u32 s = t; s < total; s += blockDim.x) {
         u32 lo = 0, hi = NB;                       // bin of slot s
         while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (lstart[mid] <= s) lo = mid; else hi = mid; }
         const u64 val = READ ? in[(u64)tile * T + s] : (((u64)tile << 32) | s);
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(1024) void k(u64* out, u32* cursors, u32 T, u32 til
     }
 }
 
-template <int NB, int ALIGN, int READ = 0, int NT = 0> void run(u64* out, u32* cur, u32 T, u64 total_records, const u64* in = nullptr)
+template <int NB, int ALIGN, int READ = 0, int NT = 0> void run(u64* out, u32* cur, u32 T, u64 total_records, const u64* in = nullptr, u32 threads = 1024, u32 lds_pad = 0)
 {
     const u32 stripes = 128;
     const u32 tiles = (u32)(total_records / T);
@@ -50,10 +52,11 @@ template <int NB, int ALIGN, int READ = 0, int NT = 0> void run(u64* out, u32* c
         for (u32 s = 0; s < stripes; ++s) for (u32 b = 0; b < NB; ++b) h[s * NB + b] = (u32)(s * (bin_cap / stripes));
         hipMemcpy(cur, h, sizeof(u32) * stripes * NB, hipMemcpyHostToDevice);
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<NB, ALIGN, READ, NT>), dim3(tiles), dim3(1024), 0, 0, out, cur, T, tps, bin_cap, in);
+        hipLaunchKernelGGL((k<NB, ALIGN, READ, NT>), dim3(tiles), dim3(threads), lds_pad, 0, out, cur, T, tps, bin_cap, in);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
+    if (threads != 1024 || lds_pad) printf("[%u threads, %u KiB of LDS per workgroup] ", threads, lds_pad >> 10);
     printf("tile %6u records, %4d bins (runs of %4u records = %5u B on average), %s: %7.3f ms  %6.0f GB/s moved\n", T, NB, T / NB, T / NB * 8,
            NT ? (READ ? "read + NON-TEMPORAL stores          " : "NON-TEMPORAL stores                 ") : READ ? "records read sequentially + written" : (ALIGN ? "claims rounded to whole sectors" : "runs abut at 8-byte positions  "), best, (double)tiles * T * 8 * (READ ? 2 : 1) / best / 1e6);
 }
@@ -72,6 +75,14 @@ int main()
     for (u32 T : {4096u, 8192u, 16384u, 32768u}) run<256, 0, 1>(out, cur, T, total, in);
     for (u32 T : {8192u, 16384u, 32768u}) run<512, 0, 1>(out, cur, T, total, in);
     run<64, 0, 1>(out, cur, 16384u, total, in);
+    // workgroups per CU: 2 x 1024 threads (above) against 3 x 512 (52 KiB each), 4 x 512, 2 x 512 (80 KiB), 1 x 1024 (100 KiB)
+    hipFuncSetAttribute((const void*)k<256, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 << 10);
+    run<256, 0>(out, cur, 16384u, total, nullptr, 512, 50 << 10);
+    run<256, 0>(out, cur, 16384u, total, nullptr, 512, 0);
+    run<256, 0>(out, cur, 16384u, total, nullptr, 512, 76 << 10);
+    run<256, 0>(out, cur, 16384u, total, nullptr, 1024, 100 << 10);
+    run<256, 0>(out, cur, 8192u, total, nullptr, 512, 50 << 10);
+    run<256, 0>(out, cur, 8192u, total, nullptr, 256, 0);
     // non-temporal stores (the runs of neighbouring tiles meet in L2: does bypassing it cost or pay?)
     for (u32 T : {8192u, 16384u}) { run<256, 0, 0, 1>(out, cur, T, total); run<256, 0, 1, 1>(out, cur, T, total, in); }
     return 0;
