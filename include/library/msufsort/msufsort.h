@@ -15,12 +15,21 @@
 // no CPU fallback behind this header.
 #pragma once
 
+// The reference header pulls these in (msufsort.h:30-36) and its one consumer relies on that: the demo uses std::thread
+// without including <thread> itself (main.cpp:76).  A drop-in has to keep the transitive includes too
+// (tests/test_cabi.py::test_reference_consumer_compiles_unchanged builds that file against this header).
+#include <vector>
+#include <stdint.h>
 #include <atomic>
+#include <thread>
+#include <memory>
+#include <array>
+#include <functional>
+// what this header needs itself
 #include <cstdint>
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
-#include <vector>
 
 #include "../../msufsort_hip.h"
 

@@ -151,3 +151,33 @@ def test_dropin_header_compiles(L, tmp_path, flags):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0
     assert r.stdout.strip() == ("uninitialized" if flags == ["-O2"] else "value-initialised")
+
+
+REF_MAIN = "/root/reference/src/executable/msufsort/main.cpp"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="the reference tree only exists in the build container")
+def test_reference_consumer_compiles_unchanged(L, tmp_path):
+    """The reference ships ONE consumer of its library: the demo executable, which includes <library/msufsort.h> (main.cpp:8)
+    and leans on what that header includes (std::thread without <thread>, main.cpp:76).  Compiled here UNCHANGED, from where it
+    lies, against this repo's include/ and linked to libmsufsort_hip.so (round-4 review: the header lacked the reference's
+    transitive includes and this build failed).  oracle/Makefile keeps the same build as oracle/_ref/msufsort_demo_dropin,
+    which travels to the GPU box and is RUN there (tests/test_gpu_dist.py::test_reference_demo_runs_on_the_dropin)."""
+    import subprocess
+    exe = tmp_path / "ref_demo"
+    libdir = os.path.join(ROOT, "msufsort_amd", "lib")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(ROOT, "include"), REF_MAIN, "-L" + libdir, "-lmsufsort_hip",
+                        "-Wl,-rpath," + libdir, "-o", str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)          # no arguments: usage text, no device needed
+    assert r.returncode == 0 and "usage: msufsort [b|s|l] input" in r.stdout
+    # the include set itself, so that a box without the reference tree still notices a regression
+    hdr = open(os.path.join(ROOT, "include", "library", "msufsort", "msufsort.h")).read()
+    for inc in ("<vector>", "<stdint.h>", "<atomic>", "<thread>", "<memory>", "<array>", "<functional>"):
+        assert "#include " + inc in hdr, inc
+
+
+def test_dropin_header_keeps_the_reference_includes():
+    hdr = open(os.path.join(ROOT, "include", "library", "msufsort", "msufsort.h")).read()
+    for inc in ("<vector>", "<stdint.h>", "<atomic>", "<thread>", "<memory>", "<array>", "<functional>"):          # reference msufsort.h:30-36
+        assert "#include " + inc in hdr, inc

@@ -1,6 +1,7 @@
 """GPU box (1 GPU): the full N>1 flow of bench.py - shard planning, per-rank sharded HIP sort, all-gatherv,
-on-device validation - with 2 ranks sharing cuda:0 over gloo (RCCL refuses two ranks on one device; the
-driver exercises RCCL itself on the 8-GPU node)."""
+on-device validation - with 2, 4 and 8 ranks sharing cuda:0 over gloo (RCCL refuses two ranks on one device).  RCCL itself and
+peer copies between two devices have NOT run anywhere yet: no box this repo has met had a second GPU (the line says so:
+`config.backend` / `config.rccl_ranks`)."""
 import json
 import os
 import subprocess
@@ -117,6 +118,27 @@ def test_demo_cli_modes(tmp_path):
     assert r.returncode == 0 and "suffix array validated" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([exe, "t"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " 0 errors" in r.stdout, r.stdout + r.stderr
+
+
+def test_reference_demo_runs_on_the_dropin(tmp_path):
+    """The reference's own demo executable - main.cpp compiled UNCHANGED against include/ and linked to libmsufsort_hip.so by
+    oracle/Makefile in the build container (oracle/_ref/msufsort_demo_dropin) - runs its s / b / l modes on the GPU engine and
+    its OWN validators (main.cpp:236-270 adjacent-pair check, the BWT round trip main.cpp:470-487) accept the results."""
+    sys.path.insert(0, ROOT)
+    from msufsort_amd import gen
+    exe = os.path.join(ROOT, "oracle", "_ref", "msufsort_demo_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/msufsort_demo_dropin was not built (no reference tree when the snapshot was made)")
+    for name, data in (("text", gen.text_bytes(3 << 20, 23)), ("random", gen.random_bytes(40 << 20, 9))):          # 40 MiB: the streaming entry point
+        f = tmp_path / (name + ".bin")
+        data.tofile(f)
+        for mode in ("s", "b") if name == "random" else ("s", "b", "l"):
+            r = subprocess.run([exe, mode, str(f), "8"], capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0 and "caught exception" not in r.stdout and "ERROR" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+            if mode != "l":
+                assert "test completed and results validated successfully" in r.stdout, r.stdout[-2000:]
+            else:
+                assert "suffix array completed" in r.stdout, r.stdout[-2000:]
 
 
 @pytest.mark.parametrize("world", [2, 4])
