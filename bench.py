@@ -469,6 +469,32 @@ def config_lines(M, torch, ctx, dev, steps, no_cpu):
     return {"cfg3": cfg3, "cfg4": cfg4}, ok
 
 
+def metric_label(workload, ops, n):
+    """The headline string only for the headline input (BASELINE.json: SA build on 1 GiB random bytes = n 2^30 - 1, the oracle's
+    ceiling); every other size / workload / op names itself (round-4 review: a 256 MiB run carried the 1 GiB label)."""
+    if workload == "random" and ops == ["sa"] and n == (1 << 30) - 1:
+        return "MB/s input for SA build on 1 GiB random bytes"
+    return f"MB/s input for {'+'.join(ops)} on {workload} (n={n})"
+
+
+def rccl_ranks_of(backend, world):
+    """`config.rccl_ranks`: ranks of an RCCL communicator - None when the process group is not RCCL (the gloo test hook)."""
+    return world if backend == "nccl" else None
+
+
+def multi_gpu_budget(n, world, index_bytes, rows_max, two_stage, want_bwt, pipelined):
+    """HBM bytes one rank of `bench.py --gpus N` allocates.  n = 2^33, N = 8, int64 rows: text 8 GiB + rows
+    64 GiB + rank replica 64 GiB + sort workspace ~70 GiB + group heads / windows ~15 GiB = ~222 GiB of the 288 GB (268 GiB)."""
+    from msufsort_amd import dist as mdist
+    b = {"text": n + 64, "rows": (n + 1) * index_bytes * (2 if pipelined else 1), "group_heads": max(rows_max, 1) * 4,
+         "sort_workspace": int(70 * (rows_max + rows_max // 8 + (2 << 20))) + (300 << 20),
+         "doubling (rank replica + update / group-head windows; only for inputs with deep ties)": mdist.ShardState.bytes_needed(n, rows_max, world, index_bytes),
+         "two_stage (sorted B* + induction workspace)": (n // 2 + 2) * 4 + 9 * n if two_stage else 0,
+         "bwt": (n + rows_max) if want_bwt else 0}
+    b["total"] = sum(b.values())
+    return b
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -482,6 +508,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip the config 3 / 4 lines")
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (PCIe inclusive) legs")
+    ap.add_argument("--index", default="auto", choices=["auto", "int32", "int64"], help="N > 1: row width. auto = int64 (wide engine, 40-bit indices) beyond 2^31 - 2 bytes "
+                    "(BASELINE config 5), int32 otherwise; int64 on a small input is the parity-test form of config 5")
+    ap.add_argument("--check-reference", action="store_true", help="N > 1, after the timed region: rank 0 compares every row (and the BWT) with the CPU checker's (oracle/)")
     ap.add_argument("--two-stage", type=int, default=0, help="N > 1: 0 = text-like inputs take the sharded B* sort + induction on every rank "
                     "(the library's size / alphabet policy), 1 = whenever possible, -1 = never (sort-all shards)")
     args = ap.parse_args()
@@ -502,10 +531,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ops = [x for x in args.op.split(",") if x]
-    assert ops and ops[0] == "sa" and set(ops) <= {"sa", "bwt", "fbwt", "ibwt", "lcp"} and (world == 1 or ops == ["sa"]), "--op sa[,bwt][,fbwt][,ibwt][,lcp] (N > 1: sa only)"
+    assert ops and ops[0] == "sa" and set(ops) <= {"sa", "bwt", "fbwt", "ibwt", "lcp"} and (world == 1 or ops in (["sa"], ["sa", "fbwt"])), "--op sa[,bwt][,fbwt][,ibwt][,lcp] (N > 1: sa or sa,fbwt)"
     n = args.size
     headline = args.workload == "random" and ops == ["sa"]
-    metric = "MB/s input for SA build on 1 GiB random bytes" if headline else f"MB/s input for {'+'.join(ops)} on {args.workload}"
+    metric = metric_label(args.workload, ops, n)
 
     if world == 1:
         dev = torch.device("cuda", local)
@@ -582,49 +611,115 @@ def main():
     else:
         dist.init_process_group(backend)
     dev = torch.device("cuda", local)
-    t = gen.GENERATORS[args.workload](n, args.seed)
-    d_text = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
-    d_text[:n] = torch.from_numpy(t).to(dev)
-    del t
-    d_sa = torch.empty(n + 1, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize(dev)          # the engine works on its own HIP stream: the upload must have landed
-    ctx = M.DeviceContext(local, n // world + n // (8 * world) + (1 << 20))     # workspace: my shard's suffixes
+
+    def refuse(msg, code=2):
+        if rank == 0:
+            print("bench.py: " + msg, file=sys.stderr)
+        dist.destroy_process_group()
+        return code
 
     # the communicator the exchange runs on must have exactly --gpus ranks: a line measured on fewer is refused
     backend_world = dist.get_world_size()
     if backend_world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but the {backend} process group has {backend_world} rank(s)", file=sys.stderr)
-        dist.destroy_process_group()
-        return 2
+        return refuse(f"--gpus {args.gpus} but the {backend} process group has {backend_world} rank(s)")
+    # row width: the reference's suffix_index is int32 with two flag bits (msufsort.h:47, 84-93: n < 2^30); int32 rows here hold
+    # n <= 2^31 - 2, beyond that (BASELINE config 5: 8 GiB) the wide engine writes int64 rows
+    int32_max_n = (1 << 31) - 2
+    if args.index == "int32" and n > int32_max_n:
+        return refuse(f"--index int32 holds n <= {int32_max_n}; n = {n} needs --index int64 (or auto)")
+    wide = args.index == "int64" or (args.index == "auto" and n > int32_max_n)
+    index_bytes, row_dt, index_name = (8, torch.int64, "int64") if wide else (4, torch.int32, "int32")
+    want_bwt = "fbwt" in ops
+
+    two_stage_possible = (not wide) and args.two_stage >= 0
+    pipelined_ok = (not wide) and (not want_bwt)
+
+    # memory: say what is needed and refuse BEFORE anything large is allocated or generated (n = 2^33 over 8 ranks: ~222 GiB per
+    # GPU) - first with balanced shards assumed, again once the real slice bounds are known
+    share = world if os.environ.get("MSUFSORT_BENCH_ONE_DEVICE") else 1          # (test hook: every rank allocates on the one GPU)
+
+    def hbm_short(rows_max, allocated):
+        budget = multi_gpu_budget(n, world, index_bytes, rows_max, two_stage_possible, want_bwt, pipelined_ok)
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        short = torch.tensor([1 if (budget["total"] - allocated) * share > free_b else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(short, op=dist.ReduceOp.MAX)
+        if not int(short.item()):
+            return budget, None
+        gib = lambda v: round(v / 2**30, 2)  # noqa: E731
+        return budget, (f"n = {n} with {index_name} rows over {world} rank(s) needs ~{gib(budget['total'])} GiB of HBM per GPU "
+                        f"({', '.join(f'{k}: {gib(v)}' for k, v in budget.items() if k != 'total' and v)}); rank {rank} has {gib(free_b)} GiB free "
+                        f"of {gib(total_b)}{' shared by ' + str(world) + ' ranks' if share > 1 else ''} - use more GPUs or a smaller --size")
+
+    budget, msg = hbm_short((n + 1) // world + (n >> 6) + 1, 0)
+    if msg:
+        return refuse(msg)
+
+    # the text is generated ONCE (rank 0) and replicated over the links ("H2D to one + broadcast")
+    d_text = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        t = gen.GENERATORS[args.workload](n, args.seed)
+        for s0 in range(0, n, 1 << 30):
+            d_text[s0:min(n, s0 + (1 << 30))] = torch.from_numpy(t[s0:min(n, s0 + (1 << 30))]).to(dev)
+        del t
+    torch.cuda.synchronize(dev)
+    dist.broadcast(d_text, src=0)
+    torch.cuda.synchronize(dev)          # the engine works on its own HIP stream: the text must have landed
+    ctx = M.DeviceContext(local, 0)
     bounds = ctx.shard_bounds(d_text, n, world)
+    rows_max = max(bounds[g + 1] - bounds[g] for g in range(world))
+    budget, msg = hbm_short(rows_max, n + 64)
+    if msg:
+        return refuse(msg)
+
     exchange = mdist.select_exchange(dist, dev)
-    d_grp = torch.empty(n + 1, dtype=torch.int32, device=dev)
-    sa_bufs = [d_sa, torch.empty(n + 1, dtype=torch.int32, device=dev)]
-    pending = {"works": [], "buf": None, "last": d_sa, "k": 0}
+    d_sa = torch.empty(n + 1, dtype=row_dt, device=dev)
+    d_grp = torch.empty(max(rows_max, 1), dtype=torch.int32, device=dev)          # tie-group heads of MY slice only
+    sa_bufs = [d_sa] + ([torch.empty(n + 1, dtype=row_dt, device=dev)] if pipelined_ok else [])
+    d_bwt = torch.empty(n, dtype=torch.uint8, device=dev) if want_bwt else None
+    d_row_bytes = torch.empty(max(rows_max, 1), dtype=torch.uint8, device=dev) if want_bwt else None
+    pending = {"works": [], "buf": None, "last": d_sa, "k": 0, "sentinel": None}
     shard_state = mdist.ShardState()
     phases = []
+    op_ms = {k: 0.0 for k in ops}
 
     # A step = ONE complete build: every rank sorts its key range, then the all-gatherv of the slices, finished on every
     # rank before the next step starts - nothing of one build overlaps another.  ms_per_step is therefore the LATENCY of a
     # build, and `value` the throughput a caller sees who needs each array before asking for the next (round-3 review:
     # a strong-scaling curve of a pipelined rate would flatter).
-    d_bstar = torch.empty(n // 2 + 2, dtype=torch.int32, device=dev) if args.two_stage >= 0 else None
-    ts_stats = {}
+    d_bstar = torch.empty(n // 2 + 2, dtype=torch.int32, device=dev) if two_stage_possible else None
+    ts_stats, bwt_stats = {}, {}
 
-    def step():
+    def build_rows(out, gather_rows=True):
+        """True: the two-stage sharded build ran (every rank holds ALL rows); False: the sort-all shards ran."""
         # text-like inputs: B* suffixes sorted by key-range shards, their slices exchanged, the rest induced on every rank
         # (declines - on every rank alike - for anything else: random bytes take the sort-all shards below)
-        if d_bstar is not None and ts_stats.get("two_stage_status") != 1 and mdist.build_sa_two_stage_sharded(ctx, d_text, n, sa_bufs[0], d_bstar, rank, world, dist, two_stage=args.two_stage, stats=ts_stats):
-            pending["last"] = sa_bufs[0]
-            return
-        mdist.build_sa_sharded(ctx, d_text, n, sa_bufs[0], rank, world, dist, bounds, d_grp_full=d_grp, overlap=False, state=shard_state)
+        if d_bstar is not None and ts_stats.get("two_stage_status") != 1 and mdist.build_sa_two_stage_sharded(ctx, d_text, n, out, d_bstar, rank, world, dist, two_stage=args.two_stage, stats=ts_stats):
+            return True
+        mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp=d_grp, overlap=False, index_bytes=index_bytes, state=shard_state,
+                               gather_rows=gather_rows)
+        return False
+
+    def step():
+        t0 = time.perf_counter()
+        build_rows(sa_bufs[0])
+        phases.append(ctx.timings())
         pending["last"] = sa_bufs[0]
+        t1 = time.perf_counter()
+        op_ms["sa"] += (t1 - t0) * 1e3
+        if want_bwt:
+            # the forward transform as ONE call (its own sort, like msufsort::forward_burrows_wheeler_transform, cpp:1771-1817): the
+            # rows stay distributed, every rank gathers the bytes of its slice, n/G-byte slices travel instead of the rows
+            if build_rows(sa_bufs[0], gather_rows=False):
+                pending["sentinel"] = ctx.bwt_from_sa(d_text, n, sa_bufs[0], d_bwt, index_bytes)          # all rows are here already: no exchange
+            else:
+                pending["sentinel"] = mdist.forward_bwt_sharded(ctx, d_text, n, sa_bufs[0], bounds, rank, world, dist, d_bwt, d_row_bytes, index_bytes, stats=bwt_stats)
+            op_ms["fbwt"] += (time.perf_counter() - t1) * 1e3
 
     # the pipelined flavour (secondary figure): two output buffers, the all-gatherv of build k travels while build k+1 is sorted
     def step_pipelined():
         out = sa_bufs[pending["k"] & 1]
         pending["k"] += 1
-        works = mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp_full=d_grp, overlap=True, state=shard_state)
+        works = mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp=d_grp, overlap=True, index_bytes=index_bytes, state=shard_state)
         mdist.wait_all(pending["works"], pending["buf"])        # the previous exchange overlapped with this build
         pending["works"], pending["buf"], pending["last"] = works, out, out
 
@@ -638,11 +733,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    phases.clear()
+    for k in op_ms:
+        op_ms[k] = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        phases.append(ctx.timings())
     barrier()
     dt = time.perf_counter() - t0
     x = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -665,20 +762,24 @@ def main():
                    "per_rank": {"latency_ms": [round(float(q[0]), 3) for q in per], "exchange_ms": [round(float(q[1]), 3) for q in per],
                                 "sort_ms": [round(float(q[2]), 3) for q in per], "rows": [int(bounds[g + 1] - bounds[g]) for g in range(world)]}}
     if not used_two_stage:
-        step_pipelined(); drain(); barrier()
-        tp0 = time.perf_counter()
-        for _ in range(kp):
-            step_pipelined()
-        drain()
-        barrier()
-        xp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
-        dist.all_reduce(xp, op=dist.ReduceOp.MAX)
-        pipelined_ms = float(xp.item()) / kp * 1e3
+        pipelined = None
+        if pipelined_ok:
+            step_pipelined(); drain(); barrier()
+            tp0 = time.perf_counter()
+            for _ in range(kp):
+                step_pipelined()
+            drain()
+            barrier()
+            xp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
+            dist.all_reduce(xp, op=dist.ReduceOp.MAX)
+            pipelined_ms = float(xp.item()) / kp * 1e3
+            pipelined = {"ms_per_build": round(pipelined_ms, 3), "MBps": round(n / pipelined_ms / 1e3, 1), "builds": kp,
+                         "note": "build k+1 sorted while the all-gatherv of build k travels (two output buffers); NOT `value`"}
         lat, exc = [], []
         for _ in range(2):
             barrier()
             a = time.perf_counter()
-            w = mdist.build_sa_sharded(ctx, d_text, n, sa_bufs[0], rank, world, dist, bounds, d_grp_full=d_grp, overlap=True, state=shard_state)
+            w = mdist.build_sa_sharded(ctx, d_text, n, sa_bufs[0], rank, world, dist, bounds, d_grp=d_grp, overlap=True, index_bytes=index_bytes, state=shard_state)
             torch.cuda.synchronize(dev)
             b = time.perf_counter()
             mdist.wait_all(w, sa_bufs[0])
@@ -691,28 +792,47 @@ def main():
         dist.all_reduce(x, op=dist.ReduceOp.MAX)
         pending["last"] = sa_bufs[0]
         latency = {"latency_ms": round(float(x[0]), 3), "exchange_ms": round(float(x[1]), 3), "sort_ms": round(float(x[2]), 3),
-                   "pipelined": {"ms_per_build": round(pipelined_ms, 3), "MBps": round(n / pipelined_ms / 1e3, 1), "builds": kp,
-                                 "note": "build k+1 sorted while the all-gatherv of build k travels (two output buffers); NOT `value`"},
+                   "pipelined": pipelined,
                    # what the sorts alone sustain (every rank keeps its slice, nothing is gathered): NOT `value` - every GPU must take in
-                   # (N-1)/N of the 4(n+1)-byte array over xGMI for the all-gatherv the metric asks for, and that, not the sort, bounds the step
+                   # (N-1)/N of the row array over xGMI for the all-gatherv the metric asks for, and that, not the sort, bounds the step
                    "sorts_only_MBps": round(n / (float(x[2]) * 1e-3) / 1e6, 1) if float(x[2]) > 0 else None,
                    "per_rank": {"latency_ms": [round(float(q[0]), 3) for q in per], "exchange_ms": [round(float(q[1]), 3) for q in per],
                                 "sort_ms": [round(float(q[2]), 3) for q in per],
                                 "rows": [int(bounds[g + 1] - bounds[g]) for g in range(world)]}}
     ok = True
     if rank == 0:
-        ok = ctx.validate_sa(d_text, n, pending["last"]) == 0     # on-device checker on the assembled array
+        ok = ctx.validate_sa(d_text, n, pending["last"], index_bytes) == 0     # on-device checker on the assembled array
         against = "on-device checker (adjacent-pair order + permutation) on the assembled array"
+        if want_bwt:
+            # the gathered byte slices against the transform read off the assembled rows on this device
+            chk = torch.empty(n, dtype=torch.uint8, device=dev)
+            s_chk = ctx.bwt_from_sa(d_text, n, pending["last"], chk, index_bytes)
+            ok = ok and s_chk == pending["sentinel"] and bool(torch.equal(chk, d_bwt))
+            against += " + BWT bytes and sentinel row equal to the transform read off the assembled rows"
+            del chk
         e = golden_entry(args.workload, args.seed, n)
-        if e is not None:
+        if e is not None and not wide:
             try:
-                gok, _ = check_golden(e, pending["last"])
+                gok, checked = check_golden(e, pending["last"], d_bwt, pending["sentinel"])
                 ok = ok and gok
-                against = "reference hash (FNV-1a-64 of sa; tests/golden/golden_full.json) + " + against
+                against = "reference hash (FNV-1a-64 of " + ", ".join(checked) + "; tests/golden/golden_full.json) + " + against
             except Exception as ex:  # noqa: BLE001
                 against += f" (reference hash not checked: {ex})"
+        if args.check_reference:
+            # every row (and the BWT) against the CPU checker - the unmodified reference when oracle/_ref is here, else the C restatement
+            import numpy as np
+
+            import oracle
+            th = gen.GENERATORS[args.workload](n, args.seed)
+            use_ref = oracle.have_reference() and n < (1 << 30)
+            want = oracle.ref_make_suffix_array(th, 4) if use_ref else oracle.make_suffix_array(th)
+            ok = ok and bool((pending["last"].cpu().numpy().astype(np.int64) == np.asarray(want, dtype=np.int64)).all())
+            if want_bwt:
+                wb, ws = oracle.ref_forward_bwt(th, 4) if use_ref else oracle.forward_bwt(th)
+                ok = ok and int(ws) == int(pending["sentinel"]) and bool((d_bwt.cpu().numpy() == wb).all())
+            against = ("rows" + (" + BWT" if want_bwt else "") + " equal to " + ("the unmodified reference's (oracle/_ref)" if use_ref else "the C restatement's (oracle/)") + " + " + against)
         K = args.steps
-        kern, avg, two_stage, mstar = kernel_table(phases, K, n, args.workload, ops, [0, 0])
+        kern, avg, two_stage, mstar = kernel_table(phases, K, n, args.workload, ["sa"], [0, 0])
         # a rank reads the whole text (hist + scatter) but sorts only its shard: bill the record passes with the shard's suffixes
         if used_two_stage:
             # (the sort phases saw this rank's share of the B* suffixes; the induction ran over all rows on every rank)
@@ -723,24 +843,31 @@ def main():
             my = int(bounds[1] - bounds[0])
             kern = {"k_hist16": kern["k_hist16"], "k_scatter0": (kern["k_scatter0"][0], n + 8 * my),
                     "k_partition(level 1)": (kern["k_partition(level 1)"][0], 16 * my),
-                    "bucket sort (rank 0's shard)": (avg("bucket_sort_ms"), 12 * my)}
+                    "bucket sort (rank 0's shard)": (avg("bucket_sort_ms"), (8 + index_bytes) * my)}
         # (key rounds / distributed doubling of a sharded build are several calls with their own timings: see "doubling")
         out = {
             "metric": metric, "value": round(n / (dt / K) / 1e6, 2), "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "valid": bool(ok), "valid_against": against,
-            "config": {"workload": f"{args.workload} bytes (splitmix64 seed {args.seed}), n={n}, int32 SA, 4-byte-prefix range sharding x{world}",
-                       "n": n, "index": "int32", "ops": ops, "allgatherv": exchange, "rccl_ranks": backend_world, "pipelined": False,
-                       "backend": backend,
+            "config": {"workload": f"{args.workload} bytes (splitmix64 seed {args.seed}), n={n}, {index_name} SA, 4-byte-prefix range sharding x{world}",
+                       "n": n, "index": index_name, "ops": ops, "allgatherv": exchange, "rccl_ranks": rccl_ranks_of(backend, backend_world), "ranks": backend_world,
+                       "pipelined": False, "backend": backend,
                        "step": ("B* suffixes of my key range sorted + all-gatherv of the sorted-B* slices (4|B*| bytes) + induction of all rows on every rank" if used_two_stage else
-                                "sort of my key range + all-gatherv of the slices, complete on every rank (latency of one build)")},
+                                "sort of my key range + all-gatherv of the slices, complete on every rank (latency of one build)") +
+                               ("; then the forward BWT as one call: its own sharded sort, rows kept distributed, n/G-byte slices all-gathered" if want_bwt else "")},
             "roofline": roofline_of(kern, n, args.workload, False),
             "kernels": kernels_json(kern),
             "phases_ms": {k: round(v[0], 4) for k, v in kern.items()} | {"refine": round(avg("refine_ms"), 4), "device_total": round(avg("total_ms"), 4)},
-            "allgatherv_bytes_per_rank": int(4 * (mstar if used_two_stage else n + 1) * (world - 1) / world),
+            "allgatherv_bytes_per_rank": int((4 * mstar if used_two_stage else index_bytes * (n + 1)) * (world - 1) / world),
+            "hbm_budget_GiB_per_rank": {k: round(v / 2**30, 3) for k, v in budget.items() if v},
         }
         out.update(latency)           # where the latency goes (sort / exchange, per rank) and the pipelined rate as a secondary figure
+        if want_bwt:
+            out["ops_ms"] = {k: round(v / K, 3) for k, v in op_ms.items()}
+            out["forward_bwt"] = dict(bwt_stats, sentinel_row=pending["sentinel"], MBps=round(n / (op_ms["fbwt"] / K) / 1e3, 1) if op_ms["fbwt"] else None,
+                                      exchanged="nothing beyond the sorted-B* slices (every rank induced all rows)" if used_two_stage else
+                                      f"{int(n * (world - 1) / world)} bytes per rank (n/G-byte slices) instead of {int(index_bytes * (n + 1) * (world - 1) / world)} (rows)")
         if shard_state.stats:
             out["doubling"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in shard_state.stats.items()}
         if ts_stats:

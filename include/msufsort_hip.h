@@ -253,6 +253,15 @@ int msufsort_hip_bwt_from_sa_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, i
 int msufsort_hip_bwt_from_sa_i64_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int64_t n,
                                      const int64_t* d_sa, uint8_t* d_bwt_out, int64_t* sentinel_row);
 
+/* Sharded forward transform (SURVEY 8(e) "Collective: ... for BWT gather n/G-byte slices instead"; the reference writes its n
+ * output bytes in place and returns the sentinel row, cpp:1771-1817).  For the FINISHED slice rows [lo, hi) of a sharded build:
+ * d_row_bytes_out[r - lo] = T[SA[r] - 1] (one byte per row; the row of suffix 0 gets a placeholder), *sentinel_row = that row
+ * if it lies in the slice, else -1.  The ranks agree on the sentinel row (max), every rank moves its bytes to
+ * out[r - (r > sentinel)] and ONE all-gatherv of the byte slices completes the transform: n bytes travel instead of the
+ * 4(n+1) or 8(n+1) of the rows (msufsort_amd/dist.py::forward_bwt_sharded). */
+int msufsort_hip_bwt_slice_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int64_t n, const void* d_sa_slice, int64_t lo, int64_t hi,
+                               int32_t index_bytes, uint8_t* d_row_bytes_out, int64_t* sentinel_row);
+
 /* ---- inverse BWT: replaces msufsort::reverse_burrows_wheeler_transform (cpp:1821-2096) ---- */
 int msufsort_hip_inverse_bwt(uint8_t* inout, int64_t n, int64_t sentinel_row,
                              const msufsort_hip_opts* opts);

@@ -259,6 +259,13 @@ class DeviceContext:
         _lib.check(f(self._h, self._ptr(d_text), n, self._ptr(d_sa), self._ptr(d_bwt), C.byref(s)), "bwt_from_sa")
         return int(s.value)
 
+    def bwt_slice(self, d_text, n: int, d_sa_slice, lo: int, hi: int, d_row_bytes, index_bytes=4) -> int:
+        """One byte per row of the finished slice rows [lo, hi): the byte in front of the suffix; returns the sentinel row if it
+        lies in the slice, else -1 (msufsort_hip_bwt_slice_dev; the sharded forward transform of msufsort_amd/dist.py)."""
+        s = C.c_int64(0)
+        _lib.check(self._L.msufsort_hip_bwt_slice_dev(self._h, self._ptr(d_text), n, self._ptr(d_sa_slice), lo, hi, index_bytes, self._ptr(d_row_bytes), C.byref(s)), "bwt_slice")
+        return int(s.value)
+
     def forward_bwt(self, d_text, n: int, d_bwt, *, two_stage=0) -> int:
         s = C.c_int64(0)
         o = _opts(self.device, two_stage=two_stage)

@@ -23,6 +23,20 @@ __global__ __launch_bounds__(256) void k_bwt_gather(const u8* __restrict__ text,
     }
 }
 
+// Sharded forward transform ("for BWT gather n/G-byte slices instead"): the byte in front of every suffix of ONE
+// finished slice, one byte per row (the sentinel row - the row of suffix 0 - gets a placeholder and is reported; the caller
+// closes the hole once every rank knows where it is).  rows = hi - lo, row_lo = lo.
+template <bool W>
+__global__ __launch_bounds__(256) void k_bwt_slice(const u8* __restrict__ text, const typename Wd<W>::sa_t* __restrict__ sa_slice, u64 rows, u64 row_lo,
+                                                   unsigned long long* __restrict__ sent, u8* __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < rows; i += (u64)gridDim.x * 256u) {
+        const u64 v = sa_slice[i];
+        out[i] = v ? text[v - 1] : (u8)0;
+        if (v == 0) *sent = row_lo + i;
+    }
+}
+
 // Two-stage builds (induce_kernels.hip.h) leave the character in front of every suffix next to its row: the BWT is a
 // sequential pass over those instead of n random text reads - how the reference's own forward transform takes its output
 // out of the second stage (cpp:1061-1492) rather than from a finished suffix array.

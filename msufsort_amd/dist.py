@@ -93,35 +93,99 @@ def wait_all(works, full=None):
         torch.cuda.synchronize(full.device)
 
 
+def _window_rows(default: int) -> int:
+    """Rows per exchange window (rank updates, group heads).  MSUFSORT_DIST_WINDOW shrinks it: a test hook that makes small
+    inputs walk several windows."""
+    import os
+    v = int(os.environ.get("MSUFSORT_DIST_WINDOW", "0") or 0)
+    return max(1, v) if v > 0 else default
+
+
 class ShardState:
-    """Per-rank buffers of the distributed prefix doubling (allocated on first use, reused by later builds)."""
+    """Per-rank buffers of the distributed prefix doubling (allocated on first use, reused by later builds).
+    Sizes for n = 2^33 over 8 ranks (BASELINE config 5; rows_max = 2^30): rank replica 8(n+2) = 64 GiB, grp_prev 4 GiB,
+    update windows 0.5 + 4 GiB, group-head windows 0.25 + 2 GiB (DESIGN.md section 3.7 has the whole budget)."""
 
     def __init__(self):
         self.isa = None
         self.grp_prev = None
         self.upd_local = None
         self.upd_all = None
+        self.grp_mine = None
+        self.grp_all = None
         self.stats = {}
+
+    @staticmethod
+    def bytes_needed(n, rows_max, world, index_bytes):
+        """What ensure() allocates (bench.py's memory check)."""
+        e = 2 if index_bytes == 8 else 1
+        win = max(1, min(rows_max, _window_rows(1 << 25)))
+        gwin = max(1, min(rows_max, _window_rows(1 << 26)))
+        return (n + 2) * index_bytes + max(rows_max, 1) * 4 + win * e * 8 * (world + 1) + gwin * 4 * (world + 1)
 
     def ensure(self, n, rows_max, world, index_bytes, device):
         import torch
         dt = torch.int64 if index_bytes == 8 else torch.int32
         if self.isa is None or self.isa.numel() < n + 2 or self.isa.dtype != dt:
+            self.isa = None                      # (drop the old replica before the new one is allocated)
             self.isa = torch.empty(n + 2, dtype=dt, device=device)
         if self.grp_prev is None or self.grp_prev.numel() < rows_max:
             self.grp_prev = torch.empty(max(rows_max, 1), dtype=torch.int32, device=device)
+        # one update = ONE 64-bit word for int32 rows (new_row << 32 | suffix), TWO for int64 rows ({suffix, new_row})
         e = 2 if index_bytes == 8 else 1
-        self.win = max(1, min(rows_max, 1 << 25))
+        self.win = max(1, min(rows_max, _window_rows(1 << 25)))
         if self.upd_local is None or self.upd_local.numel() < self.win * e:
             self.upd_local = torch.empty(self.win * e, dtype=torch.int64, device=device)
         if self.upd_all is None or self.upd_all.numel() < self.win * e * world:
             self.upd_all = torch.empty(self.win * e * world, dtype=torch.int64, device=device)
+        self.gwin = max(1, min(rows_max, _window_rows(1 << 26)))
+        if self.grp_all is None or self.grp_all.numel() < self.gwin * world:
+            self.grp_all = torch.empty(self.gwin * world, dtype=torch.int32, device=device)
 
 
-def _distributed_doubling(ctx, n, d_sa_full, d_grp_full, bounds, rank, world, dist, depth, index_bytes, state, verbose=0):
+def update_offsets(counts, index_bytes):
+    """Element offsets (int64 words) of every rank's updates inside one exchange window: counts[g] updates of rank g, one word
+    each for int32 rows, two for int64 rows.  Returns (pre, e): rank g's updates occupy words pre[g] .. pre[g + 1]."""
+    e = 2 if index_bytes == 8 else 1
+    pre = [0]
+    for x in counts:
+        pre.append(pre[-1] + int(x) * e)
+    return pre, e
+
+
+def _replicate_ranks(ctx, d_sa_full, d_grp, bounds, rank, world, dist, state, index_bytes):
+    """Builds this rank's replica of the rank array from the gathered provisional rows and the group heads of EVERY slice.
+    The group heads (uint32, relative to their slice) stay distributed: they travel in windows of `gwin` rows per rank - one
+    all-gatherv per window - instead of as one 4(n+1)-byte array per GPU (32 GiB at n = 2^33)."""
+    lo, hi = bounds[rank], bounds[rank + 1]
+    rows = [bounds[g + 1] - bounds[g] for g in range(world)]
+    W = state.gwin
+    stage = state.grp_all
+    for w0 in range(0, max(rows), W):
+        cnt = [max(0, min(W, r - w0)) for r in rows]
+        pre = [0]
+        for x in cnt:
+            pre.append(pre[-1] + x)
+        if cnt[rank]:
+            stage[pre[rank]:pre[rank + 1]] = d_grp[w0:w0 + cnt[rank]]
+        if world > 1:
+            if stage.is_cuda:
+                import torch
+                torch.cuda.current_stream(stage.device).synchronize()
+            allgatherv_slices(stage, pre, dist)
+        for g in range(world):
+            if cnt[g]:
+                r0 = bounds[g] + w0
+                # (group heads are relative to their SLICE: the base row is the slice's first row, whatever the window)
+                ctx.isa_from_slice(d_sa_full[r0:r0 + cnt[g]], stage[pre[g]:pre[g + 1]], bounds[g], bounds[g] + cnt[g], state.isa, index_bytes)
+
+
+def _distributed_doubling(ctx, n, d_sa_full, d_grp, bounds, rank, world, dist, depth, index_bytes, state, verbose=0):
     """Prefix doubling over the shards (include/msufsort_hip.h, 'Distributed prefix doubling'): every rank sorts only the
     tie groups of its own slice; the rank array is replicated and refreshed once per step with ONE all-gatherv of the
-    (suffix, new head row) updates of all ranks.  Starts from gathered provisional rows + group heads."""
+    (suffix, new head row) updates of all ranks.  Starts from gathered provisional rows (d_sa_full, all slices) and THIS rank's
+    group heads (d_grp: one uint32 per row of my slice, relative to the slice).  index_bytes = 8: int64 rows and ranks, 16-byte
+    updates (BASELINE config 5; the reference's int32 index with two flag bits stops at 2^30, msufsort.h:47, 84-93)."""
     import time
 
     import torch
@@ -129,15 +193,13 @@ def _distributed_doubling(ctx, n, d_sa_full, d_grp_full, bounds, rank, world, di
     lo, hi = bounds[rank], bounds[rank + 1]
     rows_max = max(bounds[g + 1] - bounds[g] for g in range(world))
     state.ensure(n, rows_max, world, index_bytes, dev)
-    isa, e = state.isa, (2 if index_bytes == 8 else 1)
+    isa = state.isa
     one = torch.empty(1, dtype=d_sa_full.dtype, device=dev)
     sl = d_sa_full[lo:hi] if hi > lo else one
-    gl = d_grp_full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
+    gl = d_grp[:hi - lo] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
     gp = state.grp_prev
-    for g in range(world):
-        if bounds[g + 1] > bounds[g]:
-            ctx.isa_from_slice(d_sa_full[bounds[g]:bounds[g + 1]], d_grp_full[bounds[g]:bounds[g + 1]], bounds[g], bounds[g + 1], isa, index_bytes)
-    st = {"doubling_steps": 0, "sort_ms": 0.0, "exchange_ms": 0.0, "updates": 0, "depth": depth}
+    _replicate_ranks(ctx, d_sa_full, d_grp, bounds, rank, world, dist, state, index_bytes)
+    st = {"doubling_steps": 0, "sort_ms": 0.0, "exchange_ms": 0.0, "updates": 0, "depth": depth, "index_bytes": index_bytes, "windows": 0}
     win = state.win
     h = depth
     live = hi > lo
@@ -164,10 +226,7 @@ def _distributed_doubling(ctx, n, d_sa_full, d_grp_full, bounds, rank, world, di
             counts[rank] = cnt
             if world > 1:
                 dist.all_reduce(counts)
-            cl = [int(x) for x in counts.tolist()]
-            pre = [0]
-            for x in cl:
-                pre.append(pre[-1] + x * e)
+            pre, e = update_offsets(counts.tolist(), index_bytes)
             if pre[-1]:
                 if cnt:
                     state.upd_all[pre[rank]:pre[rank + 1]] = state.upd_local[:cnt * e]
@@ -178,6 +237,7 @@ def _distributed_doubling(ctx, n, d_sa_full, d_grp_full, bounds, rank, world, di
                 st["exchange_ms"] += (time.perf_counter() - t0) * 1e3
                 ctx.apply_updates(state.upd_all, pre[-1] // e, isa, index_bytes)
                 st["updates"] += pre[-1] // e
+            st["windows"] += 1
         tt = torch.tensor([tied_local], dtype=torch.int64, device=dev)
         if world > 1:
             dist.all_reduce(tt)
@@ -225,16 +285,21 @@ def build_sa_two_stage_sharded(ctx, d_text, n: int, d_sa_full, d_bstar, rank: in
     return r == 0
 
 
-def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist, bounds=None, text_rounds: int = 8,
-                     d_grp_full=None, overlap=False, index_bytes: int = 4, state=None, verbose: int = 0):
+def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist, bounds=None, text_rounds: int = 0,
+                     d_grp=None, overlap=False, index_bytes: int = 4, state=None, verbose: int = 0, gather_rows: bool = True):
     """One step of the sharded build on this rank: sort my key range into my slice, all-gatherv the slices.
 
-    Deep ties (long repeats) cannot be finished by key gathers.  With `d_grp_full` (int32 view of uint32, n+1) every rank
-    also publishes the tie groups of its slice; if any rank stopped with unresolved groups the provisional rows and the
-    group heads are gathered once, every rank builds its replica of the rank array, and the ranks run the DISTRIBUTED
-    prefix doubling: each sorts only its own groups, one all-gatherv of rank updates per step.  The final slices are
-    gathered at the end.  Without `d_grp_full` such inputs raise (MSUFSORT_HIP_ERR_UNSUPPORTED).
-    index_bytes = 8: wide engine (int64 rows; any n up to 2^40 - 2).
+    Deep ties (long repeats) cannot be finished by key gathers.  With `d_grp` (int32 view of uint32, at least as many entries
+    as my slice has rows - NOT the whole array) every rank also keeps the tie groups of its slice; if any rank stopped with
+    unresolved groups the provisional rows are gathered once, the group heads travel in windows, every rank builds its replica
+    of the rank array, and the ranks run the DISTRIBUTED prefix doubling: each sorts only its own groups, one all-gatherv of
+    rank updates per step.  The final slices are gathered at the end.  Without `d_grp` such inputs raise
+    (MSUFSORT_HIP_ERR_UNSUPPORTED).
+    index_bytes = 8: wide engine (int64 rows; any n up to 2^40 - 2; needs d_grp) - BASELINE config 5.
+    text_rounds: key-gather rounds before the shards hand over to the doubling (0: 8, wide engine 3 - what the single-process
+    driver msufsort_hip_make_sa_multi uses).
+    gather_rows=False: the rows stay distributed (every rank's slice d_sa_full[bounds[rank]:bounds[rank+1]] is final on return;
+    the other slices hold provisional rows or nothing) - for consumers that exchange something smaller, like forward_bwt_sharded.
 
     overlap=True: returns the pending exchange handles instead of waiting, so the caller can start the next build
     (into ANOTHER output buffer) while the slices travel; finish with `wait_all(works, d_sa_full)`.  If the build
@@ -242,17 +307,22 @@ def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist
     import torch
     if bounds is None:
         bounds = ctx.shard_bounds(d_text, n, world)
+    if text_rounds <= 0:
+        text_rounds = 3 if index_bytes == 8 else 8
     lo, hi = bounds[rank], bounds[rank + 1]
     dev = d_sa_full.device
     sl = d_sa_full[lo:hi] if hi > lo else torch.empty(1, dtype=d_sa_full.dtype, device=dev)
-    if d_grp_full is None:
-        assert index_bytes == 4
+    if d_grp is None:
+        if index_bytes != 4:
+            raise ValueError("int64 rows run the wide engine, which always publishes its tie groups: pass d_grp")
         ctx.make_sa_shard(d_text, n, sl, max(hi - lo, 1), rank, world, text_rounds=text_rounds)
-        if world > 1:
+        if world > 1 and gather_rows:
             works = allgatherv_slices(d_sa_full, bounds, dist, wait=not overlap)
             return works if overlap else []
         return []
-    gl = d_grp_full[lo:hi] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
+    if d_grp.numel() < max(hi - lo, 1):
+        raise ValueError(f"d_grp holds {d_grp.numel()} group heads, my slice has {hi - lo} rows")
+    gl = d_grp[:hi - lo] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
     _, _, unresolved, depth = ctx.make_sa_shard_groups(d_text, n, sl, gl, max(hi - lo, 1), rank, world, text_rounds=text_rounds,
                                                        index_bytes=index_bytes, verbose=verbose)
     # every unresolved rank stopped at the same depth (same number of rounds, same symbols per key): check it instead of
@@ -262,22 +332,72 @@ def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist
     works = []
     if world > 1:
         w = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)       # rides along with the slice exchange
-        works = allgatherv_slices(d_sa_full, bounds, dist, wait=False)
+        if gather_rows:
+            works = allgatherv_slices(d_sa_full, bounds, dist, wait=False)
         w.wait()
     dmax, dmin = int(flag[0].item()), -int(flag[1].item())
     if dmax > 0:
         if dmin != dmax:
             raise _lib.MsufsortHipError(f"shards stopped their key rounds at different depths ({dmin} .. {dmax})")
+        if world > 1 and not gather_rows:
+            works = allgatherv_slices(d_sa_full, bounds, dist, wait=False)      # the doubling needs everybody's provisional rows
         wait_all(works, d_sa_full)
-        if world > 1:
-            allgatherv_slices(d_grp_full, bounds, dist)
         if state is None:
             state = ShardState()
-        _distributed_doubling(ctx, n, d_sa_full, d_grp_full, bounds, rank, world, dist, dmax, index_bytes, state, verbose)
-        if world > 1:
+        _distributed_doubling(ctx, n, d_sa_full, d_grp, bounds, rank, world, dist, dmax, index_bytes, state, verbose)
+        if world > 1 and gather_rows:
             allgatherv_slices(d_sa_full, bounds, dist)          # the final rows
         return []
     if overlap:
         return works
     wait_all(works, d_sa_full)
     return []
+
+
+def bwt_slice_bounds(bounds, sentinel_row: int):
+    """Where every rank's BWT bytes go: row r of the suffix array contributes byte r - (r > sentinel_row) of the n-byte transform
+    (the sentinel row - the row of suffix 0 - is removed, reference msufsort.cpp:1811-1815), so the slice of rows
+    [bounds[g], bounds[g+1]) becomes the bytes [out[g], out[g+1])."""
+    return [b - (1 if b > sentinel_row else 0) for b in bounds]
+
+
+def forward_bwt_sharded(ctx, d_text, n: int, d_sa_full, bounds, rank: int, world: int, dist, d_bwt_out, d_row_bytes, index_bytes: int = 4, stats=None):
+    """Forward BWT of a sharded build WITHOUT gathering the rows ("for BWT gather n/G-byte slices
+    instead"; reference semantics msufsort.cpp:1771-1817: n bytes, sentinel row removed and returned).  My slice of d_sa_full
+    must be final (build_sa_sharded(..., gather_rows=False)).  Every rank gathers the byte in front of each suffix of ITS rows
+    (msufsort_hip_bwt_slice_dev), the ranks agree on the sentinel row (one all-reduce), every rank moves its bytes to their final
+    positions in d_bwt_out (n bytes) and ONE all-gatherv of the byte slices completes the transform on every rank: n(G-1)/G bytes
+    arrive per GPU instead of 4(n+1)(G-1)/G.  d_row_bytes: uint8 scratch of at least my slice's rows.  Returns the sentinel row."""
+    import time
+
+    import torch
+    dev = d_bwt_out.device
+    lo, hi = bounds[rank], bounds[rank + 1]
+    s_local = -1
+    if hi > lo:
+        s_local = ctx.bwt_slice(d_text, n, d_sa_full[lo:hi], lo, hi, d_row_bytes, index_bytes)
+    t0 = time.perf_counter()
+    s = torch.tensor([s_local], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(s, op=dist.ReduceOp.MAX)
+    sent = int(s.item())
+    if not (1 <= sent <= n):
+        raise _lib.MsufsortHipError(f"sharded forward BWT: no slice holds the row of suffix 0 (got {sent})")
+    out = bwt_slice_bounds(bounds, sent)
+    if hi > lo:
+        if lo <= sent < hi:          # my slice holds the sentinel row: close the hole
+            k = sent - lo
+            if k:
+                d_bwt_out[out[rank]:out[rank] + k] = d_row_bytes[:k]
+            if hi - sent - 1 > 0:
+                d_bwt_out[sent:sent + (hi - sent - 1)] = d_row_bytes[k + 1:hi - lo]
+        else:
+            d_bwt_out[out[rank]:out[rank + 1]] = d_row_bytes[:hi - lo]
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+    if world > 1:
+        allgatherv_slices(d_bwt_out, out, dist)
+    if stats is not None:
+        stats["bwt_exchange_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        stats["bwt_bytes_received"] = int(n - (out[rank + 1] - out[rank]))
+    return sent

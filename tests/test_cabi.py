@@ -181,3 +181,22 @@ def test_dropin_header_keeps_the_reference_includes():
     hdr = open(os.path.join(ROOT, "include", "library", "msufsort", "msufsort.h")).read()
     for inc in ("<vector>", "<stdint.h>", "<atomic>", "<thread>", "<memory>", "<array>", "<functional>"):          # reference msufsort.h:30-36
         assert "#include " + inc in hdr, inc
+
+
+def test_bench_labels_and_budget():
+    """bench.py's labels must not claim what the run was not (round-4 review): the headline string only for the headline input,
+    `rccl_ranks` only for an RCCL process group; and the per-rank HBM budget of BASELINE config 5 (n = 2^33 over 8 GPUs, int64
+    rows) fits an MI355X while the same input on one rank's budget does not."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.metric_label("random", ["sa"], (1 << 30) - 1) == "MB/s input for SA build on 1 GiB random bytes"
+    assert "1 GiB" not in bench.metric_label("random", ["sa"], 1 << 28) and "n=268435456" in bench.metric_label("random", ["sa"], 1 << 28)
+    assert bench.metric_label("text", ["sa", "fbwt"], 1000) == "MB/s input for sa+fbwt on text (n=1000)"
+    assert bench.rccl_ranks_of("nccl", 8) == 8 and bench.rccl_ranks_of("gloo", 8) is None
+    n = 1 << 33
+    b8 = bench.multi_gpu_budget(n, 8, 8, (n >> 3) + (n >> 8), False, False, False)
+    assert 200 << 30 < b8["total"] < 250 << 30, b8          # DESIGN 3.7: ~222 GiB of the 288 GB (268 GiB) of one MI355X
+    assert b8["rows"] == (n + 1) * 8 and b8["text"] == n + 64
+    b2 = bench.multi_gpu_budget(n, 2, 8, n >> 1, False, False, False)
+    assert b2["total"] > 288e9                               # two ranks cannot hold it: bench.py refuses with the budget in the message

@@ -106,3 +106,159 @@ def test_allgatherv_with_empty_slices_gloo(world, tmp_path):
     mp.spawn(_worker_empty, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"e{r}").read() == "ok"
+
+
+# ------------------------------------------------------------------------------------------------
+# The multi-process driver of msufsort_amd/dist.py (sharded build -> distributed prefix doubling -> final gather, and the
+# sharded forward BWT) with int32 AND int64 rows, on CPU tensors over gloo.  The per-shard device calls are stood in for by a
+# small numpy model of the C-ABI pieces (same arguments, same update layout: ONE 64-bit word per update for int32 rows -
+# new_row << 32 | suffix - TWO for int64 rows - {suffix, new_row}; include/msufsort_hip.h "Distributed prefix doubling").
+# What this pins is the PYTHON side: slice-sized group buffers, window walking, update offsets (`pre`, e = 2), the windowed
+# replica build, byte-slice bounds of the BWT.  The HIP kernels behind the same calls are covered by tests/test_gpu_dist.py.
+# ------------------------------------------------------------------------------------------------
+class _ModelEngine:
+    def __init__(self, t, want, cuts, rows, depth):
+        self.t, self.want, self.cuts, self.rows, self.depth = t, want, cuts, rows, depth
+        self.pad = np.concatenate([t, np.zeros(depth + 8, np.uint8)])
+        self.refine_ms = 0.0
+
+    class _Tm:
+        refine_ms = 0.0
+
+    def timings(self):
+        return self._Tm()
+
+    def shard_bounds(self, d_text, n, world):
+        return list(self.rows)
+
+    def make_sa_shard_groups(self, d_text, n, sl, gl, capacity, shard, n_shards, *, verbose=0, text_rounds=0, index_bytes=4):
+        lo, hi = self.rows[shard], self.rows[shard + 1]
+        assert sl.dtype == (__import__("torch").int64 if index_bytes == 8 else __import__("torch").int32) and capacity >= hi - lo
+        final = self.want[lo:hi].astype(np.int64)
+        # provisional order: by the first `depth` bytes only (zero padded), ties in DESCENDING text position (anything but sorted)
+        keys = np.stack([self.pad[np.minimum(final + k, len(self.pad) - 1)] for k in range(self.depth)], axis=1)
+        keys[final == n] = 0
+        order = np.lexsort([-final] + [keys[:, k] for k in range(self.depth - 1, -1, -1)])
+        prov, pk = final[order], keys[order]
+        new_grp = np.ones(hi - lo, bool)
+        new_grp[1:] = (pk[1:] != pk[:-1]).any(axis=1)
+        if lo == 0:
+            new_grp[:2] = True           # row 0 (the empty suffix) is final by construction
+        heads = np.maximum.accumulate(np.where(new_grp, np.arange(hi - lo), 0))
+        sl.numpy()[:hi - lo] = prov
+        gl.numpy()[:hi - lo] = heads
+        unresolved = bool((np.bincount(heads) > 1).any())
+        return lo, hi, unresolved, self.depth if unresolved else 0
+
+    def isa_from_slice(self, sa_slice, grp_slice, lo, hi, isa, index_bytes=4):
+        isa.numpy()[sa_slice.numpy()[:hi - lo]] = lo + grp_slice.numpy()[:hi - lo].astype(np.int64)
+
+    def double_sort(self, n, sl, gl, gp, lo, hi, isa, h, index_bytes=4, verbose=0):
+        sa, grp, prev, rank = sl.numpy(), gl.numpy(), gp.numpy(), isa.numpy()
+        rows = hi - lo
+        prev[:rows] = grp[:rows]
+        sizes = np.bincount(grp[:rows], minlength=rows)
+        tied = 0
+        for head in np.nonzero(sizes > 1)[0]:
+            tied += 1
+            seg = sa[head:head + sizes[head]].astype(np.int64)
+            key = np.where(seg + h <= n, rank[np.minimum(seg + h, n)], 0)
+            o = np.argsort(key, kind="stable")
+            seg, key = seg[o], key[o]
+            sa[head:head + sizes[head]] = seg
+            nh = np.ones(len(seg), bool)
+            nh[1:] = key[1:] != key[:-1]
+            grp[head:head + sizes[head]] = head + np.maximum.accumulate(np.where(nh, np.arange(len(seg)), 0))
+        return tied, rows
+
+    def emit_updates(self, sl, gl, gp, lo, hi, i0, i1, items_total, d_updates, capacity, index_bytes=4):
+        sa, grp, prev, out = sl.numpy(), gl.numpy(), gp.numpy(), d_updates.numpy()
+        rows = hi - lo
+        r = np.arange(i0, i1)
+        chg = r[grp[r] != prev[r]]
+        assert len(chg) <= capacity
+        if index_bytes == 8:
+            out[0:2 * len(chg):2] = sa[chg]
+            out[1:2 * len(chg):2] = lo + grp[chg].astype(np.int64)
+        else:
+            out[:len(chg)] = ((lo + grp[chg].astype(np.int64)) << 32) | sa[chg].astype(np.int64)
+        sizes = np.bincount(grp[:rows], minlength=rows)
+        return len(chg), int((sizes[grp[r]] > 1).sum())
+
+    def apply_updates(self, d_updates, count, isa, index_bytes=4):
+        u, rank = d_updates.numpy(), isa.numpy()
+        if index_bytes == 8:
+            rank[u[0:2 * count:2]] = u[1:2 * count:2]
+        else:
+            rank[u[:count] & 0xFFFFFFFF] = u[:count] >> 32
+
+    def bwt_slice(self, d_text, n, d_sa_slice, lo, hi, d_row_bytes, index_bytes=4):
+        sa = d_sa_slice.numpy()[:hi - lo].astype(np.int64)
+        d_row_bytes.numpy()[:hi - lo] = np.where(sa > 0, self.t[np.maximum(sa - 1, 0)], 0)
+        z = np.nonzero(sa == 0)[0]
+        return int(lo + z[0]) if len(z) else -1
+
+
+def _worker_doubling(rank, world, port, tmp, index_bytes):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MSUFSORT_DIST_WINDOW="700")          # several update / group-head windows per step on a small input
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    from msufsort_amd import dist as D
+    from msufsort_amd import gen
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t = gen.dna_tandem_bytes(24000, 9)
+        n = t.size
+        want = oracle.make_suffix_array(t)
+        wb, ws = oracle.forward_bwt(t)
+        cuts, rows = D.plan_cuts(_bstart(t), n, 0, world)
+        eng = _ModelEngine(t, want, cuts, rows, depth=6)
+        dt = torch.int64 if index_bytes == 8 else torch.int32
+        full = torch.full((n + 1,), -7, dtype=dt)
+        rows_max = max(rows[g + 1] - rows[g] for g in range(world))
+        d_grp = torch.zeros(rows_max, dtype=torch.int32)          # slice sized: NOT n + 1
+        state = D.ShardState()
+        D.build_sa_sharded(eng, None, n, full, rank, world, dist, rows, d_grp=d_grp, index_bytes=index_bytes, state=state)
+        ok = bool((full.numpy() == want).all()) and state.stats["doubling_steps"] >= 2 and state.stats["updates"] > 0
+        ok = ok and state.stats["windows"] > state.stats["doubling_steps"] and state.stats["index_bytes"] == index_bytes
+        # rows kept distributed + the sharded forward transform: n bytes exchanged instead of the rows
+        full2 = torch.full((n + 1,), -7, dtype=dt)
+        D.build_sa_sharded(eng, None, n, full2, rank, world, dist, rows, d_grp=d_grp, index_bytes=index_bytes, state=state, gather_rows=False)
+        lo, hi = rows[rank], rows[rank + 1]
+        ok = ok and bool((full2.numpy()[lo:hi] == want[lo:hi]).all())
+        bwt = torch.zeros(n, dtype=torch.uint8)
+        st = {}
+        sent = D.forward_bwt_sharded(eng, None, n, full2, rows, rank, world, dist, bwt, torch.zeros(rows_max, dtype=torch.uint8), index_bytes, stats=st)
+        ok = ok and sent == ws and bool((bwt.numpy() == wb).all()) and st["bwt_bytes_received"] == n - (D.bwt_slice_bounds(rows, ws)[rank + 1] - D.bwt_slice_bounds(rows, ws)[rank])
+        open(os.path.join(tmp, f"d{rank}"), "w").write("ok" if ok else f"bad {state.stats}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,index_bytes", [(2, 4), (2, 8), (3, 8), (4, 4)])
+def test_distributed_doubling_driver_gloo(world, index_bytes, tmp_path, oracle_mod):
+    """dist.build_sa_sharded -> _distributed_doubling -> forward_bwt_sharded with int32 and int64 rows (BASELINE config 5 is the
+    int64 flavour over 8 ranks): result == the oracle's suffix array and BWT on every rank."""
+    import torch.multiprocessing as mp
+    port = 29900 + os.getpid() % 1000 + 8 * world + index_bytes
+    mp.spawn(_worker_doubling, args=(world, port, str(tmp_path), index_bytes), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"d{r}").read() == "ok"
+
+
+def test_update_offsets_and_bwt_bounds():
+    """The two pieces of index arithmetic the ranks must agree on: word offsets of a window's updates (one word per update for
+    int32 rows, two for int64 rows) and the byte ranges of the BWT slices around the removed sentinel row."""
+    from msufsort_amd import dist as D
+    assert D.update_offsets([3, 0, 5], 4) == ([0, 3, 3, 8], 1)
+    assert D.update_offsets([3, 0, 5], 8) == ([0, 6, 6, 16], 2)
+    assert D.update_offsets([], 8) == ([0], 2)
+    # rows 0..10 (n = 10), sentinel row 4 inside the second slice: bytes 0..2 | 3..5 (row 4 dropped) | 6..9
+    assert D.bwt_slice_bounds([0, 3, 7, 11], 4) == [0, 3, 6, 10]
+    assert D.bwt_slice_bounds([0, 3, 7, 11], 3) == [0, 3, 6, 10]          # sentinel = first row of a slice
+    assert D.bwt_slice_bounds([0, 3, 7, 11], 10) == [0, 3, 7, 10]         # ... = last row of all
+    assert D.ShardState.bytes_needed(1 << 33, 1 << 30, 8, 8) < 80 << 30   # 64 GiB replica + windows (DESIGN 3.7)

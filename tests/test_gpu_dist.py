@@ -23,7 +23,9 @@ def test_bench_two_ranks_one_gpu():
     assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["valid"] is True and d["value"] > 0 and d["scaling"] == "strong"
-    assert d["config"]["rccl_ranks"] == 2 and d["latency_ms"] > 0 and d["exchange_ms"] >= 0
+    # (two ranks over gloo are not an RCCL communicator, and the line says so)
+    assert d["config"]["ranks"] == 2 and d["config"]["rccl_ranks"] is None and d["config"]["backend"] == "gloo" and d["latency_ms"] > 0 and d["exchange_ms"] >= 0
+    assert "1 GiB" not in d["metric"] and d["config"]["index"] == "int32"
     assert len(d["per_rank"]["sort_ms"]) == 2 and sum(d["per_rank"]["rows"]) == (1 << 24) + 1
     # `value` is the latency of complete builds (sort + exchange, nothing overlapped); the pipelined rate is a secondary field
     assert d["config"]["pipelined"] is False and d["pipelined"]["MBps"] > 0 and d["ms_per_step"] >= 0.5 * d["latency_ms"]
@@ -43,7 +45,7 @@ def test_bench_four_and_eight_ranks_one_gpu(world, workload):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[-1])
-    assert d["n_gpus"] == world and d["config"]["rccl_ranks"] == world and d["valid"] is True
+    assert d["n_gpus"] == world and d["config"]["ranks"] == world and d["valid"] is True
     rows = d["per_rank"]["rows"]
     assert len(rows) == world and sum(rows) == n + 1
     if workload in ("random", "dna"):
@@ -155,3 +157,52 @@ def test_bench_two_stage_sharded_text(world):
     d = json.loads(lines[-1])
     assert d["n_gpus"] == world and d["valid"] is True
     assert d["two_stage_sharded"]["two_stage_status"] == 0 and d["allgatherv_bytes_per_rank"] < 4 * n * 0.5
+
+
+def _bench(args, timeout=900, env_extra=None):
+    env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", **(env_extra or {}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *[str(a) for a in args]], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("world,workload,n", [(2, "dna_tandem", 3 << 20), (4, "dna_tandem", 1 << 22), (2, "random", 1 << 24), (4, "random", 1 << 23), (2, "text", 1 << 21), (8, "dna", 1 << 22)])
+def test_bench_int64_rows_multi_process(world, workload, n):
+    """BASELINE config 5 as it is written - int64 rows, one process per GPU, the wide engine's shards, the 16-byte-update
+    distributed doubling, the all-gatherv of 8-byte rows - at sizes the CPU checker finishes (`--index int64` forces what
+    n > 2^31 - 2 selects by itself): every row equal to the unmodified reference's (--check-reference) and accepted by the 64-bit
+    on-device checker.  dna_tandem: the shards stop unresolved, the doubling runs (small exchange windows: several per step)."""
+    d = _bench(["--gpus", world, "--steps", 1, "--warmup", 0, "--size", n, "--workload", workload, "--index", "int64", "--no-cpu", "--check-reference"],
+               env_extra={"MSUFSORT_DIST_WINDOW": "20000"} if workload == "dna_tandem" else None)
+    assert d["n_gpus"] == world and d["valid"] is True and d["config"]["index"] == "int64" and "reference" in d["valid_against"]
+    assert sum(d["per_rank"]["rows"]) == n + 1 and d["allgatherv_bytes_per_rank"] == int(8 * (n + 1) * (world - 1) / world)
+    if workload == "dna_tandem":
+        db = d["doubling"]
+        assert db["index_bytes"] == 8 and db["doubling_steps"] >= 2 and db["updates"] > 0 and db["windows"] > db["doubling_steps"]
+
+
+@pytest.mark.parametrize("world,workload,index", [(2, "random", "int32"), (4, "random", "int64"), (4, "dna_tandem", "int32"), (2, "dna_tandem", "int64"), (2, "text", "int32"), (4, "text", "int32")])
+def test_bench_sharded_forward_bwt(world, workload, index):
+    """The forward transform over several ranks with the BYTES exchanged instead of the rows (reference semantics
+    msufsort.cpp:1771-1817): bytes + sentinel row equal to the reference's, for sort-all shards (random), shards that need the
+    distributed doubling (dna_tandem) and the two-stage sharded text build (every rank already holds all rows: no exchange)."""
+    n = 1 << 22
+    extra = ["--two-stage", 1] if workload == "text" else []
+    d = _bench(["--gpus", world, "--steps", 1, "--warmup", 0, "--size", n, "--workload", workload, "--index", index, "--op", "sa,fbwt", "--no-cpu", "--check-reference", *extra])
+    assert d["valid"] is True and "BWT" in d["valid_against"] and d["ops_ms"]["fbwt"] > 0
+    fb = d["forward_bwt"]
+    assert 1 <= fb["sentinel_row"] <= n
+    if workload == "text":
+        assert d["two_stage_sharded"]["two_stage_status"] == 0 and "nothing beyond" in fb["exchanged"]
+    else:
+        assert fb["bwt_bytes_received"] <= n * (world - 1) / world * 1.3 + 2
+
+
+def test_bench_refuses_when_hbm_is_short():
+    """n = 2^33 with int64 rows needs ~220 GiB per rank at 8 ranks - and far more at 2: bench.py says what it needs and stops
+    before allocating (here: 2 ranks sharing the one GPU)."""
+    env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", str(1 << 33), "--workload", "dna", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    assert r.returncode != 0 and "GiB of HBM per GPU" in r.stderr and "rank replica" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
