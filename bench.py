@@ -76,9 +76,9 @@ def cpu_baseline(sample_bytes, seed, workload="random", op="sa", full_n=None, al
         # 192 or 256: profiles/r03_cpu_reference_threads.txt).  So: the whole sample with 16 and with 32 threads, the faster one
         # is the value; every hardware thread on a small sample under a watchdog, reported next to it.
         counts = sorted({max(1, min(16, ncpu)), max(1, min(32, ncpu))})
-        res = cpu_reference_runs(workload, seed, sample_bytes, [(c_, op) for c_ in counts], timeout_s=240)
+        res = cpu_reference_runs(workload, seed, sample_bytes, [(c_, op) for c_ in counts], timeout_s=420)
         if not res:
-            return {"error": "the reference did not finish within 240 s", "host_cpus": ncpu}
+            return {"error": "the reference did not finish within 420 s", "host_cpus": ncpu}
         best = max(res, key=lambda r: r["MB/s"])
         what = {"sa": "make_suffix_array", "ibwt": "reverse_burrows_wheeler_transform"}.get(op, "forward_burrows_wheeler_transform")
         part = "the whole input" if full_n == sample_bytes else f"first {sample_bytes} bytes of the same stream"
@@ -457,11 +457,11 @@ def config_lines(M, torch, ctx, dev, steps, no_cpu):
             "lcp_ms": round(lcp_ms, 3)}
     if not no_cpu:
         try:
-            cfg3["cpu_baseline"] = cpu_baseline(1 << 28, seed, "text", "fbwt", n)
+            cfg3["cpu_baseline"] = cpu_baseline(n, seed, "text", "fbwt", n)          # the WHOLE 2^30 - 1 text, like the GPU legs beside it (round-4 review)
         except Exception as e:  # noqa: BLE001
             cfg3["cpu_baseline"] = {"error": str(e)}
         try:       # the reference's inverse transform (cpp:1820-2103) on the same sample
-            cfg4["cpu_baseline"] = cpu_baseline(1 << 28, seed, "text", "ibwt", n)
+            cfg4["cpu_baseline"] = cpu_baseline(n, seed, "text", "ibwt", n)
         except Exception as e:  # noqa: BLE001
             cfg4["cpu_baseline"] = {"error": str(e)}
     del S

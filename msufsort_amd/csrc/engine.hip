@@ -15,6 +15,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -1641,6 +1642,11 @@ int msufsort_hip_ctx_trim(msufsort_hip_ctx* c)
     if (!c) return MSUFSORT_HIP_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    {   // the pinned ring of the host-pointer entry points (8 x 32 MiB + its copy threads) goes with the workspace; it is rebuilt on demand
+        std::lock_guard<std::mutex> lk(c->ring_mu);
+        std::lock_guard<std::mutex> use(c->ring_use);
+        delete c->ring; c->ring = nullptr;
+    }
     c->release_all();
     return MSUFSORT_HIP_OK;
 }
@@ -1679,7 +1685,10 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     if (two_stage > 0 || (two_stage == 0 && (u64)n >= (48ull << 20) && tail_values <= 128u)) {
         const int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, two_stage > 0, &hist_done, &why);
         if (r != MSUFSORT_HIP_UNRESOLVED) return r;
-        c->sink_rows = 0;          // (whatever left for the host already is rebuilt and sent again)
+        // whatever left for the host already is rebuilt and sent again - AFTER the stale copies have landed: the ring's copy
+        // threads do not finish in order, a late stale chunk must not overwrite a fresh one (round-4 advisor finding)
+        if (c->sink && c->sink_rows) c->sink->flush();
+        c->sink_rows = 0;
     }
     const int r = build_sa<false>(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), 0, z, 0, 1ull << 32, z, true, &o, hist_done);
     if (why) c->tm.fallbacks = 1 | ((int64_t)why << 8);      // an abandoned two-stage attempt: its device time is part of this build
@@ -1703,13 +1712,34 @@ int msufsort_hip_make_sa_two_stage_sharded_dev(msufsort_hip_ctx* c, uint8_t* d_t
     u64 z = 0;
     TRY(trailing_zeros(c, d_text, (u64)n, &z));
     c->sw.load();
+    // The contract: `exchange` runs ONCE on every rank - the ranks meet in its collective.  A rank that leaves the build before it
+    // got there (an allocation that failed, a decline before the B* sort, the capacity check) would leave the healthy ranks waiting
+    // in theirs (round-4 advisor finding), so the call is made on its behalf: status 1 = "declined" when the build handed the
+    // input back (every rank alike), 2 = "this rank failed" - and every rank that is told 2 returns an error instead of going on
+    // to collectives the failed rank will never join.
+    struct Once { msufsort_hip_exchange_fn fn; void* user; bool called; int agreed; };
+    Once once{exchange, user, false, 0};
+    auto relay = [](void* u, const int64_t* bounds, int32_t ns, int32_t my_status) -> int {
+        Once* o = static_cast<Once*>(u);
+        o->called = true;
+        o->agreed = o->fn(o->user, bounds, ns, my_status);
+        return o->agreed;
+    };
     TwoStageShards sh;
-    sh.n_shards = opts->n_shards; sh.shard = opts->shard; sh.d_sstar = d_bstar; sh.sstar_capacity = (u64)bstar_capacity; sh.exchange = exchange; sh.user = user;
+    sh.n_shards = opts->n_shards; sh.shard = opts->shard; sh.d_sstar = d_bstar; sh.sstar_capacity = (u64)bstar_capacity;
+    sh.exchange = exchange ? +relay : nullptr; sh.user = &once;
     msufsort_hip_opts o = *opts;
     o.n_shards = 1; o.shard = 0;
     bool hist_done = false;
     int why = 0;
-    const int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, opts->two_stage > 0, &hist_done, &why, &sh);
+    int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, opts->two_stage > 0, &hist_done, &why, &sh);
+    if (exchange && !once.called) {
+        std::vector<int64_t> none((size_t)opts->n_shards + 1, 0);
+        const std::string keep = g_last_error;
+        (void)relay(&once, none.data(), opts->n_shards, r < 0 ? 2 : 1);
+        if (r < 0) g_last_error = keep;
+    }
+    if (exchange && once.agreed >= 2 && r >= 0) { set_error("two-stage: a peer rank failed before the exchange of the sorted B* slices"); return MSUFSORT_HIP_ERR_INTERNAL; }
     if (r == MSUFSORT_HIP_UNRESOLVED) return why == IND_WHY_LOOKBACK ? MSUFSORT_HIP_TWO_STAGE_FAILED_LOCALLY : MSUFSORT_HIP_TWO_STAGE_DECLINED;
     return r;
 }

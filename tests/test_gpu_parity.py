@@ -1,11 +1,14 @@
 """GPU parity tests (pytest -m gpu): the HIP path, reached through the C-ABI, against the oracle,
 the committed golden vectors of the unmodified reference, and size-independent properties."""
+import os
+
 import numpy as np
 import pytest
 
 from msufsort_amd import gen
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -999,3 +1002,124 @@ def test_scatter0_tile_edges(M, oracle_mod, kind):
         if n in (16384, 16387, 32771):           # the wide engine's instance of the kernel (40-bit indices, 24 key bits per record)
             assert (M.make_suffix_array_i64(t, force_wide=True) == want).all(), (kind, n, "wide")
             assert (M.make_suffix_array_i64(t, force_wide=True, n_shards=3) == want).all(), (kind, n, "wide, 3 shards")
+
+
+PEER_CHILD = r"""
+import json, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import msufsort_amd as M
+from msufsort_amd import gen, _lib
+import oracle
+out = {}
+for kind, n in (("dna_tandem", 700000), ("text", (2 << 20) + 31), ("random", (1 << 21) + 5)):
+    t = gen.GENERATORS[kind](n, 41)
+    want = oracle.ref_make_suffix_array(t, 4) if oracle.have_reference() else oracle.make_suffix_array(t)
+    sa, tm = M.make_suffix_array_multi(t, [0, 0, 0], two_stage=1 if kind == "text" else 0, text_rounds=0 if kind == "text" else 1, timings=True)
+    out[kind] = {"ok": bool((sa == want).all()), "doubling": int(tm.doubling_rounds), "bstar": int(tm.bstar_suffixes)}
+out["last_error"] = _lib.lib().msufsort_hip_last_error().decode()
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("no_peer", ["0", "1"])
+def test_peer_copy_fallback(no_peer):
+    """Copies between the devices of msufsort_hip_make_sa_multi (rank replicas and rank updates of the distributed doubling, the
+    sorted-B* slices of a text): peer access is asked for and enabled per device pair, and where the platform refuses the bytes
+    are staged through pinned host memory.  A one-GPU box never meets a refusal, so MSUFSORT_HIP_NO_PEER=1 forces the staged
+    path (also between the GPU and itself): same rows either way, and the reason is left in msufsort_hip_last_error."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MSUFSORT_ALLOW_DUPLICATE_DEVICES="1", MSUFSORT_HIP_NO_PEER=no_peer)
+    r = subprocess.run([sys.executable, "-c", PEER_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["dna_tandem"]["ok"] and d["dna_tandem"]["doubling"] >= 1          # rank replicas + updates fetched from the "peers"
+    assert d["text"]["ok"] and d["text"]["bstar"] > 0                          # sorted-B* slices collected on the first device
+    assert d["random"]["ok"]
+    assert ("staged through pinned host memory" in d["last_error"]) == (no_peer == "1")
+
+
+def test_int64_rows_of_a_narrow_build_are_widened_on_the_device(M, oracle_mod):
+    """msufsort_hip_make_sa_multi(index_bytes = 8) below 2^31 - 1 bytes: the int32 slices are widened on the device and leave as
+    8-byte rows through the same streamed copies (round 4: a host-side std::vector<int32_t>(n + 1) and a serial loop).  Twice
+    the bytes over the same link: within ~2x the int32 call (generous bound: 3x + 50 ms), equal rows; the one-build path of a text too."""
+    import time
+    n = (96 << 20) + 7
+    t = gen.random_bytes(n, 51)
+    M.make_suffix_array_multi(t[: 1 << 20], [0])                                  # context, ring, first-call costs
+    best = {4: 1e9, 8: 1e9}
+    rows = {}
+    for _ in range(2):
+        for ib in (4, 8):
+            t0 = time.perf_counter()
+            rows[ib] = M.make_suffix_array_multi(t, [0], index_bytes=ib)
+            best[ib] = min(best[ib], time.perf_counter() - t0)
+    assert rows[8].dtype == np.int64 and (rows[8] == rows[4]).all() and int(rows[8][0]) == n
+    assert best[8] <= 3 * best[4] + 0.05, best
+    print(f"\nint32 rows {best[4] * 1e3:.1f} ms, int64 rows {best[8] * 1e3:.1f} ms (n = {n})")
+    t = gen.text_bytes((24 << 20) + 3, 52)
+    sa8 = M.make_suffix_array_multi(t, [0], index_bytes=8)
+    assert sa8.dtype == np.int64 and (sa8 == M.make_suffix_array(t)).all()
+
+
+def test_two_stage_exchange_is_called_once_whatever_happens(M):
+    """Contract of msufsort_hip_make_sa_two_stage_sharded_dev: `exchange` runs exactly ONCE on every rank - the ranks meet in its
+    collective, so a rank that leaves the build early must still turn up (round-4 advisor finding: a failed or declining rank
+    returned without it and its peers would have hung in theirs).  Declined before the B* sort (random bytes are not text):
+    status 1; a failure (B* buffer too small): status 2 and an error; the normal case: status 0 with real bounds."""
+    import torch
+    calls = []
+
+    def ex(bounds, status):
+        calls.append((list(bounds), status))
+        return status
+
+    ctx = M.DeviceContext(0)
+    n = 1 << 20
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    bstar = torch.empty(n // 2 + 2, dtype=torch.int32, device="cuda")
+    r = ctx.make_sa_two_stage_sharded(_dev(M, gen.random_bytes(n, 3)), n, sa, bstar, 0, 2, ex)           # default policy: random bytes decline
+    assert r == 1 and len(calls) == 1 and calls[0][1] == 1
+    calls.clear()
+    t = gen.text_bytes(n, 4)
+    with pytest.raises(M.MsufsortHipError):
+        ctx.make_sa_two_stage_sharded(_dev(M, t), n, sa, bstar[:16], 0, 2, ex, two_stage=1)              # 16 entries cannot hold the B* suffixes
+    assert len(calls) == 1 and calls[0][1] == 2
+    calls.clear()
+    r = ctx.make_sa_two_stage_sharded(_dev(M, t), n, sa, bstar, -1, 2, None, two_stage=1)                # logical shards: no exchange at all
+    assert r == 0 and not calls
+    # a peer that reports failure makes a healthy rank stop with an error instead of walking on to the next collective alone
+    with pytest.raises(M.MsufsortHipError, match="peer rank failed"):
+        ctx.make_sa_two_stage_sharded(_dev(M, t), n, sa, bstar, 0, 1, lambda b, s: 2, two_stage=1)
+
+
+def test_trim_releases_the_host_ring(M):
+    """msufsort_hip_ctx_trim gives the pinned ring of the host-pointer entry points (8 x 32 MiB + copy threads) back with the
+    workspace; the next large call rebuilds it."""
+    import ctypes as C
+    from msufsort_amd import _lib
+    from msufsort_amd.api import _opts
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.msufsort_hip_ctx_create(C.byref(h), 0, 0), "ctx")
+    n = (24 << 20) + 1
+    t = gen.random_bytes(n, 61)
+    sa = np.empty(n + 1, dtype=np.int32)
+    o = _opts()
+
+    def threads():
+        return len(os.listdir("/proc/self/task"))
+    base = threads()
+    _lib.check(L.msufsort_hip_make_sa_i32_ctx(h, t.ctypes.data, n, sa.ctypes.data, C.byref(o)), "sa")
+    with_ring = threads()
+    assert with_ring >= base + 8                      # the ring's copy threads
+    first = sa.copy()
+    _lib.check(L.msufsort_hip_ctx_trim(h), "trim")
+    assert threads() <= with_ring - 8
+    sa[:] = -1
+    _lib.check(L.msufsort_hip_make_sa_i32_ctx(h, t.ctypes.data, n, sa.ctypes.data, C.byref(o)), "sa again")
+    assert (sa == first).all()
+    L.msufsort_hip_ctx_destroy(h)
