@@ -93,6 +93,8 @@ struct Switches {
     int radix17 = 0;             // MSUFSORT_HIP_RADIX17: -1 never, 0 by size and spread (build_sa), 1 always, after the 16-bit histogram, 2 always, 17-bit
                                  // histogram first (1, 2: test hooks)
     int sync_debug = 0;          // MSUFSORT_HIP_SYNC_DEBUG
+    int key1 = 0;                // MSUFSORT_HIP_KEY1: -1 the first gather round always gathers; 0 small alphabets get its key from k_scatter0 when the caller has
+                                 // seen few byte values; 1 whenever the alphabet turns out small
     bool host_trace = false;     // MSUFSORT_HIP_HOST_TRACE: timeline of the host-pointer entry points on stderr
     void load()
     {
@@ -111,6 +113,7 @@ struct Switches {
         ind_grid = std::max(0, num("MSUFSORT_HIP_IND_GRID", 0));
         radix17 = num("MSUFSORT_HIP_RADIX17", 0);
         sync_debug = num("MSUFSORT_HIP_SYNC_DEBUG", 0);
+        key1 = num("MSUFSORT_HIP_KEY1", 0);
         host_trace = on("MSUFSORT_HIP_HOST_TRACE");
     }
 };
@@ -134,6 +137,10 @@ struct msufsort_hip_ctx {
     bool attrs_set = false;
     // workspace
     DevBuf rec[3], pool_rec[2], pool_hdr[2];
+    DevBuf rec_x[3], pool_x;                      // companions of the records (RecBufs::x): key of the first gather round, small alphabets only
+    bool plan_small_alphabet = false;             // what plan_shards saw in the host's copy of the histogram (kept for every shard of the plan)
+    bool hint_small_alphabet = false;             // set by the callers that have seen the byte values (tail sample, host histogram): build_sa then
+                                                  // lets k_scatter0 produce the companions if the alphabet really has at most 84 codes
     DevBuf lists[2][3], large_round[2], lvl[2], seg0;
     DevBuf alpha, seg0_base, stripe_sums, hist_partial, hist, hist_clip, bstart, child_start, child_cnt, cursor, cursor0, tile_start, trivial, seg_hist;
     DevBuf counters, isa, text_own, sa_own, aux0, aux1, aux2, aux3, doneB, doneC;
@@ -254,6 +261,8 @@ struct msufsort_hip_ctx {
     void release_all()
     {
         for (auto& b : rec) b.release();
+        for (auto& b : rec_x) b.release();
+        pool_x.release();
         for (auto& b : pool_rec) b.release();
         for (auto& b : pool_hdr) b.release();
         for (int s = 0; s < 2; ++s) { for (int c = 0; c < 3; ++c) lists[s][c].release(); large_round[s].release(); lvl[s].release(); }
@@ -274,6 +283,8 @@ struct msufsort_hip_ctx {
     {
         size_t b = 0;
         for (auto& x : rec) b += x.bytes;
+        for (auto& x : rec_x) b += x.bytes;
+        b += pool_x.bytes;
         for (auto& x : pool_rec) b += x.bytes;
         for (auto& x : pool_hdr) b += x.bytes;
         for (int s = 0; s < 2; ++s) { for (int k = 0; k < 3; ++k) b += lists[s][k].bytes; b += large_round[s].bytes + lvl[s].bytes; }
@@ -559,6 +570,11 @@ int plan_shards(msufsort_hip_ctx* c, const u8* d_text, u64 n, u64 z, int n_shard
     std::vector<u64> bs(65537);
     bs[0] = 0;
     for (u32 k = 0; k < 65536; ++k) bs[k + 1] = bs[k] + (W ? c->h_hist[k] : (u64)reinterpret_cast<const u32*>(c->h_hist)[k]);
+    {   // byte values in use (first bytes of the non-empty two-byte keys): the shard builds that follow take it as their hint
+        u32 nv = 0;
+        for (u32 b = 0; b < 256; ++b) nv += bs[(b + 1) * 256] != bs[b * 256];
+        c->plan_small_alphabet = nv <= 83;
+    }
     const bool refine = !c->sw.no_refine;
     const u64 tol = std::max<u64>(m / ((u64)n_shards * 16), 1);
     std::vector<u64> sp;             // prefix of the deeper histogram of key `sp_key`
@@ -618,6 +634,10 @@ struct Rounds {
     int verbose = 0;
     bool exact_sticky = false, fast_gave_up = false, force_retry = false, no_pack = false;
     bool safe_rank = false, bucket_sort_bits = true;      // (set from c->sw by init())
+    // key of the first gather round from the sequential pass: aux_cand = companion buffers are in place and
+    // k_scatter0 / the level-1 partition were given them; aux_on = the alphabet turned out small (<= 84 codes), the companions
+    // exist and round 0's kernels carry them; the records round 0 emits then arrive in round 1 WITH their keys
+    bool aux_cand = false, aux_on = false;
     void init(msufsort_hip_ctx* ctx, hipStream_t stream, u32* cnt)
     {
         c = ctx; st = stream; counters = cnt;
@@ -682,7 +702,8 @@ struct Rounds {
                            radix17 ? c->child_start17.template as<u32>() : c->child_start.template as<u32>(), radix17 ? c->child_cnt17.template as<u32>() : c->child_cnt.template as<u32>(),
                            (const u32*)nullptr, 1u, 0u, 2u, radix17 ? 23u : 24u, sa_local, (u32*)nullptr, (u32*)nullptr, (u32)MODE_TEXT,
                            c->pool_rec[cur].template as<u64>(), c->pool_hdr[cur].template as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), cap32(),
-                           make_lists(cur), c->lvl[0].template as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters, radix17 ? 9u : 8u);
+                           make_lists(cur), c->lvl[0].template as<Desc>(), c->large_cap, (u32)C_LVL0, (u32)C_LVLT0, counters, radix17 ? 9u : 8u,
+                           aux_cand ? c->pool_x.template as<u32>() : (u32*)nullptr);
         DBG("k_children L1");
         return c->read_counters();
     }
@@ -729,13 +750,17 @@ struct Rounds {
                 DBG("k_count");
                 hipLaunchKernelGGL(k_segscan, dim3(nl), dim3(256), 0, st, src_list, nl, c->seg_hist.template as<u32>(), c->child_start.template as<u32>(), c->cursor.template as<u32>(), c->trivial.template as<u32>());
                 DBG("k_segscan");
-                hipLaunchKernelGGL(k_partition<256>, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.template as<u32>(), shift,
+                const bool ax = round == 0 && aux_on;          // round 0 of a small alphabet: the records' companions move with them
+                if (ax) hipLaunchKernelGGL((k_partition<256, true>), dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.template as<u32>(), shift,
+                                           c->cursor.template as<u32>(), c->trivial.template as<u32>(), a[0], a[1], a[2], counters + C_ASIGMA);
+                else hipLaunchKernelGGL(k_partition<256>, dim3(cdiv(ntiles, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.template as<u32>(), shift,
                                    c->cursor.template as<u32>(), c->trivial.template as<u32>(), a[0], a[1], a[2]);
                 DBG("k_partition level");
                 hipLaunchKernelGGL(k_children<W>, dim3(nl), dim3(256), 0, st, bufs, src_list, nl, c->child_start.template as<u32>(), c->seg_hist.template as<u32>(),
                                    c->trivial.template as<u32>(), a[0], a[1], a[2], shift, sa_local, isa32, grp_out, mode,
                                    c->pool_rec[cur].template as<u64>(), c->pool_hdr[cur].template as<u64>(), (u32)(cur ? C_POOL1 : C_POOL0), cap32(),
-                                   make_lists(cur), c->lvl[lp].template as<Desc>(), c->large_cap, cnt_idx, til_idx, counters);
+                                   make_lists(cur), c->lvl[lp].template as<Desc>(), c->large_cap, cnt_idx, til_idx, counters, 8u,
+                                   ax ? c->pool_x.template as<u32>() : (u32*)nullptr);
                 DBG("k_children level");
                 TRY(c->read_counters());
                 src_list = c->lvl[lp].template as<Desc>();
@@ -749,7 +774,7 @@ struct Rounds {
                                            DESC_BUF(32, nb), (u32)(nxt ? C_SEG1 : C_SEG0), cap32(),
                                            c->large_round[nxt].template as<Desc>(), c->large_cap, (u32)((nxt ? C_LIST1 : C_LIST0) + 3), (u32)(nxt ? C_LTILES1 : C_LTILES0), counters);
                         hipLaunchKernelGGL(k_carry_copy<W>, dim3(ntiles), dim3(P1_THREADS), 0, st, bufs, src_list, nl, c->tile_start.template as<u32>(), c->trivial.template as<u32>(),
-                                           sa_local, isa32, grp_out, mode, bufs.p[nb], counters);
+                                           sa_local, isa32, grp_out, mode, bufs.p[nb], counters, ax ? 1u : 0u);
                         // what the carry reserved must survive a repeated sort attempt (see the retry below)
                         hipLaunchKernelGGL(k_copy_idx, dim3(1), dim3(64), 0, st, counters, (u32)C_CARRY, (u32)(nxt ? C_SEG1 : C_SEG0));
                         DBG("k_carry");
@@ -794,7 +819,8 @@ struct Rounds {
             nA = c->h_counters[base + 0]; nB = c->h_counters[base + 1]; nC = c->h_counters[base + 2];
             nP = c->h_counters[cur ? C_POOL1 : C_POOL0];
             const bool spread = keys_spread();
-            const bool use_fast = wants_fast();
+            const bool ax0 = round == 0 && aux_on;      // round 0 of a small alphabet: the sorts emit next round's records WITH their keys
+            const bool use_fast = wants_fast() && !ax0; // (... which only k_sort_mid / k_sort_tiny know how to do)
             // k_sort_bits (round 3) where the keys are spread like random bytes; k_sort_fast2 for the dense base-sigma keys of later
             // rounds (random DNA at depth 18: an eighth of the records of a segment tie - more than the dirty list of k_sort_bits
             // holds - and k_sort_fast2 sorts such segments in 2.4 ms per GiB where k_sort_mid takes 3.8) and on request
@@ -840,7 +866,9 @@ struct Rounds {
                         ids = c->doneC.template as<u32>();
                     }
                 }
-                k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
+                if (ax0) k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W, !W><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
+                    bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, emC, counters, ids, (u32)C_FBC, gather, code);
+                else k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
                     bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, emC, counters, ids, (u32)C_FBC, gather, code);
                 DBG("k_sort_mid C");
             }
@@ -874,17 +902,21 @@ struct Rounds {
                         ids = c->doneB.template as<u32>();
                     }
                 }
-                k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
+                if (ax0) k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W, !W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
+                    bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, emB, counters, ids, (u32)C_FBB, gather, code);
+                else k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
                     bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, emB, counters, ids, (u32)C_FBB, gather, code);
                 DBG("k_sort_mid B");
             }
-            if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
+            if (nA && ax0) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W, !W><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
+                        bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, (const u32*)nullptr, 0u, gather, code);
+            else if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
                         bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, (const u32*)nullptr, 0u, gather, code);
             DBG("k_sort_mid A");
             if (nP) hipLaunchKernelGGL(k_sort_tiny<W>, dim3(std::min<u32>(cdiv(nP, 256), 8192u)), dim3(256), 0, st, c->pool_rec[cur].template as<u64>(), c->pool_hdr[cur].template as<u64>(),
                                        (u32)(cur ? C_POOL1 : C_POOL0), sa_local, isa32, mode,
                                        em.pool_rec, em.pool_hdr, em.pool_cnt_idx, cap32(), em.pool_chunk, counters, grp_out, discard, gather, code,
-                                       (mode == MODE_TEXT && gather.text) ? deep_cap : 0u);
+                                       (mode == MODE_TEXT && gather.text) ? deep_cap : 0u, ax0 ? c->pool_x.template as<u32>() : (const u32*)nullptr);
             DBG("k_sort_tiny");
             if (round == 0) HIP_TRY(hipEventRecord(c->ev[4], st));
             TRY(c->read_counters(attempt == 0));
@@ -976,6 +1008,23 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     Rounds<W> R;
     R.init(c, st, counters);            // (incl. the test hooks: force_retry throws every round's first sort attempt away)
     R.klo = klo; R.khi = khi; R.verbose = verbose;
+    // Key of the first gather round from the sequential pass (narrow records): k_scatter0 holds the text of its
+    // tile anyway and writes, next to every record, the key the first gather round would fetch with a random text access per
+    // suffix.  Worth it where nearly every suffix is still tied after round 0: small alphabets (text, DNA) - whether this is one
+    // the caller has seen (byte values of a tail sample, or the host's histogram); the device decides for good (<= 84 codes).
+    const bool hint = c->hint_small_alphabet;
+    c->hint_small_alphabet = false;
+    if constexpr (!W) {
+        R.aux_cand = !R.no_pack && !c->sw.force_fast && !c->sw.no_fuse && c->sw.key1 >= 0 && (hint || c->sw.key1 > 0) && ms >= 4096;
+        if (R.aux_cand) {
+            // (12 bytes per suffix on top of the ~70 of the workspace; if they cannot be had the round simply gathers)
+            const size_t xb = (size_t)c->cap_m * 4;
+            if (c->rec_x[0].ensure(xb) != MSUFSORT_HIP_OK || c->rec_x[1].ensure(xb) != MSUFSORT_HIP_OK || c->pool_x.ensure(xb) != MSUFSORT_HIP_OK) {
+                R.aux_cand = false;
+                (void)hipGetLastError();
+            }
+        }
+    }
 
     // ---- round 0: 16-bit histogram, offsets, two 8-bit scatter levels ----
     // Random-like inputs whose two-byte buckets outgrow the largest LDS sort (uniform bytes from 1.15 GiB): 17 radix bits instead
@@ -1002,7 +1051,8 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     else if (!hist_done) TRY(run_hist<W>(c, d_text, m));
     HIP_TRY(hipEventRecord(c->ev[1], st));
     TRY(run_scan<W>(c, d_text, m, lo32, hi32, z, spec17));
-    R.bufs = RecBufs{{c->rec[0].as<u64>(), c->rec[1].as<u64>(), c->rec[2].as<u64>()}};
+    R.bufs = RecBufs{{c->rec[0].as<u64>(), c->rec[1].as<u64>(), c->rec[2].as<u64>()},
+                     {R.aux_cand ? c->rec_x[0].as<u32>() : nullptr, R.aux_cand ? c->rec_x[1].as<u32>() : nullptr, nullptr}};
     RecBufs& bufs = R.bufs;
     sa_t* sa_local = d_sa_rows + (1 + rank0 - slice_row_lo);
     R.sa_local = sa_local;
@@ -1037,7 +1087,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
             radix17 = true;
         }
     }
-    hipLaunchKernelGGL(k_scatter0<W>, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, m, lo32, hi32, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0], c->alpha.as<u8>(), counters, R.no_pack ? 0u : 1u, c->sel_bits);
+    hipLaunchKernelGGL(k_scatter0<W>, dim3(cdiv(cdiv(m, S0_TILE), 8 * (c->chunk_len / S0_TILE)) * 8 * (c->chunk_len / S0_TILE)), dim3(S0_THREADS), 0, st, d_text, m, lo32, hi32, c->chunk_len, c->cursor0.as<u32>(), bufs.p[0], c->alpha.as<u8>(), counters, R.no_pack ? 0u : 1u, c->sel_bits, bufs.x[0]);
     HIP_TRY(hipEventRecord(c->ev[2], st));
     DBG("k_scatter0");
     if (radix17 && !spec17) {
@@ -1050,6 +1100,9 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     if (radix17)
         hipLaunchKernelGGL(k_partition<512>, dim3(cdiv(cdiv(ms, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
                            c->tile_start.as<u32>(), 23u, c->cursor17.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u);
+    else if (R.aux_cand)      // (the kernel looks at the alphabet itself: the host has not seen it yet)
+        hipLaunchKernelGGL((k_partition<256, true>), dim3(cdiv(cdiv(ms, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
+                           c->tile_start.as<u32>(), 24u, c->cursor.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u, counters + C_ASIGMA);
     else
         hipLaunchKernelGGL(k_partition<256>, dim3(cdiv(cdiv(ms, P1_TILE) + 256, 4096) * 4096), dim3(P1_THREADS), 0, st, bufs, c->seg0.as<Desc>(), 256u,
                            c->tile_start.as<u32>(), 24u, c->cursor.as<u32>(), (const u32*)nullptr, 1u, 0u, 2u);
@@ -1062,6 +1115,11 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     ks.sigma = 256; ks.cpk = W ? 3u : 4u; ks.zlow = 0; ks.dig_shift = 0; ks.dig_mask = 0xffffffu;
 
     TRY(R.children_level1(radix17));
+    {   // the companions exist iff the alphabet is small (what k_scatter0 and the level-1 partition decided on the device)
+        const u32 sg = c->h_counters[C_ASIGMA];
+        R.aux_on = R.aux_cand && !radix17 && sg >= 2 && sg <= 84;
+        if (verbose && R.aux_cand) fprintf(stderr, "[msufsort_hip] key of the first gather round from the sequential pass: %s (%u codes)\n", R.aux_on ? "yes" : "no", sg);
+    }
     if ((u64)c->h_counters[C_MS] != ms && slice_rows) { set_error("slice bounds disagree with the histogram (%u suffixes on the device, %llu planned)", c->h_counters[C_MS], (unsigned long long)ms); return MSUFSORT_HIP_ERR_INTERNAL; }
 
     if (selected && auto_switch) text_rounds = 64;       // (late rounds of a two-stage build hold a handful of large tie groups: cheap)
@@ -1094,13 +1152,9 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
             const u32 b = c->h_counters[C_ABITS], sg = c->h_counters[C_ASIGMA];
             const bool packed0 = !R.no_pack && sg >= 2 && sg <= 84;
             if (W) depth = packed0 ? 2 + s0_symbols<W>(sg) : 4;
-            if (b >= 2 && sg >= 2 && !R.no_pack) {
-                u64 p = 1; u32 k = 0;
-                while (k < 16 && p * sg <= (1ull << (W ? 24 : 32))) { p *= sg; ++k; }       // sigma^k <= 2^(key bits)
-                if (k >= (W ? 4u : 5u)) {                                          // at least one symbol more than a plain window
-                    u32 bl = 0; while (bl < 32 && ((p - 1) >> bl) != 0) ++bl;     // bits of the largest key
-                    ks.sigma = sg; ks.cpk = k; ks.zlow = 32 - bl;
-                }
+            {   // (the same function k_scatter0 calls for the companion keys)
+                u32 k = 0, zl = 0;
+                if (!R.no_pack && key_packing<W>(sg, b, k, zl)) { ks.sigma = sg; ks.cpk = k; ks.zlow = zl; }
             }
             R.cpk = ks.cpk;
             if (verbose) fprintf(stderr, "[msufsort_hip] alphabet: %u codes (%u bits) -> %u symbols per key\n", sg, b, ks.cpk);
@@ -1168,7 +1222,10 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         const sa_t* isa_any = nullptr;
         if constexpr (!W) isa_any = R.isa32;
         R.round = round + 1;              // (wants_fast looks at the round that is about to run)
-        const bool fuse = R.mode == MODE_TEXT && !R.wants_fast() && !c->sw.no_fuse;
+        // round 0 of a small alphabet emitted its still-tied records WITH the key of this round (k_scatter0 read it off the text
+        // it was holding): no gather, neither fused into the sorts nor as a k_refill pass
+        const bool keyed = round == 0 && R.aux_on && R.mode == MODE_TEXT;
+        const bool fuse = R.mode == MODE_TEXT && !keyed && !R.wants_fast() && !c->sw.no_fuse;
         R.round = round;
         R.code = c->alpha.as<u8>();
         R.gather = GatherSpec{fuse ? d_text : nullptr, n, ks};
@@ -1179,14 +1236,14 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
                 R.chain_resolve(cur, cl, sa_local, R.isa32, (const u32*)nullptr, n, depth);
             }
         }
-        if (!fuse && actP) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
+        if (!fuse && !keyed && actP) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actP, 1024), 65536u)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), counters, curP,
                                      d_text, isa_any, n, R.mode, c->alpha.as<u8>(), ks);
-        if (!fuse && actS) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actS, 1024), 65536u)), dim3(256), 0, st, bufs.p[R.sb], counters, curS,
+        if (!fuse && !keyed && actS) hipLaunchKernelGGL(k_refill<W>, dim3(std::min<u32>(cdiv(actS, 1024), 65536u)), dim3(256), 0, st, bufs.p[R.sb], counters, curS,
                                      d_text, isa_any, n, R.mode, c->alpha.as<u8>(), ks);
         DBG("k_refill");
         if (R.mode == MODE_TEXT) depth += ks.cpk; else { depth *= 2; tm.doubling_rounds++; }
         tm.rounds++;
-        tm.gathered_records += (int64_t)(actP + actS);          // records whose next key was gathered (roofline of the key rounds)
+        if (!keyed) tm.gathered_records += (int64_t)(actP + actS);          // records whose next key was gathered (roofline of the key rounds)
     }
     finish_groups();
     HIP_TRY(hipEventRecord(c->ev[5], st));
@@ -1403,6 +1460,7 @@ int build_logical(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* 
         const u64 lo = sc.rows[g], hi = sc.rows[g + 1];
         if (hi == lo) continue;
         o.shard = g;
+        c->hint_small_alphabet = c->plan_small_alphabet;
         const int r = build_sa<W>(c, d_text, n, d_sa + lo, lo, z, sc.cuts[g], sc.cuts[g + 1], sc.rank0[g], g == 0, &o, n - z > 0, grp + lo, hi - lo);
         if (r < 0) return r;
         acc.hist16_ms += c->tm.hist16_ms; acc.scatter0_ms += c->tm.scatter0_ms; acc.scatter1_ms += c->tm.scatter1_ms;
@@ -1682,9 +1740,12 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     if (c->sw.two_stage_set) two_stage = c->sw.two_stage;
     bool hist_done = false;
     int why = 0;                 // why a two-stage attempt was handed back (IND_WHY_*; 0: not tried / nothing spent)
+    const bool few_values = tail_values <= 84u;          // (byte values among the tail and three body samples)
+    c->hint_small_alphabet = few_values;
     if (two_stage > 0 || (two_stage == 0 && (u64)n >= (48ull << 20) && tail_values <= 128u)) {
         const int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, two_stage > 0, &hist_done, &why);
         if (r != MSUFSORT_HIP_UNRESOLVED) return r;
+        c->hint_small_alphabet = few_values;
         // whatever left for the host already is rebuilt and sent again - AFTER the stale copies have landed: the ring's copy
         // threads do not finish in order, a late stale chunk must not overwrite a fresh one (round-4 advisor finding)
         if (c->sink && c->sink_rows) c->sink->flush();
@@ -1794,6 +1855,7 @@ int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, typename
     if (slice_hi) *slice_hi = (int64_t)hi;
     if ((int64_t)(hi - lo) > slice_capacity) { set_error("slice needs %llu rows, capacity %lld", (unsigned long long)(hi - lo), (long long)slice_capacity); return MSUFSORT_HIP_ERR_BAD_ARG; }
     if (hi == lo) return MSUFSORT_HIP_OK;
+    c->hint_small_alphabet = c->plan_small_alphabet;
     const int r = build_sa<W>(c, d_text, (u64)n, d_slice_out, lo, z, sc.cuts[g], sc.cuts[g + 1], sc.rank0[g], g == 0, opts, m > 0, d_grp_slice_out, hi - lo);
     if (r == MSUFSORT_HIP_OK || r == MSUFSORT_HIP_UNRESOLVED) {
         // the histogram (every shard reads the whole text) and the planning of the cuts ran before build_sa started its clock

@@ -71,7 +71,10 @@ struct Desc {            // one segment = run of records that are equal on every
 // their members still hold the parent's rank and are all rewritten.
 #define DESC_STALE 4u
 
-struct RecBufs { u64* p[3]; };
+// x[] (optional, narrow builds of small alphabets): one 32-bit word per record of p[], same indexing - the key of the FIRST gather
+// round, which k_scatter0 reads off the text tile it holds anyway; it travels with the records through round 0 and the round-0
+// sorts put it into the free upper half of the records they emit, so that round 1 needs no gather
+struct RecBufs { u64* p[3]; u32* x[3]; };
 
 // counters block (device resident, read back by the host once per phase)
 enum {
@@ -176,6 +179,7 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 T)
 // 16-byte records pairs.  Vector-memory instructions are what a CU runs out of first in the scatter kernels, so
 // neighbouring records travel together wherever they can: one dwordx4 per lane instead of two dwordx2.
 struct __attribute__((aligned(8))) Rec2 { u64 a, b; };
+struct __attribute__((aligned(4))) Aux2 { u32 a, b; };      // the same for the records' 32-bit companions (RecBufs::x)
 
 // inclusive wave scan with DPP row shifts / row broadcasts: 12 vector instructions, no LDS traffic (the __shfl_up form costs
 // six ds_bpermute round trips - and the first wave of every scatter tile runs one while fifteen waves wait at a barrier)
@@ -826,109 +830,6 @@ __global__ __launch_bounds__(128) void k_stripes(const u32* __restrict__ sums, u
     if (c < nchunks) cursor0[c * 256u + b] = seg0_base[b] + e;
 }
 
-// number of dense key symbols of round 0 and where their base-sigma number sits in the key word (host and device agree):
-// narrow: 3 symbols in the 24 bits below the bucket byte; wide: the 16 bits between the bucket byte and the index byte
-// hold 3 symbols when sigma^3 <= 2^16, else 2
-template <bool W> __host__ __device__ inline u32 s0_symbols(u32 sigma) { return (!W || (u64)sigma * sigma * sigma <= 65536ull) ? 3u : 2u; }
-template <bool W> __host__ __device__ inline u32 s0_digit_bits(u32 sigma)      // bits of the largest dense number
-{
-    u64 p = 1;
-    for (u32 k = 0; k < s0_symbols<W>(sigma); ++k) p *= sigma;
-    u32 b = 0;
-    while (b < 32 && ((p - 1) >> b) != 0) ++b;
-    return b;
-}
-
-template <bool W>
-__global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ text, u64 m, u64 lo32, u64 hi32, u32 chunk_len,
-                                                         u32* __restrict__ cursor0, u64* __restrict__ out,
-                                                         const u8* __restrict__ code, const u32* __restrict__ counters, u32 allow_pack,
-                                                         const u8* __restrict__ sel_bits /* one bit per position, or nullptr: all */)
-{
-    // Small alphabets (up to 84 codes, k_alphabet): the three key symbols behind the second byte are written as ONE
-    // dense base-sigma number, left-aligned in the 24 key bits below the bucket byte.  Same depth (5 characters), but
-    // the partition levels below the two-byte buckets split on evenly used bits: one level instead of three for DNA
-    // (sigma^3 = 125 values), two for a 28-letter text, and children that k_sort_fast2 accepts when the symbols are
-    // evenly used.
-    __shared__ u8 s_code[256];
-    const u32 sigma = counters[C_ASIGMA];
-    const bool tiny = allow_pack != 0u && sigma >= 2u && sigma <= 84u;        // kernel-uniform
-    const u32 nsym = tiny ? s0_symbols<W>(sigma) : 3u;
-    const u32 dshift = tiny ? 24u - s0_digit_bits<W>(sigma) : 0u;             // (wide: 8 + 16 - bits)
-    // Compact staging: LDS holds the text of the tile and, per kept position, its 2-byte offset in the tile, bin-sorted; the
-    // record (key bytes behind the position + index) is put together at write-out from the LDS copy of the text.  3 bytes of
-    // LDS per position instead of 9, so a 16,384-position tile (runs of 64 records = 512 bytes per bin on uniform bytes) keeps two
-    // workgroups per CU (52 KB each; runs beyond 512 bytes buy nothing at 256 bins: tools/microbench/exp_write_runs.hip).
-    __shared__ __attribute__((aligned(16))) u32 tile[S0_TILE / 4 + 4];
-    __shared__ __attribute__((aligned(16))) unsigned short spos[S0_TILE];
-    __shared__ u32 hist[256], lstart[256], gbase[256];
-    __shared__ u32 s_total;
-    const u32 t = threadIdx.x;
-    const u64 base0 = (u64)xcd_tile(blockIdx.x, chunk_len / S0_TILE) * S0_TILE;
-    if (base0 >= m) return;
-    const u64 base = base0 + (u64)t * S0_POS;
-    if (t < 256) { hist[t] = 0; if (tiny) s_code[t] = code[t]; }
-    __syncthreads();
-    u32 w[S0_POS / 4 + 2];
-#pragma unroll
-    for (int k = 0; k < S0_POS / 4 + 2; ++k) w[k] = 0;
-    if (base < m + S0_POS) {                     // (one thread past the end too: its words are the look-ahead of the last positions; the text is padded)
-#pragma unroll
-        for (int k = 0; k < S0_POS / 4 + 1; ++k) w[k] = *reinterpret_cast<const u32*>(text + base + 4 * k);
-    }
-#pragma unroll
-    for (int k = 0; k < S0_POS / 4; ++k) tile[t * (S0_POS / 4) + k] = w[k];
-    if (t == S0_THREADS - 1) { tile[S0_TILE / 4] = w[S0_POS / 4]; tile[S0_TILE / 4 + 1] = 0; }
-    u32 rank[S0_POS / 2];                       // two 16-bit ranks per word
-    u32 validmask = 0;
-    static_assert(S0_POS == 8 || S0_POS == 16, "the positions of one thread are one or two bytes of the bitmap");
-    u32 selmask = S0_POS == 8 ? 0xffu : 0xffffu;
-    if (sel_bits) selmask = base < m ? (S0_POS == 8 ? (u32)sel_bits[base >> 3] : (u32)reinterpret_cast<const u16*>(sel_bits)[base >> 4]) : 0u;
-#pragma unroll
-    for (int k = 0; k < S0_POS / 2; ++k) rank[k] = 0;
-#pragma unroll
-    for (int j = 0; j < S0_POS; ++j) {
-        const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
-        const u32 b1 = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u;
-        const u32 b2 = (w[(j + 2) >> 2] >> (8 * ((j + 2) & 3))) & 255u, b3 = (w[(j + 3) >> 2] >> (8 * ((j + 3) & 3))) & 255u;
-        const u64 k32 = ((u64)b0 << 24) | (b1 << 16) | (b2 << 8) | b3;                 // shard = range of 4-byte prefixes
-        const bool valid = (base + j < m) && k32 >= lo32 && k32 < hi32 && ((selmask >> j) & 1u);
-        if (valid) { rank[j >> 1] |= atomicAdd(&hist[b0], 1u) << (16 * (j & 1)); validmask |= 1u << j; }
-    }
-    __syncthreads();
-    // claim the output ranges now, consume the answer after staging (hides the atomic's latency)
-    u32 claim = 0;
-    if (t < 256) { const u32 c = hist[t]; if (c) claim = atomicAdd(&cursor0[(u32)(base0 / chunk_len) * 256u + t], c); }
-    const u32 total = scan256_first_wave(hist, lstart);
-    if (t == 0) s_total = total;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < S0_POS; ++j) {
-        if (validmask & (1u << j)) {
-            const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
-            spos[lstart[b0] + ((rank[j >> 1] >> (16 * (j & 1))) & 0xffffu)] = (unsigned short)(t * S0_POS + j);
-        }
-    }
-    if (t < 256) gbase[t] = claim - lstart[t];            // slot -> output index is one add: out[gbase[bin] + slot]
-    __syncthreads();
-    const u32 tot = s_total;
-    for (u32 s = t; s < tot; s += S0_THREADS) {
-        const u32 l = spos[s];
-        const u64 v = (((u64)tile[(l >> 2) + 1] << 32) | tile[l >> 2]) >> (8u * (l & 3u));      // text bytes l .. l + 4 (and more)
-        const u32 b0 = (u32)v & 255u;
-        u32 key;
-        if (!tiny) key = __builtin_bswap32((u32)(v >> 8));                                       // (wide: the 4th byte is dropped by make_rec)
-        else {
-            u32 dg = 0;
-#pragma unroll
-            for (int q = 2; q <= 4; ++q)
-                if ((u32)q < 2u + nsym) dg = dg * sigma + (u32)s_code[(u32)(v >> (8 * q)) & 255u];
-            key = (((u32)(v >> 8) & 255u) << 24) | (dg << dshift);
-        }
-        out[gbase[b0] + s] = make_rec<W>(key, (typename Wd<W>::sa_t)(base0 + l));
-    }
-}
-
 // Prefix-doubling keys.  narrow: the rank itself (32 bits).  wide: ranks have up to 40 bits but a record only 24 key bits,
 // so a doubling step sorts in two passes over the same (read-only) rank array - first on digit A = rank >> dig_shift,
 // then, inside the groups that tie on it, on digit B = rank & dig_mask (the passes are ordinary rounds of the engine).
@@ -985,6 +886,153 @@ __device__ __forceinline__ void gather_keys(const GatherSpec& g, const u8* code,
         }
 #pragma unroll
         for (int k = 0; k < B; ++k) if (b0 + k < N) key[b0 + k] = valid[b0 + k] ? window_key<W>(w[k], g.ks, code) : 0xffffffffu;
+    }
+}
+
+// number of dense key symbols of round 0 and where their base-sigma number sits in the key word (host and device agree):
+// narrow: 3 symbols in the 24 bits below the bucket byte; wide: the 16 bits between the bucket byte and the index byte
+// hold 3 symbols when sigma^3 <= 2^16, else 2
+template <bool W> __host__ __device__ inline u32 s0_symbols(u32 sigma) { return (!W || (u64)sigma * sigma * sigma <= 65536ull) ? 3u : 2u; }
+template <bool W> __host__ __device__ inline u32 s0_digit_bits(u32 sigma)      // bits of the largest dense number
+{
+    u64 p = 1;
+    for (u32 k = 0; k < s0_symbols<W>(sigma); ++k) p *= sigma;
+    u32 b = 0;
+    while (b < 32 && ((p - 1) >> b) != 0) ++b;
+    return b;
+}
+
+// Packing of the gather rounds' keys (host and device agree): cpk symbols read as ONE base-sigma number, shifted left by zlow;
+// false: plain big-endian window of 4 (wide: 3) bytes.
+template <bool W> __host__ __device__ inline bool key_packing(u32 sigma, u32 abits, u32& cpk, u32& zlow)
+{
+    cpk = W ? 3u : 4u; zlow = 0;
+    if (abits < 2u || sigma < 2u) return false;
+    u64 p = 1; u32 k = 0;
+    while (k < 16 && p * sigma <= (1ull << (W ? 24 : 32))) { p *= sigma; ++k; }
+    if (k < (W ? 4u : 5u)) return false;                   // not even one symbol more than a plain window
+    u32 bl = 0;
+    while (bl < 32 && ((p - 1) >> bl) != 0) ++bl;          // bits of the largest key
+    cpk = k; zlow = 32 - bl;
+    return true;
+}
+
+template <bool W>
+__global__ __launch_bounds__(S0_THREADS) void k_scatter0(const u8* __restrict__ text, u64 m, u64 lo32, u64 hi32, u32 chunk_len,
+                                                         u32* __restrict__ cursor0, u64* __restrict__ out,
+                                                         const u8* __restrict__ code, const u32* __restrict__ counters, u32 allow_pack,
+                                                         const u8* __restrict__ sel_bits /* one bit per position, or nullptr: all */,
+                                                         u32* __restrict__ aux_out = nullptr /* narrow, small alphabets: key of the first gather round, per record */)
+{
+    // Small alphabets (up to 84 codes, k_alphabet): the three key symbols behind the second byte are written as ONE
+    // dense base-sigma number, left-aligned in the 24 key bits below the bucket byte.  Same depth (5 characters), but
+    // the partition levels below the two-byte buckets split on evenly used bits: one level instead of three for DNA
+    // (sigma^3 = 125 values), two for a 28-letter text, and children that k_sort_fast2 accepts when the symbols are
+    // evenly used.
+    __shared__ u8 s_code[256];
+    const u32 sigma = counters[C_ASIGMA];
+    const bool tiny = allow_pack != 0u && sigma >= 2u && sigma <= 84u;        // kernel-uniform
+    const u32 nsym = tiny ? s0_symbols<W>(sigma) : 3u;
+    const u32 dshift = tiny ? 24u - s0_digit_bits<W>(sigma) : 0u;             // (wide: 8 + 16 - bits)
+    // Compact staging: LDS holds the text of the tile and, per kept position, its 2-byte offset in the tile, bin-sorted; the
+    // record (key bytes behind the position + index) is put together at write-out from the LDS copy of the text.  3 bytes of
+    // LDS per position instead of 9, so a 16,384-position tile (runs of 64 records = 512 bytes per bin on uniform bytes) keeps two
+    // workgroups per CU (52 KB each; runs beyond 512 bytes buy nothing at 256 bins: tools/microbench/exp_write_runs.hip).
+    __shared__ __attribute__((aligned(16))) u32 tile[S0_TILE / 4 + 8];
+    __shared__ __attribute__((aligned(16))) unsigned short spos[S0_TILE];
+    __shared__ u32 hist[256], lstart[256], gbase[256];
+    __shared__ u32 s_total;
+    const u32 t = threadIdx.x;
+    const u64 base0 = (u64)xcd_tile(blockIdx.x, chunk_len / S0_TILE) * S0_TILE;
+    if (base0 >= m) return;
+    const u64 base = base0 + (u64)t * S0_POS;
+    if (t < 256) { hist[t] = 0; if (tiny) s_code[t] = code[t]; }
+    __syncthreads();
+    u32 w[S0_POS / 4 + 2];
+#pragma unroll
+    for (int k = 0; k < S0_POS / 4 + 2; ++k) w[k] = 0;
+    if (base < m + S0_POS) {                     // (one thread past the end too: its words are the look-ahead of the last positions; the text is padded)
+#pragma unroll
+        for (int k = 0; k < S0_POS / 4 + 1; ++k) w[k] = *reinterpret_cast<const u32*>(text + base + 4 * k);
+    }
+#pragma unroll
+    for (int k = 0; k < S0_POS / 4; ++k) tile[t * (S0_POS / 4) + k] = w[k];
+    // look-ahead behind the tile: 4 bytes for the round-0 keys, up to 5 + 16 for the key of the first gather round (the text is
+    // followed by MSUFSORT_HIP_TEXT_PAD = 64 zero bytes)
+    if (t < 8) { const u64 at = base0 + S0_TILE + 4u * t; tile[S0_TILE / 4 + t] = at + 4 <= m + 64 ? *reinterpret_cast<const u32*>(text + at) : 0u; }
+    u32 rank[S0_POS / 2];                       // two 16-bit ranks per word
+    u32 validmask = 0;
+    static_assert(S0_POS == 8 || S0_POS == 16, "the positions of one thread are one or two bytes of the bitmap");
+    u32 selmask = S0_POS == 8 ? 0xffu : 0xffffu;
+    if (sel_bits) selmask = base < m ? (S0_POS == 8 ? (u32)sel_bits[base >> 3] : (u32)reinterpret_cast<const u16*>(sel_bits)[base >> 4]) : 0u;
+#pragma unroll
+    for (int k = 0; k < S0_POS / 2; ++k) rank[k] = 0;
+#pragma unroll
+    for (int j = 0; j < S0_POS; ++j) {
+        const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+        const u32 b1 = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u;
+        const u32 b2 = (w[(j + 2) >> 2] >> (8 * ((j + 2) & 3))) & 255u, b3 = (w[(j + 3) >> 2] >> (8 * ((j + 3) & 3))) & 255u;
+        const u64 k32 = ((u64)b0 << 24) | (b1 << 16) | (b2 << 8) | b3;                 // shard = range of 4-byte prefixes
+        const bool valid = (base + j < m) && k32 >= lo32 && k32 < hi32 && ((selmask >> j) & 1u);
+        if (valid) { rank[j >> 1] |= atomicAdd(&hist[b0], 1u) << (16 * (j & 1)); validmask |= 1u << j; }
+    }
+    __syncthreads();
+    // claim the output ranges now, consume the answer after staging (hides the atomic's latency)
+    u32 claim = 0;
+    if (t < 256) { const u32 c = hist[t]; if (c) claim = atomicAdd(&cursor0[(u32)(base0 / chunk_len) * 256u + t], c); }
+    const u32 total = scan256_first_wave(hist, lstart);
+    if (t == 0) s_total = total;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < S0_POS; ++j) {
+        if (validmask & (1u << j)) {
+            const u32 b0 = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+            spos[lstart[b0] + ((rank[j >> 1] >> (16 * (j & 1))) & 0xffffu)] = (unsigned short)(t * S0_POS + j);
+        }
+    }
+    if (t < 256) gbase[t] = claim - lstart[t];            // slot -> output index is one add: out[gbase[bin] + slot]
+    __syncthreads();
+    const u32 tot = s_total;
+    // key of the first gather round (window_key at depth 2 + nsym), read off the tile: that round then needs no random text access
+    KeySpec ks1{};
+    bool with_aux = false;
+    if constexpr (!W) {
+        if (aux_out != nullptr && tiny) {
+            ks1.sigma = sigma; ks1.depth = 2u + nsym;
+            with_aux = key_packing<W>(sigma, counters[C_ABITS], ks1.cpk, ks1.zlow);
+        }
+    }
+    for (u32 s = t; s < tot; s += S0_THREADS) {
+        const u32 l = spos[s];
+        const u64 v = (((u64)tile[(l >> 2) + 1] << 32) | tile[l >> 2]) >> (8u * (l & 3u));      // text bytes l .. l + 4 (and more)
+        const u32 b0 = (u32)v & 255u;
+        u32 key;
+        if (!tiny) key = __builtin_bswap32((u32)(v >> 8));                                       // (wide: the 4th byte is dropped by make_rec)
+        else {
+            u32 dg = 0;
+#pragma unroll
+            for (int q = 2; q <= 4; ++q)
+                if ((u32)q < 2u + nsym) dg = dg * sigma + (u32)s_code[(u32)(v >> (8 * q)) & 255u];
+            key = (((u32)(v >> 8) & 255u) << 24) | (dg << dshift);
+        }
+        const u32 o = gbase[b0] + s;
+        out[o] = make_rec<W>(key, (typename Wd<W>::sa_t)(base0 + l));
+        if constexpr (!W) {
+            if (with_aux) {
+                const u32 a = l + (u32)ks1.depth, sh = 8u * (a & 3u);
+                const u32* tw = tile + (a >> 2);
+                u32 w4[4] = {0, 0, 0, 0};
+                const u32 t0 = tw[0], t1 = tw[1], t2 = tw[2];
+                w4[0] = sh ? (t0 >> sh) | (t1 << (32u - sh)) : t0;
+                w4[1] = sh ? (t1 >> sh) | (t2 << (32u - sh)) : t1;
+                if (ks1.cpk > 8u) {
+                    const u32 t3 = tw[3], t4 = tw[4];
+                    w4[2] = sh ? (t2 >> sh) | (t3 << (32u - sh)) : t2;
+                    w4[3] = sh ? (t3 >> sh) | (t4 << (32u - sh)) : t3;
+                }
+                aux_out[o] = window_key<W>(w4, ks1, s_code);
+            }
+        }
     }
 }
 
@@ -1067,11 +1115,15 @@ __global__ __launch_bounds__(256) void k_segscan(const Desc* __restrict__ list, 
     if (t == 0 && d.len == 0) trivial[s] = 1u;
 }
 
-template <int NB>
+// AUX: every record has a companion word in bufs.x[] (the key of the first gather round, k_scatter0) that moves with it.  The
+// tile's records leave first; the same LDS then stages (bin, companion) pairs at the same slots and the companions follow -
+// no LDS beyond what the records need, so the two workgroups per CU stay.  `aux_sigma` points at counters[C_ASIGMA]: the
+// level-1 launch is queued before the host knows whether the alphabet is small enough for k_scatter0 to have written companions.
+template <int NB, bool AUX = false>
 __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                           const u32* __restrict__ tile_start, u32 shift,
                                                           u32* __restrict__ cursor, const u32* __restrict__ trivial,
-                                                          u32 alt0, u32 alt1, u32 alt2)
+                                                          u32 alt0, u32 alt1, u32 alt2, const u32* __restrict__ aux_sigma = nullptr)
 {
     __shared__ __attribute__((aligned(16))) u64 stage[P1_TILE];
     __shared__ u32 hist[NB], lstart[NB], gbase[NB];
@@ -1089,16 +1141,23 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
     const u64* src = bufs.p[d.buf & 3u] + d.rec_off;
     const u32 alt = (d.buf & 3u) == 0 ? alt0 : ((d.buf & 3u) == 1 ? alt1 : alt2);
     u64* dst = bufs.p[alt];
+    bool aux_live = false;
+    if constexpr (AUX) { const u32 sg = aux_sigma[0]; aux_live = sg >= 2u && sg <= 84u; }
     u64 rec[P1_ITEMS];
     u32 rank[P1_ITEMS];
+    u32 ax[AUX ? P1_ITEMS : 1];
     static_assert(P1_ITEMS % 2 == 0, "records are read in pairs");
 #pragma unroll
     for (int j = 0; j < P1_ITEMS; j += 2) {                  // items j, j+1 = records 2 (j/2 * THREADS + t) and the next one
         const u32 p = off + 2u * ((u32)(j / 2) * P1_THREADS + t);
         rec[j] = 0; rec[j + 1] = 0; rank[j] = 0xffffffffu; rank[j + 1] = 0xffffffffu;
+        if constexpr (AUX) { ax[j] = 0; ax[j + 1] = 0; }
         if (p < d.len) {
             const Rec2 v = *reinterpret_cast<const Rec2*>(src + p);      // (may read one record past the segment)
             rec[j] = v.a; rec[j + 1] = v.b;
+            if constexpr (AUX) {
+                if (aux_live) { const Aux2 a2 = *reinterpret_cast<const Aux2*>(bufs.x[d.buf & 3u] + d.rec_off + p); ax[j] = a2.a; ax[j + 1] = a2.b; }
+            }
             rank[j] = atomicAdd(&hist[(u32)(rec[j] >> (32 + shift)) & (u32)(NB - 1)], 1u);
             if (p + 1 < d.len) rank[j + 1] = atomicAdd(&hist[(u32)(rec[j + 1] >> (32 + shift)) & (u32)(NB - 1)], 1u);
         }
@@ -1124,6 +1183,23 @@ __global__ __launch_bounds__(P1_THREADS) void k_partition(RecBufs bufs, const De
         const u64 r = stage[q];
         dst[gbase[(u32)(r >> (32 + shift)) & (u32)(NB - 1)] + q] = r;      // the bin is in the record itself
     }
+    if constexpr (AUX) {
+        if (!aux_live) return;                            // (kernel-uniform)
+        u32* adst = bufs.x[alt];
+        __syncthreads();                                  // the records have left the stage
+#pragma unroll
+        for (int j = 0; j < P1_ITEMS; ++j) {
+            if (rank[j] != 0xffffffffu) {
+                const u32 b = (u32)(rec[j] >> (32 + shift)) & (u32)(NB - 1);
+                stage[lstart[b] + rank[j]] = ((u64)b << 32) | ax[j];
+            }
+        }
+        __syncthreads();
+        for (u32 q = t; q < tot; q += P1_THREADS) {
+            const u64 r = stage[q];
+            adst[gbase[(u32)(r >> 32)] + q] = (u32)r;
+        }
+    }
 }
 
 // Route the 256 children of every partitioned segment by size (partition scheduling, cpp:1652-1683,
@@ -1136,7 +1212,8 @@ __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __re
                                                   typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32* __restrict__ grp_out, u32 mode,
                                                   u64* __restrict__ pool_rec, u64* __restrict__ pool_hdr, u32 pool_cnt_idx, u32 pool_cap,
                                                   Lists lists, Desc* __restrict__ lvl_dst, u32 lvl_cap, u32 lvl_cnt_idx, u32 lvl_tiles_idx,
-                                                  u32* __restrict__ counters, u32 cbits = 8u /* log2(children per segment) */)
+                                                  u32* __restrict__ counters, u32 cbits = 8u /* log2(children per segment) */,
+                                                  u32* __restrict__ pool_aux = nullptr /* companions of the pool records (bufs.x[]): see RecBufs */)
 {
     const u64 c = (u64)blockIdx.x * 256u + threadIdx.x;
     const bool live = c < ((u64)nseg << cbits);
@@ -1152,6 +1229,8 @@ __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __re
         sa = par.sa_off + (start - par.rec_off);
     }
     const u64* src = bufs.p[buf] + start;
+    bool aux_live = false;
+    if constexpr (!W) { if (pool_aux != nullptr) { const u32 sg = counters[C_ASIGMA]; aux_live = sg >= 2u && sg <= 84u; } }
     const u32 rank0 = counters[C_RANK0];
     if (cnt == 1) {
         const auto idx = rec_idx<W>(src[0]);
@@ -1172,6 +1251,7 @@ __global__ __launch_bounds__(256) void k_children(RecBufs bufs, const Desc* __re
                 const u32 b = base + woff;
                 const u64 st = (sa != par.sa_off || (par.buf & DESC_STALE)) ? (1ull << 48) : 0ull;      // header bit 48 = DESC_STALE of a pool run
                 for (u32 k = 0; k < cnt; ++k) { pool_rec[b + k] = src[k]; pool_hdr[b + k] = pack_hdr(sa, cnt, k) | st; }
+                if (aux_live) { const u32* asrc = bufs.x[buf] + start; for (u32 k = 0; k < cnt; ++k) pool_aux[b + k] = asrc[k]; }
             }
         }
     }
@@ -1249,7 +1329,7 @@ template <bool W>
 __global__ __launch_bounds__(P1_THREADS) void k_carry_copy(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                            const u32* __restrict__ tile_start, const u32* __restrict__ carry_base,
                                                            typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32* __restrict__ grp_out, u32 mode,
-                                                           u64* __restrict__ seg_rec, const u32* __restrict__ counters)
+                                                           u64* __restrict__ seg_rec, const u32* __restrict__ counters, u32 with_aux = 0u)
 {
     __shared__ u32 s_seg;
     const u32 t = threadIdx.x;
@@ -1267,7 +1347,8 @@ __global__ __launch_bounds__(P1_THREADS) void k_carry_copy(RecBufs bufs, const D
     for (int j = 0; j < P1_ITEMS; ++j) {
         const u32 p = off + j * P1_THREADS + t;
         if (p < d.len) {
-            const u64 r = src[p];
+            u64 r = src[p];
+            if constexpr (!W) { if (with_aux) r = ((u64)bufs.x[d.buf & 3u][d.rec_off + p] << 32) | (u32)r; }      // keyed for the first gather round
             seg_rec[base + p] = r;
             sa_out[d.sa_off + p] = rec_idx<W>(r);
             if (mode == MODE_ISA) isa[(u32)r] = rank0 + d.sa_off + 1u;
@@ -1446,7 +1527,10 @@ constexpr size_t sort_mid_lds_bytes()
     return (size_t)CAP * 4 + (size_t)WC * 4 + 256 * 4 * 2 + (size_t)(CAP / 64) * (8 * 3 + 4 * 2) + 8 * 4 + 24 * 4;
 }
 
-template <int THREADS, int ITEMS, bool W>
+// AUX (narrow, round 0 of small alphabets): every record has a companion word (RecBufs::x) - the key of the first gather round.
+// It is permuted with the record (one more LDS exchange per LSD pass) and goes into the upper half of the records emitted for
+// the next round, which therefore arrive WITH their key.
+template <int THREADS, int ITEMS, bool W, bool AUX = false>
 __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc d,
                                                  typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                  const Emit& em, u32* __restrict__ counters, const GatherSpec& g, const u8* s_code MPROF_PARAM)
@@ -1492,13 +1576,18 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
     u32 key[ITEMS], idx[ITEMS], pos[ITEMS];
+    u32 ax[AUX ? ITEMS : 1];
     u32 diff = 0;
     if (g.text == nullptr) {
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const u32 p = wbase + j * 64 + lane;
             key[j] = 0xffffffffu; idx[j] = 0xffffffffu;
-            if ((u32)j < rpw && p < len) { const u64 r = src[p]; key[j] = (u32)(r >> 32); idx[j] = (u32)r; }
+            if constexpr (AUX) ax[j] = 0;
+            if ((u32)j < rpw && p < len) {
+                const u64 r = src[p]; key[j] = (u32)(r >> 32); idx[j] = (u32)r;
+                if constexpr (AUX) ax[j] = bufs.x[d.buf & 3u][d.rec_off + p];
+            }
         }
     } else {        // text round: the records carry the suffix index only, the key is gathered here
         typename Wd<W>::sa_t fi[ITEMS];
@@ -1603,6 +1692,14 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) if (j < rows) idx[j] = ex[wbase + j * 64 + lane];
         __syncthreads();
+        if constexpr (AUX) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[pos[j]] = ax[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) if (j < rows) ax[j] = ex[wbase + j * 64 + lane];
+            __syncthreads();
+        }
     }
 
     MPROF(2);
@@ -1699,7 +1796,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const u32 p = j * 64 + lane;
-            if (p < len) { const u32 f = c_lt[j] + c_eqb[j]; ex[f] = idx[j]; ex[128 + f] = c_lt[j]; ex[256 + f] = c_eq[j]; if (W) ex[384 + f] = key[j]; }
+            if (p < len) { const u32 f = c_lt[j] + c_eqb[j]; ex[f] = idx[j]; ex[128 + f] = c_lt[j]; ex[256 + f] = c_eq[j]; if (W) ex[384 + f] = key[j]; if constexpr (AUX) ex[384 + f] = ax[j]; }
         }
         for (u32 i = t; i < (u32)NW; i += THREADS) { bm_eq[i] = 0; bm_tiny[i] = 0; bm_seg[i] = 0; }
         __syncthreads();
@@ -1710,6 +1807,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
             if (j < 2 && p < len) {
                 idx[j] = ex[p]; rs[j] = ex[128 + p]; rl[j] = ex[256 + p];
                 if (W) key[j] = ex[384 + p];             // (the index byte travels with the key word)
+                if constexpr (AUX) ax[j] = ex[384 + p];
                 sa_out[d.sa_off + p] = full_idx<W>(key[j], idx[j]);
                 if (mode == MODE_ISA && (rs[j] != 0 || (d.buf & DESC_STALE))) isa[idx[j]] = rank0 + d.sa_off + rs[j] + 1u;
                 if (mode == MODE_DEFER) em.grp_out[d.sa_off + p] = d.sa_off + rs[j];
@@ -1832,11 +1930,15 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                 const u32 w = p >> 6;
                 if (rl[j] <= TINY_MAX) {
                     const u32 o = base_t + pre_tiny[w] + (u32)__popcll(bm_tiny[w] & lt_mask);
-                    em.pool_rec[o] = (u64)full_idx<W>(key[j], idx[j]);
+                    u64 r = (u64)full_idx<W>(key[j], idx[j]);
+                    if constexpr (AUX) r |= (u64)ax[j] << 32;        // next round's key comes with the record
+                    em.pool_rec[o] = r;
                     em.pool_hdr[o] = pack_hdr(d.sa_off + rs[j], rl[j], p - rs[j]);
                 } else {
                     const u32 o = base_s + pre_seg[w] + (u32)__popcll(bm_seg[w] & lt_mask);
-                    em.seg_rec[o] = (u64)full_idx<W>(key[j], idx[j]);
+                    u64 r = (u64)full_idx<W>(key[j], idx[j]);
+                    if constexpr (AUX) r |= (u64)ax[j] << 32;
+                    em.seg_rec[o] = r;
                     if (p == rs[j]) {
                         const Desc nd = {o, rl[j], d.sa_off + rs[j], em.seg_buf};
                         const u32 cls = class_of(rl[j]);
@@ -2204,7 +2306,7 @@ constexpr size_t sort_fast_lds_bytes()
 
 // persistent launch: workgroups stride over the list and skip what k_sort_fast already finished
 // (the class-B instance asks for 4 waves per SIMD = 128 VGPRs: one more resident workgroup per CU)
-template <int THREADS, int ITEMS, bool W>
+template <int THREADS, int ITEMS, bool W, bool AUX = false>
 __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
                                                       typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                       Emit em, u32* __restrict__ counters, const u32* __restrict__ ids, u32 ids_cnt_idx,
@@ -2228,7 +2330,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(
         for (u32 i = blockIdx.x; i < total; i += gridDim.x) {
             const u32 ni = i + gridDim.x < total ? i + gridDim.x : i;
             const Desc dn = list[ids ? ids[ni] : ni];
-            sort_mid_segment<THREADS, ITEMS, W>(bufs, d, sa_out, isa, mode, em, counters, g, s_code MPROF_ARG);
+            sort_mid_segment<THREADS, ITEMS, W, AUX>(bufs, d, sa_out, isa, mode, em, counters, g, s_code MPROF_ARG);
             __syncthreads();
             d = dn;
         }
@@ -2298,7 +2400,8 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
                                                    u32 cnt_idx, typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
                                                    u64* __restrict__ next_rec, u64* __restrict__ next_hdr, u32 next_cnt_idx, u32 next_cap,
                                                    u32 chunk, u32* __restrict__ counters, u32* __restrict__ grp_out, u32 discard,
-                                                   GatherSpec g, const u8* __restrict__ code, u32 deep_cap)
+                                                   GatherSpec g, const u8* __restrict__ code, u32 deep_cap,
+                                                   const u32* __restrict__ pool_aux = nullptr /* round 0, small alphabets: companions of the pool records (RecBufs::x) */)
 {
     // deep_cap != 0 (narrow text rounds of a two-stage build, once the pool is small): the runs are finished HERE by comparing
     // the suffixes themselves, however long they agree (repeated passages: thousands of key rounds otherwise) - nothing goes
@@ -2318,11 +2421,15 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
         __syncthreads();
         if (t == 0) { s_total = 0; s_fb = 0; s_fe = 0; }
         u64 rec[2] = {0, 0}, hdr[2] = {0, 0};
+        u32 ax[2] = {0, 0};
         bool have[2] = {false, false};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const u32 e = t + k * WIN;
-            if (e < TOT && b0 + e < count) { rec[k] = pool_rec[b0 + e]; hdr[k] = pool_hdr[b0 + e]; have[k] = true; if (!g.text) lkey[e] = (u32)(rec[k] >> (32 + KL)); }
+            if (e < TOT && b0 + e < count) {
+                rec[k] = pool_rec[b0 + e]; hdr[k] = pool_hdr[b0 + e]; have[k] = true; if (!g.text) lkey[e] = (u32)(rec[k] >> (32 + KL));
+                if constexpr (!W) { if (pool_aux) ax[k] = pool_aux[b0 + e]; }
+            }
         }
         if (deep) {
 #pragma unroll
@@ -2396,7 +2503,9 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
             if (owned[k] && n_eq[k] > 1) {
                 const u32 sa_start = (u32)hdr[k];
                 const u32 o = s_base + lrun[lead[k]] + n_eqb[k];
-                next_rec[o] = (u64)rec_idx<W>(rec[k]);
+                u64 r = (u64)rec_idx<W>(rec[k]);
+                if constexpr (!W) { if (pool_aux) r = ((u64)ax[k] << 32) | (u32)r; }      // next round's key comes with the record
+                next_rec[o] = r;
                 next_hdr[o] = pack_hdr(sa_start + n_lt[k], n_eq[k], n_eqb[k]);
             }
     }
