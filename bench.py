@@ -353,10 +353,13 @@ def kernel_table(phases, K, n, workload, ops, ibwt_us):
     mstar = phases[-1].bstar_suffixes
     two_stage = mstar > 0
     ms_ = mstar if two_stage else m          # suffixes the sort phases handle
+    # small alphabets: the key of the first gather round travels with the records through round 0: 4 bytes more per
+    # suffix written by the scatter, 8 more moved by the partition level
+    k1 = 1 if phases[-1].key1_records > 0 else 0
     kern = {
         "k_hist16": (avg("hist16_ms"), n),
-        "k_scatter0": (avg("scatter0_ms"), n + 8 * ms_),
-        "k_partition(level 1)": (avg("scatter1_ms"), 16 * ms_),
+        "k_scatter0": (avg("scatter0_ms"), n + (8 + 4 * k1) * ms_),
+        "k_partition(level 1)": (avg("scatter1_ms"), (16 + 8 * k1) * ms_),
         ("bucket sort (LDS sorts of the two-byte buckets)" if workload == "random" else "round-0 LDS sorts (k_sort_mid/k_sort_tiny/bucket sort)"): (avg("bucket_sort_ms"), 12 * ms_),
     }
     if two_stage:
@@ -445,6 +448,8 @@ def config_lines(M, torch, ctx, dev, steps, no_cpu):
         cfg3["two_stage"] = {"bstar_suffixes": int(mstar), "induced_suffixes": int(n - mstar), "front_ms": round(avg("front_ms"), 3),
                              "induction_ms": round(avg("other_ms"), 3), "level_launches": int(S.phases[-1].induction_launches)}
     cfg3["fallbacks"] = int(sum(p.fallbacks & 1 for p in S.phases))
+    cfg3["key1_records"] = int(S.phases[-1].key1_records)          # suffixes whose first gather round needed no gather
+    cfg3["gathered_records"] = int(sum(p.gathered_records for p in S.phases) / K)
     walk_ms = S.ibwt_us[0] / K / 1e3
     cfg4 = {"workload": f"forward BWT of that text -> inverse BWT, n={n}, output compared with the text on the device", "valid": ok,
             "inverse_bwt_ms": round(ib_ms, 3), "inverse_bwt_MBps": round(n / ib_ms / 1e3, 1), "round_trip_ms": round(fb_ms + ib_ms, 3), "steps": K,
@@ -487,7 +492,7 @@ def multi_gpu_budget(n, world, index_bytes, rows_max, two_stage, want_bwt, pipel
     64 GiB + rank replica 64 GiB + sort workspace ~70 GiB + group heads / windows ~15 GiB = ~222 GiB of the 288 GB (268 GiB)."""
     from msufsort_amd import dist as mdist
     b = {"text": n + 64, "rows": (n + 1) * index_bytes * (2 if pipelined else 1), "group_heads": max(rows_max, 1) * 4,
-         "sort_workspace": int(70 * (rows_max + rows_max // 8 + (2 << 20))) + (300 << 20),
+         "sort_workspace": int((70 if index_bytes == 8 else 82) * (rows_max + rows_max // 8 + (2 << 20))) + (300 << 20),
          "doubling (rank replica + update / group-head windows; only for inputs with deep ties)": mdist.ShardState.bytes_needed(n, rows_max, world, index_bytes),
          "two_stage (sorted B* + induction workspace)": (n // 2 + 2) * 4 + 9 * n if two_stage else 0,
          "bwt": (n + rows_max) if want_bwt else 0}
@@ -560,6 +565,7 @@ def main():
             "kernels": kernels_json(kern),
             "phases_ms": {k: round(v[0], 4) for k, v in kern.items()} | {"refine": round(avg("refine_ms"), 4), "device_total": round(avg("total_ms"), 4)},
             "fallbacks": int(sum(p.fallbacks & 1 for p in S.phases)),
+            "key1_records": int(S.phases[-1].key1_records), "gathered_records": int(sum(p.gathered_records for p in S.phases) / K),
         }
         if two_stage:
             out["two_stage"] = {"bstar_suffixes": int(mstar), "induced_suffixes": int(n - mstar), "front_ms": round(avg("front_ms"), 3),

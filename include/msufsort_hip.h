@@ -97,7 +97,10 @@ typedef struct msufsort_hip_timings {
                                   key bits or skew outside its shapes); a handful of 65,536 on uniform random bytes up to the class-C limit */
     double hist17_ms;          /* 17-bit histogram of random-like inputs above the class-C limit (part of hist16_ms) */
     int64_t radix_bits;        /* bits of the two scatter levels of the last build: 16, or 17 (level 1 splits 512 ways) */
-    int64_t reserved[2];
+    int64_t key1_records;      /* small alphabets (<= 84 codes), narrow records: suffixes whose key of the FIRST gather round was read off the
+                                  text tile by k_scatter0 and carried through round 0 as a companion word (that round then gathers nothing:
+                                  its records are not in gathered_records; round 0 moves 4 bytes more per suffix and pass); 0: every round gathered */
+    int64_t reserved[1];
 } msufsort_hip_timings;
 /* The struct's size is part of the ABI (callers pass timings_out buffers): new fields only ever take reserved slots. */
 #ifdef __cplusplus

@@ -1118,6 +1118,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     {   // the companions exist iff the alphabet is small (what k_scatter0 and the level-1 partition decided on the device)
         const u32 sg = c->h_counters[C_ASIGMA];
         R.aux_on = R.aux_cand && !radix17 && sg >= 2 && sg <= 84;
+        tm.key1_records = R.aux_on ? (int64_t)ms : 0;
         if (verbose && R.aux_cand) fprintf(stderr, "[msufsort_hip] key of the first gather round from the sequential pass: %s (%u codes)\n", R.aux_on ? "yes" : "no", sg);
     }
     if ((u64)c->h_counters[C_MS] != ms && slice_rows) { set_error("slice bounds disagree with the histogram (%u suffixes on the device, %llu planned)", c->h_counters[C_MS], (unsigned long long)ms); return MSUFSORT_HIP_ERR_INTERNAL; }

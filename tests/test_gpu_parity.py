@@ -1123,3 +1123,53 @@ def test_trim_releases_the_host_ring(M):
     _lib.check(L.msufsort_hip_make_sa_i32_ctx(h, t.ctypes.data, n, sa.ctypes.data, C.byref(o)), "sa again")
     assert (sa == first).all()
     L.msufsort_hip_ctx_destroy(h)
+
+
+@pytest.mark.parametrize("kind", ["text", "dna", "sigma84", "sigma85", "dna_tandem", "text_tail_zeros"])
+def test_key1_from_the_sequential_pass(M, oracle_mod, monkeypatch, kind):
+    """for small alphabets (<= 84 codes) k_scatter0 writes, next to every record, the key the FIRST gather round would
+    fetch (the next cpk symbols as one base-sigma number: 6 for text, 13 for DNA - up to 21 bytes of look-ahead behind the tile);
+    it travels with the records through round 0 and round 1 sorts without a single random text access.  Same rows as with the
+    lever off (MSUFSORT_HIP_KEY1=-1) and as the reference; the first round's records no longer count as gathered; 85 codes: off.
+    Sizes around the 16,384-position scatter tiles; sort-all, two-stage and sharded builds; the forced-retry path."""
+    import torch
+    o = oracle_mod
+    for n in (16384 * 3 - 7, 16384 * 3, 16384 * 3 + 13, (3 << 20) + 5):
+        r = np.random.default_rng(n)
+        if kind == "text":
+            t = gen.text_bytes(n, 91)
+        elif kind == "dna":
+            t = gen.dna_bytes(n, 92)
+        elif kind == "dna_tandem":
+            t = gen.dna_tandem_bytes(n, 93)
+        elif kind == "text_tail_zeros":
+            t = gen.text_bytes(n, 94).copy(); t[-37:] = 0
+        else:
+            t = (r.integers(0, 83 if kind == "sigma84" else 84, n, dtype=np.uint8) + 1)          # + the reserved zero code: 84 / 85 codes
+        want = o.ref_make_suffix_array(t, 4) if o.have_reference() else o.make_suffix_array(t)
+        d = _dev(M, t)
+        ctx = M.DeviceContext(0)
+        sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        got = {}
+        for key1 in ("-1", "0"):
+            monkeypatch.setenv("MSUFSORT_HIP_KEY1", key1)
+            for two_stage in (-1, 1):
+                ctx.make_sa(d, n, sa, two_stage=two_stage)
+                tm = ctx.timings()
+                assert (sa.cpu().numpy() == want).all(), (kind, n, key1, two_stage)
+                got[(key1, two_stage)] = (tm.gathered_records, tm.rounds, tm.fallbacks & 1)
+            ctx.make_sa(d, n, sa, logical_shards=3, text_rounds=2)                              # sharded (+ distributed doubling where the ties are deep)
+            assert (sa.cpu().numpy() == want).all(), (kind, n, key1, "sharded")
+        for two_stage in (-1, 1):
+            off, on = got[("-1", two_stage)], got[("0", two_stage)]
+            assert on[1] == off[1]                                                              # same rounds either way
+            if kind == "sigma85" or off[0] == 0:
+                assert on[0] == off[0]
+            elif not (two_stage == 1 and on[2]):                                                # (a declined two-stage attempt reports the sort-all build)
+                assert on[0] < off[0], (kind, n, two_stage, on, off)
+        monkeypatch.setenv("MSUFSORT_HIP_KEY1", "0")
+        monkeypatch.setenv("MSUFSORT_HIP_FORCE_RETRY", "1")                                     # every round's first sort attempt is thrown away
+        ctx.make_sa(d, n, sa, two_stage=-1)
+        assert (sa.cpu().numpy() == want).all(), (kind, n, "retry")
+        monkeypatch.delenv("MSUFSORT_HIP_FORCE_RETRY")
+        monkeypatch.delenv("MSUFSORT_HIP_KEY1")
