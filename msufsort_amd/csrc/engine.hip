@@ -1743,7 +1743,7 @@ int msufsort_hip_make_sa_i32_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n
     int why = 0;                 // why a two-stage attempt was handed back (IND_WHY_*; 0: not tried / nothing spent)
     const bool few_values = tail_values <= 84u;          // (byte values among the tail and three body samples)
     c->hint_small_alphabet = few_values;
-    if (two_stage > 0 || (two_stage == 0 && (u64)n >= (48ull << 20) && tail_values <= 128u)) {
+    if (two_stage > 0 || (two_stage == 0 && (u64)n >= ((u64)TWO_STAGE_MIN_MIB_TEXT << 20) && tail_values <= 128u)) {
         const int r = build_sa_two_stage(c, d_text, (u64)n, reinterpret_cast<u32*>(d_sa_out), z, &o, two_stage > 0, &hist_done, &why);
         if (r != MSUFSORT_HIP_UNRESOLVED) return r;
         c->hint_small_alphabet = few_values;
