@@ -371,9 +371,12 @@ def kernel_table(phases, K, n, workload, ops, ibwt_us):
         else:
             # single-pass levels: every source row read once (4 B index + 4 B characters), every induced row written once (8 B)
             kern["induction (k_ind_fused + k_ind_small)"] = (avg("other_ms"), int(8 * rows_read + 8 * (n - mstar) + 4 * fetches))
-    if refilled > 0.01 * m:
+    # (small alphabets: round 1 receives its records WITH their keys - no gather, but the same 16 bytes per record: record read 8,
+    # row / next record written 8 - and its time is part of refine_ms: its records are counted here, not in gathered_records)
+    keyed = sum(p.unresolved_after_round0 for p in phases) / K if k1 else 0
+    if refilled + keyed > 0.01 * m:
         # per still-tied suffix and key round: index read (4) + key (8) + index written (4)
-        kern["key rounds (k_refill + k_partition levels + LDS sorts)"] = (avg("refine_ms"), int(16 * refilled))
+        kern["key rounds (k_refill + k_partition levels + LDS sorts)"] = (avg("refine_ms"), int(16 * (refilled + keyed)))
     if "ibwt" in ops and ibwt_us[0]:
         kern["k_ibwt_walk"] = (ibwt_us[0] / K / 1e3, 9 * n)       # n hops x 8 B entry + n bytes written
     return kern, avg, two_stage, mstar
@@ -526,6 +529,10 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}", file=sys.stderr)
         return 2
 
+    if os.environ.get("MSUFSORT_BENCH_DEBUG_HANG"):          # every thread's stack on stderr after that many seconds (and again, repeatedly)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MSUFSORT_BENCH_DEBUG_HANG"]), repeat=True, file=sys.stderr)
+
     import torch
 
     import msufsort_amd as M
@@ -662,13 +669,15 @@ def main():
 
     # the text is generated ONCE (rank 0) and replicated over the links ("H2D to one + broadcast")
     d_text = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
-    if rank == 0:
+    bcast = not os.environ.get("MSUFSORT_BENCH_NO_BROADCAST")
+    if rank == 0 or not bcast:
         t = gen.GENERATORS[args.workload](n, args.seed)
         for s0 in range(0, n, 1 << 30):
             d_text[s0:min(n, s0 + (1 << 30))] = torch.from_numpy(t[s0:min(n, s0 + (1 << 30))]).to(dev)
         del t
     torch.cuda.synchronize(dev)
-    dist.broadcast(d_text, src=0)
+    if bcast:
+        dist.broadcast(d_text, src=0)
     torch.cuda.synchronize(dev)          # the engine works on its own HIP stream: the text must have landed
     ctx = M.DeviceContext(local, 0)
     bounds = ctx.shard_bounds(d_text, n, world)

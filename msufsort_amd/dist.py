@@ -331,10 +331,9 @@ def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist
     flag = torch.tensor([depth if unresolved else 0, -(depth if unresolved else big)], dtype=torch.int64, device=dev)
     works = []
     if world > 1:
-        w = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)       # rides along with the slice exchange
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)       # (16 bytes; completed before the slices are posted: see the note in DESIGN 3.3)
         if gather_rows:
             works = allgatherv_slices(d_sa_full, bounds, dist, wait=False)
-        w.wait()
     dmax, dmin = int(flag[0].item()), -int(flag[1].item())
     if dmax > 0:
         if dmin != dmax:
