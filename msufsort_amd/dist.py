@@ -16,6 +16,14 @@ import numpy as np
 from . import _lib
 
 
+def _many(world: int) -> bool:
+    """Are the collectives of a step issued?  Yes with more than one rank - and, under MSUFSORT_DIST_ALWAYS_COLLECTIVE=1, with one
+    rank too: the hook that lets a one-GPU box put every all-reduce / all-gatherv call of this module through RCCL itself
+    (tests/test_gpu_dist.py::test_bench_dist_path_on_rccl_with_one_rank; a one-rank all-gatherv posts no sends)."""
+    import os
+    return world > 1 or bool(os.environ.get("MSUFSORT_DIST_ALWAYS_COLLECTIVE"))
+
+
 def plan_cuts(bstart, n: int, z: int, n_shards: int):
     """Host-only: (cuts, rows) for `n_shards` shards from the exclusive 16-bit-key prefix bstart[65537] (uint64)."""
     b = np.ascontiguousarray(bstart, dtype=np.uint64)
@@ -168,7 +176,7 @@ def _replicate_ranks(ctx, d_sa_full, d_grp, bounds, rank, world, dist, state, in
             pre.append(pre[-1] + x)
         if cnt[rank]:
             stage[pre[rank]:pre[rank + 1]] = d_grp[w0:w0 + cnt[rank]]
-        if world > 1:
+        if _many(world):
             if stage.is_cuda:
                 import torch
                 torch.cuda.current_stream(stage.device).synchronize()
@@ -210,7 +218,7 @@ def _distributed_doubling(ctx, n, d_sa_full, d_grp, bounds, rank, world, dist, d
             live = tied_before > 0
             st["sort_ms"] += ctx.timings().refine_ms
         nw = torch.tensor([(items + win - 1) // win if live else 0], dtype=torch.int64, device=dev)
-        if world > 1:
+        if _many(world):
             dist.all_reduce(nw, op=dist.ReduceOp.MAX)        # every rank walks the same number of exchange windows
         nwin = int(nw.item())
         tied_local = 0
@@ -224,7 +232,7 @@ def _distributed_doubling(ctx, n, d_sa_full, d_grp, bounds, rank, world, dist, d
             t0 = time.perf_counter()
             counts = torch.zeros(world, dtype=torch.int64, device=dev)
             counts[rank] = cnt
-            if world > 1:
+            if _many(world):
                 dist.all_reduce(counts)
             pre, e = update_offsets(counts.tolist(), index_bytes)
             if pre[-1]:
@@ -232,14 +240,14 @@ def _distributed_doubling(ctx, n, d_sa_full, d_grp, bounds, rank, world, dist, d
                     state.upd_all[pre[rank]:pre[rank + 1]] = state.upd_local[:cnt * e]
                 if dev.type == "cuda":
                     torch.cuda.current_stream(dev).synchronize()
-                if world > 1:
+                if _many(world):
                     allgatherv_slices(state.upd_all, pre, dist)
                 st["exchange_ms"] += (time.perf_counter() - t0) * 1e3
                 ctx.apply_updates(state.upd_all, pre[-1] // e, isa, index_bytes)
                 st["updates"] += pre[-1] // e
             st["windows"] += 1
         tt = torch.tensor([tied_local], dtype=torch.int64, device=dev)
-        if world > 1:
+        if _many(world):
             dist.all_reduce(tt)
         st["doubling_steps"] += 1
         if int(tt.item()) == 0:
@@ -267,10 +275,10 @@ def build_sa_two_stage_sharded(ctx, d_text, n: int, d_sa_full, d_bstar, rank: in
     def exchange(bounds, my_status):
         t0 = time.perf_counter()
         flag = torch.tensor([my_status], dtype=torch.int32, device=dev)
-        if world > 1:
+        if _many(world):
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         agreed = int(flag.item())
-        if agreed == 0 and world > 1:
+        if agreed == 0 and _many(world):
             allgatherv_slices(d_bstar, bounds, dist)          # waits, and synchronises the device (wait_all)
         t_ex[0] = (time.perf_counter() - t0) * 1e3
         return agreed
@@ -316,7 +324,7 @@ def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist
         if index_bytes != 4:
             raise ValueError("int64 rows run the wide engine, which always publishes its tie groups: pass d_grp")
         ctx.make_sa_shard(d_text, n, sl, max(hi - lo, 1), rank, world, text_rounds=text_rounds)
-        if world > 1 and gather_rows:
+        if _many(world) and gather_rows:
             works = allgatherv_slices(d_sa_full, bounds, dist, wait=not overlap)
             return works if overlap else []
         return []
@@ -330,7 +338,7 @@ def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist
     big = 1 << 62
     flag = torch.tensor([depth if unresolved else 0, -(depth if unresolved else big)], dtype=torch.int64, device=dev)
     works = []
-    if world > 1:
+    if _many(world):
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)       # (16 bytes; completed before the slices are posted: see the note in DESIGN 3.3)
         if gather_rows:
             works = allgatherv_slices(d_sa_full, bounds, dist, wait=False)
@@ -338,13 +346,13 @@ def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist
     if dmax > 0:
         if dmin != dmax:
             raise _lib.MsufsortHipError(f"shards stopped their key rounds at different depths ({dmin} .. {dmax})")
-        if world > 1 and not gather_rows:
+        if _many(world) and not gather_rows:
             works = allgatherv_slices(d_sa_full, bounds, dist, wait=False)      # the doubling needs everybody's provisional rows
         wait_all(works, d_sa_full)
         if state is None:
             state = ShardState()
         _distributed_doubling(ctx, n, d_sa_full, d_grp, bounds, rank, world, dist, dmax, index_bytes, state, verbose)
-        if world > 1 and gather_rows:
+        if _many(world) and gather_rows:
             allgatherv_slices(d_sa_full, bounds, dist)          # the final rows
         return []
     if overlap:
@@ -377,7 +385,7 @@ def forward_bwt_sharded(ctx, d_text, n: int, d_sa_full, bounds, rank: int, world
         s_local = ctx.bwt_slice(d_text, n, d_sa_full[lo:hi], lo, hi, d_row_bytes, index_bytes)
     t0 = time.perf_counter()
     s = torch.tensor([s_local], dtype=torch.int64, device=dev)
-    if world > 1:
+    if _many(world):
         dist.all_reduce(s, op=dist.ReduceOp.MAX)
     sent = int(s.item())
     if not (1 <= sent <= n):
@@ -394,7 +402,7 @@ def forward_bwt_sharded(ctx, d_text, n: int, d_sa_full, bounds, rank: int, world
             d_bwt_out[out[rank]:out[rank + 1]] = d_row_bytes[:hi - lo]
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()
-    if world > 1:
+    if _many(world):
         allgatherv_slices(d_bwt_out, out, dist)
     if stats is not None:
         stats["bwt_exchange_ms"] = round((time.perf_counter() - t0) * 1e3, 3)

@@ -1,7 +1,8 @@
 """GPU box (1 GPU): the full N>1 flow of bench.py - shard planning, per-rank sharded HIP sort, all-gatherv,
-on-device validation - with 2, 4 and 8 ranks sharing cuda:0 over gloo (RCCL refuses two ranks on one device).  RCCL itself and
-peer copies between two devices have NOT run anywhere yet: no box this repo has met had a second GPU (the line says so:
-`config.backend` / `config.rccl_ranks`)."""
+on-device validation - with 2, 4 and 8 ranks sharing cuda:0 over gloo (RCCL refuses two ranks on one device), and with ONE rank on
+RCCL itself forced through the same code path (every process-group call of the flow, no point-to-point sends).  What has NOT run
+anywhere yet: RCCL sends / receives and peer copies between two devices - no box this repo has met had a second GPU (the line
+says what ran: `config.backend` / `config.rccl_ranks`)."""
 import json
 import os
 import subprocess
@@ -206,3 +207,22 @@ def test_bench_refuses_when_hbm_is_short():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", str(1 << 33), "--workload", "dna", "--no-cpu"],
                        env=env, capture_output=True, text=True, timeout=1800, cwd=ROOT)
     assert r.returncode != 0 and "GiB of HBM per GPU" in r.stderr and "rank replica" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("args", [["--workload", "random", "--size", 1 << 22], ["--workload", "dna_tandem", "--size", 1 << 21, "--index", "int64", "--op", "sa,fbwt"],
+                                  ["--workload", "text", "--size", 1 << 22, "--two-stage", 1]])
+def test_bench_dist_path_on_rccl_with_one_rank(args):
+    """RCCL refuses two ranks on one device, so no box this repository has met could run the N > 1 flow on the backend it is written
+    for.  What a one-GPU box CAN do: one rank, backend nccl (= RCCL), forced through the N > 1 code path - process group with
+    device_id, broadcast of the text, the all-reduces (int32 / int64 / float64, MAX and SUM), barrier, the two-stage exchange
+    callback, the distributed doubling's window loop with its collectives, the byte-slice exchange of the forward BWT - everything
+    but the point-to-point sends (a one-rank all-gatherv posts none).  API misuse against RCCL shows here, not on the 8-GPU node."""
+    env = {k: v for k, v in os.environ.items() if k not in ("MSUFSORT_BENCH_BACKEND", "MSUFSORT_BENCH_ONE_DEVICE")}
+    env.update(MSUFSORT_BENCH_FORCE_DIST="1", MSUFSORT_DIST_ALWAYS_COLLECTIVE="1", MSUFSORT_DIST_WINDOW="50000", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29633",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu", "--check-reference", *[str(a) for a in args]]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[-1])
+    assert d["valid"] is True and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1 and d["n_gpus"] == 1
