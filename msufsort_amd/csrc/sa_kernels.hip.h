@@ -328,8 +328,18 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
     extern __shared__ u32 h_lds[];
     u64* ovf = reinterpret_cast<u64*>(h_lds + 32768);
     u32* ovf_n = h_lds + 32768 + H16_OVF_CAP * 2;            // [0] list length, [1] checksum, [2] keys counted (SUB), [3] largest counter
+    // DENSE mode (round 5; small alphabets: DNA, plain text): a skewed chunk whose first sub-chunk showed at most 64 byte values does
+    // not continue in SAFE mode (every add of a 4-letter text is a many-way same-address conflict, and SAFE mode's run merging and
+    // sweeps cost 1.3 ms per GiB of DNA against 0.3 for random bytes) but counts DENSE keys code(b0) << S | code(b1) in up to 64
+    // private copies of a small table (copy = lane: lanes never meet on an address), 32-bit counters, no sweeps; the counts of the
+    // first sub-chunk are flushed to the output first, the dense totals are added to it at the end, and a byte value that only
+    // turns up later is counted straight into the output (one global atomic, rare).
+    __shared__ u32 s_present[8];
+    __shared__ u8 s_dcode[256], s_dsym[256];
     const u32 chunk = blockIdx.x, t = threadIdx.x;
     if (chunk >= nchunks) return;
+    u32* const out = partial + (u64)chunk * 65536u;
+    u32 dense_s = 0, dense_lc = 0;                           // != 0: DENSE mode, S = bits per code; log2(copies)
     uint4* h4 = reinterpret_cast<uint4*>(h_lds);
     const u64 cbeg = (u64)chunk * chunk_len;
     u64 cend = cbeg + chunk_len;
@@ -344,6 +354,7 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
     for (u32 pass = 0; pass < 2; ++pass) {
         for (u32 i = t; i < 8192u; i += 1024u) h4[i] = make_uint4(0, 0, 0, 0);
         if (t < 4) ovf_n[t] = 0;
+        if (t < 8) s_present[t] = 0;
         __syncthreads();
         u64 base = cbeg + (u64)t * 16u;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -364,6 +375,34 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
                 const u32 lim = cend - cb >= 16 ? 16u : (u32)(cend - cb);
                 u32 pb = 0xffffu;
                 if (BITS) pb = bits[cb >> 4];
+                if (dense_s) {
+                    const u32 copy = lane_id() & ((1u << dense_lc) - 1u);
+                    if constexpr (SUB) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            if ((u32)j < lim && h16_key(w, j) == sel) {
+                                const u32 k = h16_key(w, j + 2);
+                                const u32 c0 = s_dcode[k & 255u], c1 = s_dcode[k >> 8];
+                                if ((c0 | c1) < 64u) atomicAdd(&h_lds[((((c0 << dense_s) | c1)) << dense_lc) | copy], 1u);
+                                else atomicAdd(&out[k], 1u);                     // a byte value the first sub-chunk did not show
+                            }
+                        }
+                    } else {
+                        // (the second byte of position j is the first byte of position j + 1: one code look-up per byte)
+                        u32 b0 = w[0] & 255u, c0 = s_dcode[b0];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const u32 b1 = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u, c1 = s_dcode[b1];
+                            bool on = (u32)j < lim;
+                            if (BITS) on = on && ((pb >> j) & 1u);
+                            if (on) {
+                                if ((c0 | c1) < 64u) atomicAdd(&h_lds[((((c0 << dense_s) | c1)) << dense_lc) | copy], 1u);
+                                else atomicAdd(&out[b0 | (b1 << 8)], 1u);        // a byte value the first sub-chunk did not show
+                            }
+                            b0 = b1; c0 = c1;
+                        }
+                    }
+                } else
                 if (!safe && !FILT && lim == 16u) {                // the common case: 16 plain adds, nothing predicated
 #pragma unroll
                     for (int j = 0; j < 16; ++j) h16_add(h_lds, h16_key(w, j), 1u);
@@ -399,6 +438,7 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
                 }
             }
             if (sub + H16_SUB >= cend) continue;                    // the last sub-chunk needs no sweep
+            if (dense_s) continue;                                  // 32-bit private counters: nothing can wrap
             if (!safe && sub != cbeg) continue;                     // optimistic: only the look after the first sub-chunk
             __syncthreads();
             u32 cmax = 0;
@@ -409,6 +449,17 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
                     const u32 a = max(max(q.x & 0xffffu, q.x >> 16), max(q.y & 0xffffu, q.y >> 16));
                     const u32 b = max(max(q.z & 0xffffu, q.z >> 16), max(q.w & 0xffffu, q.w >> 16));
                     cmax = max(cmax, max(a, b));
+                    if (q.x | q.y | q.z | q.w) {                     // byte values seen so far (for the DENSE code): word = b0 | (b1 & 127) << 8, half = b1 >> 7
+                        const u32 qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (!qq[e]) continue;
+                            const u32 word = i * 4u + e, b0 = word & 255u, b1 = word >> 8;
+                            atomicOr(&s_present[b0 >> 5], 1u << (b0 & 31u));
+                            if (qq[e] & 0xffffu) atomicOr(&s_present[b1 >> 5], 1u << (b1 & 31u));
+                            if (qq[e] >> 16) atomicOr(&s_present[(b1 | 128u) >> 5], 1u << (b1 & 31u));
+                        }
+                    }
                 }
                 if (((q.x | q.y | q.z | q.w) & 0xC000C000u) == 0) continue;
                 u32 ww[4] = {q.x, q.y, q.z, q.w};
@@ -433,7 +484,28 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
             }
             __syncthreads();
             // (counters >= H16_FLUSH were moved to the overflow list above in either mode, so switching is seamless)
-            if (!safe && (u64)ovf_n[3] * nsub >= 65535ull) safe = true;
+            if (!safe && (u64)ovf_n[3] * nsub >= 65535ull) {
+                safe = true;
+                u32 sigma = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sigma += (u32)__popc(s_present[k]);
+                if (sigma >= 1u && sigma <= 64u) {                      // (workgroup-uniform) small alphabet: DENSE mode for the rest of the chunk
+                    if (t < 256u) {
+                        const u32 wd = s_present[t >> 5], bit = t & 31u;
+                        u32 r = (u32)__popc(wd & ((1u << bit) - 1u));
+                        for (u32 k = 0; k < (t >> 5); ++k) r += (u32)__popc(s_present[k]);
+                        const bool on = (wd >> bit) & 1u;
+                        s_dcode[t] = on ? (u8)r : (u8)255;
+                        if (on) s_dsym[r] = (u8)t;
+                    }
+                    // what the first sub-chunk counted goes to the output now (the table is needed for the private copies)
+                    for (u32 i = t; i < 32768u; i += 1024u) { const u32 q = h_lds[i]; out[i] = q & 0xffffu; out[i + 32768u] = q >> 16; h_lds[i] = 0; }
+                    __threadfence();                                    // ... and is there before anything is ADDED to it
+                    dense_s = sigma <= 2u ? 1u : 32u - (u32)__clz(sigma - 1u);
+                    dense_lc = 15u - 2u * dense_s; if (dense_lc > 6u) dense_lc = 6u;
+                    __syncthreads();
+                }
+            }
         }
         __syncthreads();
         if (safe) break;
@@ -454,7 +526,18 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
         if (clean) break;
         safe = true;                                                // recount everything with sweeps
     }
-    u32* out = partial + (u64)chunk * 65536u;
+    if (dense_s) {
+        // totals of the private copies (2^dense_lc consecutive words per dense key) -> added to the output under the key itself
+        const u32 S = dense_s, LC = dense_lc, words = 1u << (2u * S + LC);
+        for (u32 i = t; i < words; i += 1024u) {                   // (words is a multiple of 1024 or below it: whole waves stay together)
+            u32 v = h_lds[i];
+            for (u32 d = 1; d < (1u << LC); d <<= 1) v += (u32)__shfl_xor((int)v, (int)d, 64);
+            if ((i & ((1u << LC) - 1u)) == 0 && v) {
+                const u32 e = i >> LC;
+                atomicAdd(&out[(u32)s_dsym[e >> S] | ((u32)s_dsym[e & ((1u << S) - 1u)] << 8)], v);
+            }
+        }
+    } else
     for (u32 i = t; i < 32768u; i += 1024u) {
         const u32 q = h_lds[i];
         out[i] = q & 0xffffu;

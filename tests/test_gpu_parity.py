@@ -1173,3 +1173,52 @@ def test_key1_from_the_sequential_pass(M, oracle_mod, monkeypatch, kind):
         assert (sa.cpu().numpy() == want).all(), (kind, n, "retry")
         monkeypatch.delenv("MSUFSORT_HIP_FORCE_RETRY")
         monkeypatch.delenv("MSUFSORT_HIP_KEY1")
+
+
+@pytest.mark.parametrize("kind", ["dna", "skew2", "skew3", "skew16", "skew17", "skew32", "skew33", "skew64", "skew65", "late_symbol", "alphabet_grows", "all_a"])
+def test_hist16_dense_mode_small_alphabets(M, kind):
+    """k_hist16's DENSE mode (round 5): a SKEWED chunk (one that would wrap its 16-bit counters: SAFE mode until now) whose first
+    sub-chunk showed at most 64 byte values counts dense keys in private copies of a small table.  Sizes at which the chunks ARE
+    skewed (a key's count in the first 48 KiB x sub-chunks >= 65,535: uniform DNA from 264 MiB, half-'a' alphabets from ~72 MiB);
+    alphabets at the boundaries of the code widths (2 / 3, 16 / 17, 32 / 33, 64 values; 65 stays in SAFE mode); a byte value that
+    turns up late in a chunk, a whole new alphabet half-way (counted straight into the output).  Exact counts - and the kernel's
+    BITS mode (B* histogram of the two-stage build) and SUB mode (deeper histogram of a heavy key: shard cuts inside it) through
+    the rows they lead to."""
+    import torch
+    r = np.random.default_rng(5)
+    n = (300 << 20) + 4321 if kind == "dna" else (80 << 20) + 4321
+
+    def skewed(sigma, count, base):          # half of the positions hold the first symbol, the others are uniform
+        x = r.integers(0, 256, count, dtype=np.uint8)
+        y = r.integers(0, sigma, count, dtype=np.uint8)
+        return (np.where(x < 128, 0, y) * 3 + base).astype(np.uint8)
+    if kind == "dna":
+        t = gen.dna_bytes(n, 3)
+    elif kind.startswith("skew"):
+        t = skewed(int(kind[4:]), n, 7)
+    elif kind == "late_symbol":
+        t = skewed(4, n, 65); t[70000:: 99991] = 200
+    elif kind == "alphabet_grows":
+        t = np.concatenate([skewed(4, n // 2, 65), skewed(20, n - n // 2, 130)])
+    else:
+        t = np.full(n, 65, dtype=np.uint8)
+    d = _dev(M, t)
+    ctx = M.DeviceContext(0, n)
+    h = torch.zeros(65536, dtype=torch.int32, device="cuda")
+    ctx.debug_hist16(d, n, h)
+    tp = np.concatenate([t, np.zeros(1, np.uint8)]).astype(np.uint32)
+    want = np.bincount((tp[:-1] << 8) | tp[1:], minlength=65536)
+    del tp
+    assert (h.cpu().numpy().astype(np.int64) == want).all(), kind
+    if kind in ("all_a", "skew65", "skew33", "skew3"):
+        return
+    ref = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, n, ref, two_stage=-1)
+    assert ctx.validate_sa(d, n, ref) == 0
+    ctx.make_sa(d, n, sa, two_stage=1)                 # BITS mode
+    assert bool(torch.equal(sa, ref)), (kind, "two-stage")
+    ctx.make_sa(d, n, sa, logical_shards=5)            # SUB mode (cuts inside the heavy two-byte key)
+    assert bool(torch.equal(sa, ref)), (kind, "sharded")
+    del sa, ref, d
+    ctx.trim(); torch.cuda.empty_cache()

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F, P = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
 # only what tools/gpu_final_r5.sh writes (gpurun_out/final/ also holds earlier rounds' files)
 FILES = ["pytest_gpu.log", "bench.json", "bench_time.txt", "bench_256MiB.json", "bench_text_sort_all.json", "bench_dna.json", "bench_dna_tandem_256MiB.json",
-         "bench_2ranks_one_gpu_256MiB.json", "bench_2ranks_one_gpu_text_256MiB_two_stage_sharded.json", "sizes.txt",
+         "bench_2ranks_one_gpu_256MiB.json", "bench_2ranks_one_gpu_64MiB.json", "bench_2ranks_one_gpu_text_256MiB_two_stage_sharded.json", "sizes.txt",
          "kernel_stats_random.txt", "kernel_stats_random.csv", "kernel_stats_text.txt", "kernel_stats_text.csv", "kernel_stats_2GiB.txt", "kernel_stats_2GiB.csv",
          "pmc_traffic_random.txt", "pmc_traffic_text_sa.txt", "pmc_traffic_text_ibwt_lcp.txt", "pmc_sq_text.txt", "pmc_sq_random.txt",
          "induction_level_durations.txt", "host_trace_random.txt", "host_trace_text.txt", "microbench_host_xfer.txt", "microbench_h2d_fresh.txt",

@@ -16,7 +16,7 @@ agg = collections.defaultdict(float); cnt = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"].split("(")[0][:44]
     agg[k] += float(r["Counter_Value"]); cnt[k] += 1
-for k in sorted(agg, key=lambda x: -agg[x])[:14]:
+for k in sorted(agg, key=lambda x: -agg[x])[:40]:
     if not k.startswith("void at::") and "rocclr" not in k:
         print(sys.argv[2], k, "calls", cnt[k], "sum_KiB", f"{agg[k]:.6g}", "per_call_KiB", f"{agg[k]/cnt[k]:.6g}")
 PY
