@@ -220,9 +220,7 @@ __device__ __forceinline__ u32 ind_fetch(const u8* __restrict__ text, u32 j)
     return v | ((j < 3u ? j : 3u) << 24);
 }
 
-#ifndef IND_ITEMS
 #define IND_ITEMS 16
-#endif
 #define IND_TILE (256u * IND_ITEMS)      // sources per tile: 256 threads x 16, wave-major rows of 64
 
 // start of a bucket's work
