@@ -121,8 +121,20 @@ namespace maniscalco
         std::int32_t forward_burrows_wheeler_transform(std::uint8_t * inputBegin, std::uint8_t * inputEnd)
         {
             std::int64_t sentinel = 0;
-            check(::msufsort_hip_forward_bwt_ctx(ctx(), inputBegin, static_cast<std::int64_t>(inputEnd - inputBegin), &sentinel, nullptr),
-                  "forward_burrows_wheeler_transform");
+            auto n = static_cast<std::int64_t>(inputEnd - inputBegin);
+            // large inputs: the streaming entry point - the BWT bytes of finished key ranges leave for the host while the rest is
+            // sorted (n bytes over PCIe, none of the rows) - on this instance's device, or on the devices MSUFSORT_DEVICES lists;
+            // text-like inputs are recognised there and take one two-stage build.  Small inputs: this instance's context
+            if (n >= (std::int64_t(32) << 20))
+            {
+                std::int32_t const own = 0;
+                char const * const env = std::getenv("MSUFSORT_DEVICES");
+                bool const listed = env != nullptr && *env != '\0';
+                pooled() = true;
+                check(::msufsort_hip_forward_bwt_multi(listed ? nullptr : &own, listed ? 0 : 1, inputBegin, n, &sentinel, nullptr, nullptr), "forward_burrows_wheeler_transform");
+            }
+            else
+                check(::msufsort_hip_forward_bwt_ctx(ctx(), inputBegin, n, &sentinel, nullptr), "forward_burrows_wheeler_transform");
             return static_cast<std::int32_t>(sentinel);
         }
 

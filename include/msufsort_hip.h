@@ -265,6 +265,13 @@ int msufsort_hip_bwt_from_sa_i64_dev(msufsort_hip_ctx* ctx, const uint8_t* d_tex
 int msufsort_hip_bwt_slice_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int64_t n, const void* d_sa_slice, int64_t lo, int64_t hi,
                                int32_t index_bytes, uint8_t* d_row_bytes_out, int64_t* sentinel_row);
 
+/* One process, the listed devices (as msufsort_hip_make_sa_multi: NULL / 0 = MSUFSORT_DEVICES, else all visible GPUs), host bytes
+ * in place: key-range shards, and what leaves a device is the BYTE in front of every suffix of a finished slice - n bytes over PCIe
+ * instead of 4 (n + 1), streamed while the remaining shards are sorted (nothing lands in the caller's buffer before every device has
+ * read the text from it).  Text-like and small inputs take msufsort_hip_forward_bwt on the first device. */
+int msufsort_hip_forward_bwt_multi(const int32_t* devices, int32_t n_dev, uint8_t* inout, int64_t n, int64_t* sentinel_row,
+                                   const msufsort_hip_opts* opts, msufsort_hip_timings* timings_out);
+
 /* ---- inverse BWT: replaces msufsort::reverse_burrows_wheeler_transform (cpp:1821-2096) ---- */
 int msufsort_hip_inverse_bwt(uint8_t* inout, int64_t n, int64_t sentinel_row,
                              const msufsort_hip_opts* opts);

@@ -47,7 +47,7 @@ SYMBOLS = [
     "msufsort_hip_validate_sa_dev", "msufsort_hip_debug_hist16_dev",
     "msufsort_hip_make_sa_i32_ctx", "msufsort_hip_forward_bwt_ctx", "msufsort_hip_inverse_bwt_ctx", "msufsort_hip_lcp_i32_ctx",
     "msufsort_hip_make_sa_i64", "msufsort_hip_make_sa_i64_ctx", "msufsort_hip_make_sa_i64_dev",
-    "msufsort_hip_make_sa_two_stage_sharded_dev", "msufsort_hip_bwt_slice_dev",
+    "msufsort_hip_make_sa_two_stage_sharded_dev", "msufsort_hip_bwt_slice_dev", "msufsort_hip_forward_bwt_multi",
 ]
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32)
 
@@ -118,6 +118,7 @@ def lib():
     L.msufsort_hip_make_sa_i64_ctx.argtypes = [vp, vp, i64, vp, C.POINTER(Opts)]
     L.msufsort_hip_make_sa_i64_dev.argtypes = [vp, vp, i64, vp, C.POINTER(Opts)]
     L.msufsort_hip_make_sa_two_stage_sharded_dev.argtypes = [vp, vp, i64, vp, vp, i64, EXCHANGE_FN, vp, C.POINTER(Opts)]
+    L.msufsort_hip_forward_bwt_multi.argtypes = [vp, i32, vp, i64, C.POINTER(i64), C.POINTER(Opts), C.POINTER(Timings)]
     L.msufsort_hip_bwt_slice_dev.argtypes = [vp, vp, i64, vp, i64, i64, i32, vp, C.POINTER(i64)]
     L.msufsort_hip_forward_bwt_ctx.argtypes = [vp, vp, i64, C.POINTER(i64), C.POINTER(Opts)]
     L.msufsort_hip_inverse_bwt_ctx.argtypes = [vp, vp, i64, i64, C.POINTER(Opts)]

@@ -89,6 +89,18 @@ def forward_burrows_wheeler_transform(data, threads: int = 1, *, device: int = 0
     return t, int(s.value)
 
 
+def forward_burrows_wheeler_transform_multi(data, devices=None, *, n_shards: int = 0, force_wide: bool = False, text_rounds: int = 0, timings: bool = False):
+    """msufsort_hip_forward_bwt_multi: one process, the listed GPUs; the BWT bytes of finished key-range slices stream to the host
+    while the remaining shards are sorted.  Returns (bwt bytes, sentinel row[, timings])."""
+    t = _u8(data).copy()
+    s = C.c_int64(0)
+    o = _opts(0, 0, text_rounds, 0, n_shards, force_wide)
+    tm = Timings()
+    dv = (C.c_int32 * len(devices))(*devices) if devices else None
+    _lib.check(_lib.lib().msufsort_hip_forward_bwt_multi(dv, len(devices) if devices else 0, t.ctypes.data, t.size, C.byref(s), C.byref(o), C.byref(tm)), "forward_bwt_multi")
+    return (t, int(s.value), tm) if timings else (t, int(s.value))
+
+
 def reverse_burrows_wheeler_transform(bwt, sentinel_index: int, threads: int = 1, *, device: int = 0) -> np.ndarray:
     """maniscalco::reverse_burrows_wheeler_transform (h:466-476): returns the original text."""
     t = _u8(bwt).copy()

@@ -1222,3 +1222,45 @@ def test_hist16_dense_mode_small_alphabets(M, kind):
     assert bool(torch.equal(sa, ref)), (kind, "sharded")
     del sa, ref, d
     ctx.trim(); torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_forward_bwt_multi_streams_bytes(M, oracle_mod, monkeypatch, devices):
+    """msufsort_hip_forward_bwt_multi (host bytes in place, one process, the listed devices): key-range shards whose BWT BYTES stream to
+    the host as the slices finish - n bytes over PCIe, none of the rows; the shard that holds the row of suffix 0 is known from the plan,
+    so the others can leave at once (rows below it at r, above it at r - 1).  Bytes + sentinel equal to the reference's: random bytes
+    (the row of suffix 0 in a middle shard), texts that begin with the smallest / the largest byte value (first / last shard), tandem DNA
+    below the text-like sample threshold (shards stop unresolved: distributed doubling first), a text (one two-stage build instead),
+    int64 rows forced (wide engine)."""
+    monkeypatch.setenv("MSUFSORT_ALLOW_DUPLICATE_DEVICES", "1")
+
+    def want_bwt(t, own_rows=False):
+        # the transform read off a suffix array: the reference's (4 threads) - or, for the block repeated twelve times, this engine's
+        # own rows after the on-device checker has accepted them (the reference needs minutes for common prefixes of megabytes)
+        if own_rows:
+            sa = M.make_suffix_array_multi(t, [0], text_rounds=1)
+            ctx = M.DeviceContext(0)
+            import torch
+            assert ctx.validate_sa(_dev(M, t), t.size, torch.from_numpy(sa).cuda()) == 0
+            sa = sa.astype(np.int64)
+        else:
+            sa = (oracle_mod.ref_make_suffix_array(t, 4) if oracle_mod.have_reference() else oracle_mod.make_suffix_array(t)).astype(np.int64)
+        s = int(np.nonzero(sa == 0)[0][0])
+        keep = np.ones(sa.size, bool); keep[s] = False
+        return t[sa[keep] - 1], s
+    n = (34 << 20) + 77
+    r = gen.random_bytes(n, 61)
+    lo = r.copy(); lo[:8] = 0; lo[8] = 1
+    hi = r.copy(); hi[:8] = 255
+    cases = [("random", r, {}), ("starts low", lo, {}), ("starts high", hi, {}), ("text", gen.text_bytes(n, 62), {}),
+             ("random, 5 shards", r, {"n_shards": 5}), ("random, wide", r[: (33 << 20)], {"force_wide": True})]
+    for name, t, kw in cases:
+        wb, ws = want_bwt(t)
+        b, s = M.forward_burrows_wheeler_transform_multi(t, devices, **kw)
+        assert s == ws and (b == wb).all(), (name, devices)
+    # deep ties in shards: many byte values (so that the sample does not call it a text) with long repeats
+    base = gen.random_bytes(3 << 20, 63)
+    t = np.concatenate([base] * 12)[: (34 << 20) + 5]
+    wb, ws = want_bwt(t, own_rows=True)
+    b, s, tm = M.forward_burrows_wheeler_transform_multi(t, devices, text_rounds=1, timings=True)
+    assert s == ws and (b == wb).all() and tm.doubling_rounds >= 1
