@@ -134,6 +134,8 @@ struct msufsort_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;            // second stream of the streaming host path (slices leave while the next shard is sorted)
+    hipStream_t gather_stream = nullptr;          // msufsort_hip_forward_bwt_multi: the BWT bytes of a finished slice are gathered (random text reads)
+                                                  // while the next shard is sorted (sequential bandwidth) - different bottlenecks, one GPU
     bool attrs_set = false;
     // workspace
     DevBuf rec[3], pool_rec[2], pool_hdr[2];
@@ -1681,6 +1683,7 @@ void msufsort_hip_ctx_destroy(msufsort_hip_ctx* c)
     if (c->h_upd) (void)hipHostFree(c->h_upd);
     if (c->h_ind) (void)hipHostFree(c->h_ind);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->gather_stream) (void)hipStreamDestroy(c->gather_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
