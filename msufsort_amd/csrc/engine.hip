@@ -96,6 +96,7 @@ struct Switches {
     int key1 = 0;                // MSUFSORT_HIP_KEY1: -1 the first gather round always gathers; 0 small alphabets get its key from k_scatter0 when the caller has
                                  // seen few byte values; 1 whenever the alphabet turns out small
     bool host_trace = false;     // MSUFSORT_HIP_HOST_TRACE: timeline of the host-pointer entry points on stderr
+    int isa_window_kib = 256 << 10;      // MSUFSORT_HIP_ISA_WINDOW_MIB / _KIB (tests): piece of the rank array one pass of its build writes into (0: one pass)
     void load()
     {
         auto on = [](const char* k) { return getenv(k) != nullptr; };
@@ -115,6 +116,7 @@ struct Switches {
         sync_debug = num("MSUFSORT_HIP_SYNC_DEBUG", 0);
         key1 = num("MSUFSORT_HIP_KEY1", 0);
         host_trace = on("MSUFSORT_HIP_HOST_TRACE");
+        isa_window_kib = std::max(0, on("MSUFSORT_HIP_ISA_WINDOW_KIB") ? num("MSUFSORT_HIP_ISA_WINDOW_KIB", 0) : std::min(1 << 20, num("MSUFSORT_HIP_ISA_WINDOW_MIB", 256)) << 10);
     }
 };
 
@@ -1205,6 +1207,33 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
                 // switch to prefix doubling: build the inverse suffix array
                 TRY(c->isa.ensure((size_t)(n + 1) * 4));
                 u32* isa = c->isa.as<u32>();
+                // ONE random rank write per suffix (round 5; before: every suffix by k_isa_init, then the ~80 % that are still tied AGAIN by
+                // k_isa_pool / k_isa_segs - 486 M random 4-byte writes, 15.8 of the 60 ms of a 256 MiB tandem-repeat DNA): the tie-group head
+                // of every row is filled in first, with sequential writes (the kernels the sharded exit publishes its groups with), then
+                // isa[SA[r]] = 1 + rank0 + head(r) - what the sharded builds do with k_isa_from_slice
+                if (c->grp_full.ensure((size_t)std::max<u64>(ms, 1) * 4) == MSUFSORT_HIP_OK) {
+                    u32* grp = c->grp_full.as<u32>();
+                    hipLaunchKernelGGL(k_grp_iota, dim3(grid_for(ms)), dim3(256), 0, st, grp, ms, 0u);
+                    if (actP) hipLaunchKernelGGL(k_grp_pool, dim3(grid_for(actP)), dim3(256), 0, st, c->pool_hdr[cur].as<u64>(), counters, curP, grp, 0u);
+                    for (int k = 0; k < 3; ++k) {
+                        const u32 cnt = c->h_counters[curL + k];
+                        if (cnt) hipLaunchKernelGGL(k_grp_segs, dim3(cnt), dim3(256), 0, st, c->lists[cur][k].as<Desc>(), cnt, grp, 0u);
+                    }
+                    if (u32 cnt = c->h_counters[curL + 3]) hipLaunchKernelGGL(k_grp_segs, dim3(cnt), dim3(256), 0, st, c->large_round[cur].as<Desc>(), cnt, grp, 0u);
+                    // ... a pass per 256 MiB window of the rank array: the random writes of a pass then land in a piece the memory-side
+                    // cache holds (70 G writes/s instead of the 27 G/s HBM takes partial lines at); a pass reads the rows again (4 bytes
+                    // per suffix: 0.27 ms per GiB).  Measured on tandem-repeat DNA, 2^27 / 2^28 / 2^29 / 2^30 bytes: 29.9 -> 28.2,
+                    // 55.4 -> 50.4, 107.1 -> 96.7, 217.6 -> 212.4 ms; 128 and 512 MiB windows lose at every size
+                    const u64 wl = (u64)c->sw.isa_window_kib << 8;      // suffixes per window
+                    if (wl > 0 && n > wl && n / wl <= 4096) {
+                        for (u64 lo = 0; lo < n; lo += wl)
+                            hipLaunchKernelGGL(k_isa_from_slice_win, dim3(grid_for(ms)), dim3(256), 0, st, sa_local, grp, ms, (u32)(rank0 + 1), isa, (u32)lo, (u32)std::min<u64>(lo + wl, n));
+                    } else
+                    hipLaunchKernelGGL(k_isa_from_slice<false>, dim3(grid_for(ms)), dim3(256), 0, st, sa_local, grp, ms, rank0 + 1, isa);
+                    if (z) hipLaunchKernelGGL(k_isa_zero_tail, dim3(grid_for(z)), dim3(256), 0, st, isa, (u32)n, (u32)z);
+                    DBG("isa from group heads");
+                } else {
+                (void)hipGetLastError();
                 hipLaunchKernelGGL(k_isa_init, dim3(grid_for(m + z)), dim3(256), 0, st, sa_local, counters, isa, (u32)n, (u32)z);
                 DBG("k_isa_init");
                 if (actP) hipLaunchKernelGGL(k_isa_pool, dim3(grid_for(actP)), dim3(256), 0, st, c->pool_rec[cur].as<u64>(), c->pool_hdr[cur].as<u64>(), counters, curP, isa);
@@ -1214,6 +1243,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
                     if (cnt) hipLaunchKernelGGL(k_isa_segs, dim3(cnt), dim3(256), 0, st, bufs, c->lists[cur][k].as<Desc>(), cnt, counters, isa);
                 }
                 if (u32 cnt = c->h_counters[curL + 3]) hipLaunchKernelGGL(k_isa_segs, dim3(cnt), dim3(256), 0, st, bufs, c->large_round[cur].as<Desc>(), cnt, counters, isa);
+                }
                 DBG("isa build");
                 R.mode = MODE_ISA;
                 R.isa32 = isa;

@@ -2610,6 +2610,12 @@ __global__ __launch_bounds__(256) void k_isa_init(const u32* __restrict__ sa_loc
     }
 }
 
+// ranks of the trailing-zero suffixes (they are the z smallest, shortest first): isa[n - 1 - j] = j + 1
+__global__ __launch_bounds__(256) void k_isa_zero_tail(u32* __restrict__ isa, u32 n, u32 z)
+{
+    for (u64 j = (u64)blockIdx.x * 256u + threadIdx.x; j < z; j += (u64)gridDim.x * 256u) isa[n - 1u - (u32)j] = (u32)j + 1u;
+}
+
 __global__ __launch_bounds__(256) void k_isa_pool(const u64* __restrict__ pool_rec, const u64* __restrict__ pool_hdr,
                                                   const u32* __restrict__ counters, u32 cnt_idx, u32* __restrict__ isa)
 {
@@ -2674,6 +2680,17 @@ __global__ __launch_bounds__(256) void k_isa_from_slice(const typename Wd<W>::sa
 {
     for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r < rows; r += (u64)gridDim.x * 256u)
         isa[sa_rows[r]] = (typename Wd<W>::sa_t)(slice_lo + grp[r]);
+}
+
+// The same, restricted to the suffixes of one window [lo, hi) of the text: a pass per window keeps the random writes inside a
+// piece of the rank array that the memory-side cache holds (narrow builds' switch to prefix doubling)
+__global__ __launch_bounds__(256) void k_isa_from_slice_win(const u32* __restrict__ sa_rows, const u32* __restrict__ grp, u64 rows, u32 slice_lo,
+                                                            u32* __restrict__ isa, u32 lo, u32 hi)
+{
+    for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r < rows; r += (u64)gridDim.x * 256u) {
+        const u32 s = __builtin_nontemporal_load(sa_rows + r);
+        if (s >= lo && s < hi) isa[s] = slice_lo + grp[r];
+    }
 }
 
 // Rebuild tiny pool / descriptor lists from (rows, grp): the LAST row of every group emits it.  Segment records use

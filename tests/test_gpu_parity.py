@@ -306,6 +306,26 @@ def test_tandem_progressions(M, oracle_mod, monkeypatch):
     assert sum(h > 0 for h in hits) >= 10, hits          # the shortcut really ran on most of these inputs
 
 
+@pytest.mark.parametrize("window_kib", [0, 64, 1000])
+def test_rank_array_built_in_windows(M, oracle_mod, monkeypatch, window_kib):
+    """The switch to prefix doubling (narrow, one GPU) builds the rank array from the rows' group heads with one write per suffix,
+    a pass per window of the array: one pass, many small windows, windows that do not divide n - incl. trailing
+    zero bytes (their ranks are written apart) and pool / small / large tie groups; rows equal to the reference's."""
+    import torch
+    monkeypatch.setenv("MSUFSORT_HIP_ISA_WINDOW_KIB", str(window_kib))
+    inputs = _deep_inputs() + [np.concatenate([np.tile(gen.dna_bytes(1000, 4), 700), np.zeros(33, np.uint8)])]
+    for t in inputs:
+        n = t.size
+        d = _dev(M, t)
+        ctx = M.DeviceContext(0)
+        sa = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        for rounds in (1, 2):
+            sa.fill_(-1)
+            ctx.make_sa(d, n, sa, two_stage=-1, text_rounds=rounds)
+            assert ctx.timings().doubling_rounds >= 1
+            assert (sa.cpu().numpy() == _want(oracle_mod, t)).all(), (n, window_kib, rounds)
+
+
 @pytest.mark.parametrize("shards", [2, 3])
 def test_sharded_doubling_pieces(M, oracle_mod, shards):
     """The same flow through the per-shard C-ABI pieces a multi-process job uses (msufsort_amd/dist.py): shard build with
