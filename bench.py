@@ -705,7 +705,10 @@ def main():
     # build, and `value` the throughput a caller sees who needs each array before asking for the next (round-3 review:
     # a strong-scaling curve of a pipelined rate would flatter).
     d_bstar = torch.empty(n // 2 + 2, dtype=torch.int32, device=dev) if two_stage_possible else None
-    ts_stats, bwt_stats = {}, {}
+    ts_stats, bwt_stats, hist_stats = {}, {}, {}
+    # the histogram a sharded build starts with is counted 1/N per rank (dist.plan_sharded): its all-reduce and all-gather get a
+    # communicator of their own, so that in the pipelined figure they do not queue behind the previous build's slices
+    hist_group = dist.new_group(ranks=list(range(backend_world))) if mdist.sharded_hist_enabled(world, n) else None
 
     def build_rows(out, gather_rows=True):
         """True: the two-stage sharded build ran (every rank holds ALL rows); False: the sort-all shards ran."""
@@ -714,7 +717,7 @@ def main():
         if d_bstar is not None and ts_stats.get("two_stage_status") != 1 and mdist.build_sa_two_stage_sharded(ctx, d_text, n, out, d_bstar, rank, world, dist, two_stage=args.two_stage, stats=ts_stats):
             return True
         mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp=d_grp, overlap=False, index_bytes=index_bytes, state=shard_state,
-                               gather_rows=gather_rows)
+                               gather_rows=gather_rows, stats=hist_stats, hist_group=hist_group)
         return False
 
     def step():
@@ -737,7 +740,8 @@ def main():
     def step_pipelined():
         out = sa_bufs[pending["k"] & 1]
         pending["k"] += 1
-        works = mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp=d_grp, overlap=True, index_bytes=index_bytes, state=shard_state)
+        works = mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp=d_grp, overlap=True, index_bytes=index_bytes, state=shard_state,
+                                       stats=hist_stats, hist_group=hist_group)
         mdist.wait_all(pending["works"], pending["buf"])        # the previous exchange overlapped with this build
         pending["works"], pending["buf"], pending["last"] = works, out, out
 
@@ -797,7 +801,8 @@ def main():
         for _ in range(2):
             barrier()
             a = time.perf_counter()
-            w = mdist.build_sa_sharded(ctx, d_text, n, sa_bufs[0], rank, world, dist, bounds, d_grp=d_grp, overlap=True, index_bytes=index_bytes, state=shard_state)
+            w = mdist.build_sa_sharded(ctx, d_text, n, sa_bufs[0], rank, world, dist, bounds, d_grp=d_grp, overlap=True, index_bytes=index_bytes, state=shard_state,
+                                       stats=hist_stats, hist_group=hist_group)
             torch.cuda.synchronize(dev)
             b = time.perf_counter()
             mdist.wait_all(w, sa_bufs[0])
@@ -886,6 +891,8 @@ def main():
             out["forward_bwt"] = dict(bwt_stats, sentinel_row=pending["sentinel"], MBps=round(n / (op_ms["fbwt"] / K) / 1e3, 1) if op_ms["fbwt"] else None,
                                       exchanged="nothing beyond the sorted-B* slices (every rank induced all rows)" if used_two_stage else
                                       f"{int(n * (world - 1) / world)} bytes per rank (n/G-byte slices) instead of {int(index_bytes * (n + 1) * (world - 1) / world)} (rows)")
+        out["histogram"] = (f"counted 1/{world} per rank, one all-reduce + one all-gather per build ({hist_stats['sharded_hist']} builds)" if hist_stats.get("sharded_hist")
+                            else "replicated: every rank counts the whole text (below the size where counting 1/N pays - MSUFSORT_DIST_SHARDED_HIST=1 forces it -, a shard boundary inside a heavy two-byte key, or the two-stage build)")
         if shard_state.stats:
             out["doubling"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in shard_state.stats.items()}
         if ts_stats:

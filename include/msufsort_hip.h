@@ -216,6 +216,29 @@ int msufsort_hip_make_sa_two_stage_sharded_dev(msufsort_hip_ctx* ctx, uint8_t* d
 int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
                                   int32_t n_shards, int64_t* bounds);
 
+/* The 16-bit histogram computed SHARDED (SURVEY.md section 8(e) "Partitioning": "if computed sharded: one all-reduce" of
+ * 65,536 counters; the reference counts per thread and sums, count_suffixes msufsort.cpp:1496-1521, :1603-1630).  A shard
+ * build (msufsort_hip_make_sa_shard_*_dev) otherwise starts with a pass over the WHOLE text on every rank.  Three calls per
+ * build and rank, with two small collectives of the caller's in between (msufsort_amd/dist.py: plan_sharded):
+ *   1. hist_part:  counts the two-byte keys of the suffixes that start in this part's scatter stripes of the text (stripes
+ *      [first, end) of `total`: stripes_out[0..2] = total, first, end; part p of P owns stripes [total p / P, total (p + 1) / P))
+ *      and writes the part's totals to d_hist_out (65,536 x uint64, key T[i] << 8 | T[i+1]).    -> all-reduce (SUM) of d_hist_out
+ *   2. hist_plan:  plans the n_shards key ranges from the summed histogram exactly as msufsort_hip_shard_bounds_dev would
+ *      (bounds_out[n_shards + 1], suffix-array rows) and writes, for EVERY shard g, the first-byte counts of my stripes over g's key
+ *      range - what g's scatter needs to place its records: d_sums_out[g][stripes_per_part][256] (uint32; rows beyond my stripe
+ *      count stay zero).  Returns MSUFSORT_HIP_HIST_NEEDS_REPLICA when a shard boundary has to fall INSIDE a heavy two-byte key
+ *      (DNA, text: the plan then needs a deeper histogram of that key): nothing is kept, the shard build computes its own
+ *      histogram as before - on every rank alike, since all ranks hold the same sum.      -> all-gather of d_sums_out
+ *   3. hist_install: the counts of ALL stripes over MY shard's key range, d_stripe_sums[total][256], assembled from the gathered
+ *      blocks (stripes in text order).  The next msufsort_hip_make_sa_shard_*_dev call for this text, n_shards and shard runs
+ *      without a histogram pass; any other call drops the state. */
+#define MSUFSORT_HIP_HIST_NEEDS_REPLICA 3
+int msufsort_hip_hist_part_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n, int32_t part, int32_t parts,
+                               uint64_t* d_hist_out /* 65536 */, int32_t* stripes_out /* 3, may be NULL */);
+int msufsort_hip_hist_plan_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n, int32_t n_shards, const uint64_t* d_hist_sum,
+                               uint32_t* d_sums_out, int32_t stripes_per_part, int64_t* bounds_out);
+int msufsort_hip_hist_install_dev(msufsort_hip_ctx* ctx, int32_t shard, const uint32_t* d_stripe_sums, int32_t stripes);
+
 /* 64-bit output (callers with 64-bit index types; the reference's suffix_index is int32 with two
  * flag bits, msufsort.h:47,84-93, i.e. n < 2^30).  n <= 2^31 - 2: the int32 rows, widened on the device.  Larger inputs, up to
  * 2^40 - 2 bytes: the wide engine - 8-byte records (24-bit key, 40-bit index), as many logical shards as the workspace

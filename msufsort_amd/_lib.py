@@ -48,6 +48,7 @@ SYMBOLS = [
     "msufsort_hip_make_sa_i32_ctx", "msufsort_hip_forward_bwt_ctx", "msufsort_hip_inverse_bwt_ctx", "msufsort_hip_lcp_i32_ctx",
     "msufsort_hip_make_sa_i64", "msufsort_hip_make_sa_i64_ctx", "msufsort_hip_make_sa_i64_dev",
     "msufsort_hip_make_sa_two_stage_sharded_dev", "msufsort_hip_bwt_slice_dev", "msufsort_hip_forward_bwt_multi",
+    "msufsort_hip_hist_part_dev", "msufsort_hip_hist_plan_dev", "msufsort_hip_hist_install_dev",
 ]
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32)
 
@@ -104,6 +105,9 @@ def lib():
     L.msufsort_hip_bwt_from_sa_i64_dev.argtypes = [vp, vp, i64, vp, vp, C.POINTER(i64)]
     L.msufsort_hip_shard_bounds_dev.argtypes = [vp, vp, i64, i32, C.POINTER(i64)]
     L.msufsort_hip_plan_cuts.argtypes = [vp, i64, i64, i32, vp, vp]
+    L.msufsort_hip_hist_part_dev.argtypes = [vp, vp, i64, i32, i32, vp, C.POINTER(i32)]
+    L.msufsort_hip_hist_plan_dev.argtypes = [vp, vp, i64, i32, vp, vp, i32, C.POINTER(i64)]
+    L.msufsort_hip_hist_install_dev.argtypes = [vp, i32, vp, i32]
     L.msufsort_hip_forward_bwt.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(Opts)]
     L.msufsort_hip_forward_bwt_dev.argtypes = [vp, vp, i64, vp, C.POINTER(i64), C.POINTER(Opts)]
     L.msufsort_hip_bwt_from_sa_dev.argtypes = [vp, vp, i64, vp, vp, C.POINTER(i64)]

@@ -222,6 +222,29 @@ class DeviceContext:
         _lib.check(self._L.msufsort_hip_shard_bounds_dev(self._h, self._ptr(d_text), n, n_shards, b), "shard_bounds")
         return [int(x) for x in b]
 
+    # ---- the 16-bit histogram computed sharded (include/msufsort_hip.h; driver: dist.plan_sharded) ----
+    def hist_part(self, d_text, n: int, part: int, parts: int, d_hist):
+        """Counts my stripes of the text into d_hist (65,536 x int64, device).  Returns (stripes in all, my first, my end)."""
+        assert d_hist.numel() == 65536 and d_hist.element_size() == 8
+        st = (C.c_int32 * 3)()
+        _lib.check(self._L.msufsort_hip_hist_part_dev(self._h, self._ptr(d_text), n, part, parts, self._ptr(d_hist), st), "hist_part")
+        return int(st[0]), int(st[1]), int(st[2])
+
+    def hist_plan(self, d_text, n: int, n_shards: int, d_hist_sum, d_sums):
+        """d_sums: [n_shards][stripes_per_part][256] int32 (device).  Returns the slice bounds, or None when the plan needs a
+        replicated histogram after all (a shard boundary inside a heavy two-byte key: DNA, text)."""
+        assert d_sums.dim() == 3 and d_sums.shape[0] == n_shards and d_sums.shape[2] == 256 and d_sums.element_size() == 4 and d_sums.is_contiguous()
+        b = (C.c_int64 * (n_shards + 1))()
+        r = self._L.msufsort_hip_hist_plan_dev(self._h, self._ptr(d_text), n, n_shards, self._ptr(d_hist_sum), self._ptr(d_sums), int(d_sums.shape[1]), b)
+        if r == 3:
+            return None
+        _lib.check(r, "hist_plan")
+        return [int(x) for x in b]
+
+    def hist_install(self, shard: int, d_stripe_sums):
+        assert d_stripe_sums.dim() == 2 and d_stripe_sums.shape[1] == 256 and d_stripe_sums.element_size() == 4 and d_stripe_sums.is_contiguous()
+        _lib.check(self._L.msufsort_hip_hist_install_dev(self._h, shard, self._ptr(d_stripe_sums), int(d_stripe_sums.shape[0])), "hist_install")
+
     def make_sa_shard(self, d_text, n: int, d_slice, capacity: int, shard: int, n_shards: int, *, verbose=0, text_rounds=0):
         o = _opts(self.device, verbose, text_rounds, shard, n_shards)
         lo, hi = C.c_int64(0), C.c_int64(0)

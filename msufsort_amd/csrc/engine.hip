@@ -161,6 +161,21 @@ struct msufsort_hip_ctx {
     int64_t sub_key = -1;                         // which key sub_partial describes (-1: none); valid for the current text only
     DevBuf grp_full, grp_prev, upd, upd_cnt;      // single-process sharded builds: tie-group heads (all rows), their copy at the
                                                   // start of a doubling step, rank updates of one row window
+    // Histogram computed sharded (multi-GPU jobs, SURVEY 8(e) "Partitioning"; msufsort_hip_hist_part_dev / _hist_plan_dev /
+    // _hist_install_dev): this rank counted the stripes [s0, s1) only; the all-reduced totals, the plan made from them and the
+    // first-byte sums of ALL stripes over one shard's key range wait here for that shard's build (one use).
+    struct SharedHist {
+        int stage = 0;               // 1: part counted, 2: planned, 3: stripe sums installed
+        const u8* text = nullptr; u64 n = 0, z = 0;
+        u32 s0 = 0, s1 = 0;          // my stripes
+        u32 per = 1;                 // histogram chunks per stripe in MY partials (finer than the replicated histogram's: the part still fills the chip)
+        int n_shards = 0, shard = -1;
+        bool small_alphabet = false;
+        std::vector<u64> cuts, rows, rank0;
+        void reset() { stage = 0; text = nullptr; shard = -1; }
+    } xh;
+    DevBuf xh_hist, xh_sums;         // 65,536 x u64 totals; [stripes][256] x u32
+    bool ext_stripe_sums = false;    // the next run_scan takes xh_sums instead of reducing hist_partial
     u32* h_counters = nullptr;   // pinned
     u64* h_hist = nullptr;       // pinned, 65536 (the 16-bit histogram on the host: shard planning)
     unsigned long long* h_upd = nullptr;   // pinned, 2
@@ -274,7 +289,7 @@ struct msufsort_hip_ctx {
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
         h17_partial.release(); h17_fb.release(); h17.release(); child_start17.release(); child_cnt17.release(); cursor17.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
-        grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release();
+        grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release(); xh_hist.release(); xh_sums.release(); xh.reset();
         sub_partial.release(); sub_hist.release(); sub_saved.release(); sub_key = -1;
         ind_sbits.release(); sel_partial.release(); sel_hist.release(); ind_sstar.release();
         ind_pc.release(); ind_tiles.release(); ind_state.release(); ind_tables.release();
@@ -427,7 +442,7 @@ int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
     TRY(plan_stripes(c, m, &hchunks));
     const u32 per = c->hist_per;
     const u64 chunk_len = c->chunk_len;
-    hipLaunchKernelGGL(k_hist16<0>, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>(), 0u, (const unsigned short*)nullptr);
+    hipLaunchKernelGGL(k_hist16<0>, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, (u32)(chunk_len / per), hchunks, c->hist_partial.as<u32>(), 0u, (const unsigned short*)nullptr, 0u);
     hipLaunchKernelGGL(k_reduce16<W>, dim3(256), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), hchunks, c->hist.as<typename Wd<W>::hist_t>());
     HIP_TRY(hipGetLastError());
     return MSUFSORT_HIP_OK;
@@ -443,7 +458,7 @@ int run_subhist(msufsort_hip_ctx* c, const u8* d_text, u64 m, u32 key)
     TRY(c->sub_partial.ensure((size_t)hchunks * 65536 * 4));
     TRY(c->sub_hist.ensure(65536 * 8));
     hipLaunchKernelGGL(k_hist16<1>, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, c->chunk_len / c->hist_per, hchunks, c->sub_partial.as<u32>(),
-                       (key >> 8) | ((key & 255u) << 8), (const unsigned short*)nullptr);
+                       (key >> 8) | ((key & 255u) << 8), (const unsigned short*)nullptr, 0u);
     hipLaunchKernelGGL(k_reduce16<W>, dim3(256), dim3(256), 0, c->stream, c->sub_partial.as<u32>(), hchunks, c->sub_hist.as<typename Wd<W>::hist_t>());
     HIP_TRY(hipGetLastError());
     c->sub_key = (int64_t)key;
@@ -487,7 +502,12 @@ int run_scan(msufsort_hip_ctx* c, const u8* d_text, u64 m, u64 lo32, u64 hi32, u
                        c->child_start.as<u32>(), c->child_cnt.as<u32>(), c->cursor.as<u32>(), c->counters.as<u32>());
     hipLaunchKernelGGL(k_alphabet<W>, dim3(1), dim3(256), 0, c->stream, c->hist.as<typename Wd<W>::hist_t>(), c->alpha.as<u8>(), c->counters.as<u32>());
     (void)hipMemsetAsync(c->stripe_sums.p, 0, (size_t)c->nchunks * 256 * 4, c->stream);
-    if (from17) hipLaunchKernelGGL(k_stripe_sums17, dim3(c->nchunks), dim3(256), 0, c->stream, c->h17_fb.as<u32>(), c->h17_q, c->stripe_sums.as<u32>());
+    if (c->ext_stripe_sums) {      // sharded histogram: the other ranks counted most stripes, the sums came through the all-gather
+        c->ext_stripe_sums = false;
+        if (from17 || c->sel_bits || nfix) { set_error("stripe sums from a sharded histogram do not fit this build"); return MSUFSORT_HIP_ERR_INTERNAL; }
+        HIP_TRY(hipMemcpyAsync(c->stripe_sums.p, c->xh_sums.p, (size_t)c->nchunks * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
+    else if (from17) hipLaunchKernelGGL(k_stripe_sums17, dim3(c->nchunks), dim3(256), 0, c->stream, c->h17_fb.as<u32>(), c->h17_q, c->stripe_sums.as<u32>());
     else hipLaunchKernelGGL(k_stripe_sums, dim3(c->nchunks * 4), dim3(256), 0, c->stream, partial_counts, c->hist_per, klo, khi, c->stripe_sums.as<u32>());
     hipLaunchKernelGGL(k_stripes, dim3(256), dim3(128), 0, c->stream, c->stripe_sums.as<u32>(), c->nchunks,
                        c->seg0_base.as<u32>(), c->cursor0.as<u32>());
@@ -1855,6 +1875,109 @@ int msufsort_hip_shard_bounds_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t 
     return MSUFSORT_HIP_OK;
 }
 
+// ---- the 16-bit histogram computed sharded (SURVEY 8(e) "Partitioning": "if computed sharded: one all-reduce") ----
+int msufsort_hip_hist_part_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t part, int32_t parts, uint64_t* d_hist_out, int32_t* stripes_out)
+{
+    if (!c || !d_text || !d_hist_out || n < 1 || parts < 1 || part < 0 || part >= parts) return MSUFSORT_HIP_ERR_BAD_ARG;
+    TRY(check_n64(n));
+    HIP_TRY(hipSetDevice(c->device));
+    c->xh.reset();
+    TRY(zero_pad(c, d_text, (u64)n));
+    u64 z = 0;
+    TRY(trailing_zeros(c, d_text, (u64)n, &z));
+    const u64 m = (u64)n - z;
+    HIP_TRY(hipMemsetAsync(d_hist_out, 0, 65536 * 8, c->stream));
+    u32 s0 = 0, s1 = 0, ns = 0;
+    if (m > 0) {
+        u32 hchunks = 0;
+        TRY(plan_stripes(c, m, &hchunks));
+        ns = c->nchunks;
+        s0 = (u32)((u64)ns * (u32)part / (u32)parts); s1 = (u32)((u64)ns * ((u32)part + 1) / (u32)parts);
+        // one workgroup per histogram chunk: a part of the stripes is cut into as many chunks as the whole text would be (>= 64 KiB each)
+        u32 per = c->hist_per;
+        while ((u64)(s1 - s0) * per < 256 && c->chunk_len / (per * 2) >= 65536 && (c->chunk_len % (per * 2 * 16)) == 0) per *= 2;
+        c->xh.per = per;
+        const u32 c0 = s0 * per, c1 = s1 * per;
+        if (c1 > c0) {
+            TRY(c->hist_partial.ensure((size_t)std::max<u32>(c1 - c0, 256u) * 65536 * 4));
+            hipLaunchKernelGGL(k_hist16<0>, dim3(c1 - c0), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, (u32)(c->chunk_len / per), c1, c->hist_partial.as<u32>(), 0u,
+                               (const unsigned short*)nullptr, c0);
+            hipLaunchKernelGGL(k_reduce16_part, dim3(256), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), c1 - c0, reinterpret_cast<u64*>(d_hist_out));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    if (stripes_out) { stripes_out[0] = (int32_t)ns; stripes_out[1] = (int32_t)s0; stripes_out[2] = (int32_t)s1; }
+    c->xh.stage = 1; c->xh.text = d_text; c->xh.n = (u64)n; c->xh.z = z; c->xh.s0 = s0; c->xh.s1 = s1;
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_hist_plan_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, int32_t n_shards, const uint64_t* d_hist_sum,
+                               uint32_t* d_sums_out, int32_t stripes_per_part, int64_t* bounds_out)
+{
+    if (!c || !d_text || !d_hist_sum || !d_sums_out || !bounds_out || n_shards < 1 || stripes_per_part < 0) return MSUFSORT_HIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    auto& x = c->xh;
+    if (x.stage != 1 || x.text != d_text || x.n != (u64)n) { x.reset(); set_error("hist_plan: no histogram part of this text in the context (call msufsort_hip_hist_part_dev first)"); return MSUFSORT_HIP_ERR_BAD_ARG; }
+    if ((int32_t)(x.s1 - x.s0) > stripes_per_part) { x.reset(); set_error("hist_plan: %u stripes in my part, room for %d", x.s1 - x.s0, stripes_per_part); return MSUFSORT_HIP_ERR_BAD_ARG; }
+    const u64 z = x.z, m = (u64)n - z;
+    c->sw.load();
+    TRY(c->xh_hist.ensure(65536 * 8));
+    HIP_TRY(hipMemcpyAsync(c->h_hist, d_hist_sum, 65536 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->xh_hist.p, d_hist_sum, 65536 * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_sums_out, 0, (size_t)n_shards * (size_t)stripes_per_part * 256 * 4, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<u64> bs(65537);
+    bs[0] = 0;
+    for (u32 k = 0; k < 65536; ++k) bs[k + 1] = bs[k] + c->h_hist[k];
+    if (bs[65536] != m) { x.reset(); set_error("hist_plan: the summed histogram counts %llu suffixes, the text has %llu", (unsigned long long)bs[65536], (unsigned long long)m); return MSUFSORT_HIP_ERR_BAD_ARG; }
+    {
+        u32 nv = 0;
+        for (u32 b = 0; b < 256; ++b) nv += bs[(b + 1) * 256] != bs[b * 256];
+        x.small_alphabet = nv <= 83;
+    }
+    // the plan of plan_shards, two-byte keys only: a cut that would be refined inside a heavy key (DNA, text) needs the
+    // per-stripe counts of that key's deeper histogram from every rank - those inputs keep the replicated histogram
+    x.cuts.assign(n_shards + 1, 0); x.rows.assign(n_shards + 1, 0); x.rank0.assign(n_shards + 1, z);
+    x.cuts[n_shards] = 1ull << 32; x.rows[n_shards] = (u64)n + 1;
+    const u64 tol = std::max<u64>(m / ((u64)n_shards * 16), 1);
+    for (int g = 1; g < n_shards; ++g) {
+        const u64 target = (u64)((unsigned __int128)m * (u64)g / (u64)n_shards);
+        const u32 k = (u32)(std::lower_bound(bs.begin(), bs.begin() + 65536, target) - bs.begin());
+        if (!c->sw.no_refine && k > 0 && bs[k] - target > tol) { x.reset(); return MSUFSORT_HIP_HIST_NEEDS_REPLICA; }
+        u64 cut = (u64)k << 16, before = bs[k];
+        if (cut < x.cuts[g - 1]) { cut = x.cuts[g - 1]; before = x.rank0[g - 1] - z; }
+        x.cuts[g] = cut; x.rows[g] = 1 + z + before; x.rank0[g] = z + before;
+    }
+    x.rank0[n_shards] = z + m;
+    // what every shard's scatter needs from my stripes: first-byte sums over ITS key range
+    if (x.s1 > x.s0)
+        for (int g0 = 0; g0 < n_shards; g0 += 64) {          // (all cuts are two-byte key boundaries here; one pass over my partials per 64 shards)
+            ShardKeys keys;
+            keys.n = (u32)std::min(64, n_shards - g0); keys.first = (u32)g0;
+            for (u32 i = 0; i <= keys.n; ++i) keys.k[i] = (u32)(x.cuts[g0 + i] >> 16);
+            hipLaunchKernelGGL(k_stripe_sums_multi, dim3((x.s1 - x.s0) * 16), dim3(256), 0, c->stream, c->hist_partial.as<u32>(), x.per, keys, d_sums_out, (u32)stripes_per_part);
+        }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    for (int g = 0; g <= n_shards; ++g) bounds_out[g] = (int64_t)x.rows[g];
+    x.n_shards = n_shards; x.stage = 2;
+    return MSUFSORT_HIP_OK;
+}
+
+int msufsort_hip_hist_install_dev(msufsort_hip_ctx* c, int32_t shard, const uint32_t* d_stripe_sums, int32_t stripes)
+{
+    if (!c || !d_stripe_sums) return MSUFSORT_HIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    auto& x = c->xh;
+    if (x.stage != 2 || shard < 0 || shard >= x.n_shards || (u32)stripes != c->nchunks) { x.reset(); set_error("hist_install: no plan in the context, or the stripe count is not the plan's"); return MSUFSORT_HIP_ERR_BAD_ARG; }
+    TRY(c->xh_sums.ensure(128 * 256 * 4));
+    HIP_TRY(hipMemcpyAsync(c->xh_sums.p, d_stripe_sums, (size_t)stripes * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    x.shard = shard; x.stage = 3;
+    return MSUFSORT_HIP_OK;
+}
+
 }  // extern "C"
 
 namespace {
@@ -1875,13 +1998,29 @@ int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, typename
         }
         return MSUFSORT_HIP_OK;
     }
-    TRY(zero_pad(c, d_text, (u64)n));
+    const bool planned = c->xh.stage == 3 && c->xh.text == d_text && c->xh.n == (u64)n && c->xh.n_shards == opts->n_shards && c->xh.shard == opts->shard;
     u64 z = 0;
-    TRY(trailing_zeros(c, d_text, (u64)n, &z));
+    if (planned) z = c->xh.z;      // (hist_part padded the text and counted its trailing zero bytes)
+    else {
+        TRY(zero_pad(c, d_text, (u64)n));
+        TRY(trailing_zeros(c, d_text, (u64)n, &z));
+    }
     const u64 m = (u64)n - z;
     ShardCuts sc;
+    bool ext_sums = false;
     HIP_TRY(hipEventRecord(c->ev[8], c->stream));
-    TRY(plan_shards<W>(c, d_text, (u64)n, z, opts->n_shards, sc));
+    if (planned && m > 0) {
+        // the histogram was computed sharded and all-reduced, the plan is made, my shard's stripe sums are here: no pass over the text
+        sc.cuts = c->xh.cuts; sc.rows = c->xh.rows; sc.rank0 = c->xh.rank0;
+        hipLaunchKernelGGL(k_hist_from_u64<W>, dim3(256), dim3(256), 0, c->stream, c->xh_hist.as<u64>(), c->hist.as<typename Wd<W>::hist_t>());
+        c->plan_small_alphabet = c->xh.small_alphabet;
+        ext_sums = true;
+        c->sub_key = -1;
+        c->xh.reset();
+    } else {
+        c->xh.reset();
+        TRY(plan_shards<W>(c, d_text, (u64)n, z, opts->n_shards, sc));
+    }
     HIP_TRY(hipEventRecord(c->ev[9], c->stream));
     const int g = opts->shard;
     const u64 lo = sc.rows[g], hi = sc.rows[g + 1];
@@ -1890,7 +2029,9 @@ int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, typename
     if ((int64_t)(hi - lo) > slice_capacity) { set_error("slice needs %llu rows, capacity %lld", (unsigned long long)(hi - lo), (long long)slice_capacity); return MSUFSORT_HIP_ERR_BAD_ARG; }
     if (hi == lo) return MSUFSORT_HIP_OK;
     c->hint_small_alphabet = c->plan_small_alphabet;
+    c->ext_stripe_sums = ext_sums;
     const int r = build_sa<W>(c, d_text, (u64)n, d_slice_out, lo, z, sc.cuts[g], sc.cuts[g + 1], sc.rank0[g], g == 0, opts, m > 0, d_grp_slice_out, hi - lo);
+    c->ext_stripe_sums = false;
     if (r == MSUFSORT_HIP_OK || r == MSUFSORT_HIP_UNRESOLVED) {
         // the histogram (every shard reads the whole text) and the planning of the cuts ran before build_sa started its clock
         float ms_ = 0;

@@ -322,7 +322,8 @@ __device__ __forceinline__ void h16_add(u32* h_lds, u32 k, u32 c)
 //              histograms of the B and B* suffixes for the two-stage build (induce_kernels.hip.h).
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u64 m, u32 chunk_len, u32 nchunks,
-                                                 u32* __restrict__ partial, u32 sel, const unsigned short* __restrict__ bits)
+                                                 u32* __restrict__ partial, u32 sel, const unsigned short* __restrict__ bits,
+                                                 u32 chunk0 /* first chunk of this launch: a rank of a multi-GPU job counts its stripes only */)
 {
     constexpr bool SUB = MODE == 1, BITS = MODE == 2, FILT = MODE != 0;
     extern __shared__ u32 h_lds[];
@@ -336,9 +337,9 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
     // turns up later is counted straight into the output (one global atomic, rare).
     __shared__ u32 s_present[8];
     __shared__ u8 s_dcode[256], s_dsym[256];
-    const u32 chunk = blockIdx.x, t = threadIdx.x;
+    const u32 chunk = blockIdx.x + chunk0, t = threadIdx.x;
     if (chunk >= nchunks) return;
-    u32* const out = partial + (u64)chunk * 65536u;
+    u32* const out = partial + (u64)blockIdx.x * 65536u;      // (a part's partials are indexed from its first chunk)
     u32 dense_s = 0, dense_lc = 0;                           // != 0: DENSE mode, S = bits per code; log2(copies)
     uint4* h4 = reinterpret_cast<uint4*>(h_lds);
     const u64 cbeg = (u64)chunk * chunk_len;
@@ -549,6 +550,34 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
         __syncthreads();
         for (u32 i = t; i < no; i += 1024u) atomicAdd(&out[(u32)(ovf[i] >> 32)], (u32)ovf[i]);
     }
+}
+
+// a part's partials -> 64-bit totals (the all-reduce's element type): 32-bit sums over blocks of 64 chunks (a chunk holds at most
+// 2^24 keys), eight loads in flight per lane
+__global__ __launch_bounds__(256) void k_reduce16_part(const u32* __restrict__ partial, u32 nchunks, u64* __restrict__ hist)
+{
+    const u32 kle = blockIdx.x * 256u + threadIdx.x;
+    u64 total = 0;
+    for (u32 c0 = 0; c0 < nchunks; c0 += 64u) {
+        const u32 ce = min(c0 + 64u, nchunks);
+        u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        u32 c = c0;
+        for (; c + 8 <= ce; c += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += partial[(u64)(c + j) * 65536u + kle];
+        }
+        for (; c < ce; ++c) s[0] += partial[(u64)c * 65536u + kle];
+        total += (u64)s[0] + s[1] + s[2] + s[3] + s[4] + s[5] + s[6] + s[7];
+    }
+    hist[((kle & 255u) << 8) | (kle >> 8)] = total;
+}
+
+// the all-reduced 64-bit histogram of a multi-GPU job (big-endian key order) -> the engine's own counters
+template <bool W>
+__global__ __launch_bounds__(256) void k_hist_from_u64(const u64* __restrict__ in, typename Wd<W>::hist_t* __restrict__ hist)
+{
+    const u32 k = blockIdx.x * 256u + threadIdx.x;
+    hist[k] = (typename Wd<W>::hist_t)in[k];
 }
 
 // sums the per-chunk partials (indexed by the memory-order key) and stores them under the big-endian key
@@ -897,6 +926,27 @@ __global__ __launch_bounds__(256) void k_stripe_sums(const u32* __restrict__ par
         }
     }
     if (sum) atomicAdd(&sums[c * 256u + b], sum);
+}
+
+// The same for SEVERAL key ranges at once (sharded histogram: what every shard of a multi-GPU job needs from the stripes this
+// rank counted): the ranges are consecutive, keys.k[g] .. keys.k[g + 1] belongs to shard keys.first + g; one pass over the partials.
+struct ShardKeys { u32 n, first; u32 k[65]; };
+__global__ __launch_bounds__(256) void k_stripe_sums_multi(const u32* __restrict__ partial, u32 per, ShardKeys keys, u32* __restrict__ sums /* [shard][stripes_room][256], zeroed */,
+                                                           u32 stripes_room)
+{
+    const u32 c = blockIdx.x >> 4, q = blockIdx.x & 15u, b = threadIdx.x;      // 16 workgroups per stripe, 16 second bytes each
+    u32 g = 0, sum = 0;
+    // thread b walks the keys b << 8 | b1 in rising order: its shard index only ever moves forward
+    for (u32 i = 0; i < 16u; ++i) {
+        const u32 b1 = q * 16u + i, k = (b << 8) | b1;
+        if (k < keys.k[0] || k >= keys.k[keys.n]) continue;
+        while (k >= keys.k[g + 1]) {
+            if (sum) atomicAdd(&sums[((u64)(keys.first + g) * stripes_room + c) * 256u + b], sum);
+            sum = 0; ++g;
+        }
+        for (u32 h = 0; h < per; ++h) sum += partial[(u64)(c * per + h) * 65536u + b1 * 256u + b];
+    }
+    if (sum) atomicAdd(&sums[((u64)(keys.first + g) * stripes_room + c) * 256u + b], sum);
 }
 
 __global__ __launch_bounds__(128) void k_stripes(const u32* __restrict__ sums, u32 nchunks,

@@ -293,8 +293,59 @@ def build_sa_two_stage_sharded(ctx, d_text, n: int, d_sa_full, d_bstar, rank: in
     return r == 0
 
 
+def sharded_hist_enabled(world: int, n: int = None) -> bool:
+    """Does a sharded build start with plan_sharded?  MSUFSORT_DIST_SHARDED_HIST=1 / 0: always / never.  Default: where it pays -
+    the replicated histogram costs 0.30 ms per GiB of text on every rank, the sharded one 1/world of that plus ~0.35 ms of fixed
+    cost (three calls with a stream synchronisation each, measured: tools/gpu_sharded_hist.py) and two small collectives: from
+    1.5 GiB of text counted by OTHER ranks (8 ranks: n >= 1.75 GiB; 2 ranks: n >= 3 GiB).  n = None: could any size take it?"""
+    import os
+    e = os.environ.get("MSUFSORT_DIST_SHARDED_HIST", "")
+    if not _many(world) or e == "0":
+        return False
+    return e == "1" or n is None or n * (world - 1) >= world * (3 << 29)
+
+
+def plan_sharded(ctx, d_text, n: int, rank: int, world: int, dist, stats=None, group=None, device=None):
+    """The 16-bit histogram of a sharded build computed SHARDED (SURVEY.md section 8(e) "Partitioning"): every rank counts 1/world
+    of the text's scatter stripes, ONE all-reduce (512 KiB) gives everybody the totals, every rank plans the same key ranges
+    from them, and ONE all-gather (128 KiB per rank) hands every shard the per-stripe first-byte counts of its key range that
+    its scatter needs from the stripes the others counted.  The shard build that follows on this context then starts without
+    a pass over the whole text (reference: per-thread counts summed, msufsort.cpp:1496-1521, :1603-1630).
+    Returns the slice bounds, or None when the plan needs a boundary inside a heavy two-byte key (DNA, text): every rank gets the
+    same answer (same totals), nothing is kept and the shard builds compute their own histogram as before."""
+    import torch
+    if n < 1:
+        return None
+    dev = device if device is not None else d_text.device
+    h = torch.empty(65536, dtype=torch.int64, device=dev)
+    total, s0, s1 = ctx.hist_part(d_text, n, rank, world, h)
+    if total == 0:          # (nothing but zero bytes: every rank sees that alike)
+        return None
+    if _many(world):
+        dist.all_reduce(h, group=group)
+    per = max(1, -(-total // world))
+    sums = torch.empty((world, per, 256), dtype=torch.int32, device=dev)
+    bounds = ctx.hist_plan(d_text, n, world, h, sums)
+    if bounds is None:
+        return None
+    if world > 1:
+        got = [torch.empty_like(sums) for _ in range(world)]
+        dist.all_gather(got, sums, group=group)
+    else:
+        if _many(world):
+            dist.all_gather([torch.empty_like(sums)], sums, group=group)        # (the one-rank RCCL hook: the collective is issued all the same)
+        got = [sums]
+    # part p counted the stripes [total p / world, total (p + 1) / world): its block for MY shard, in text order
+    mine = torch.cat([got[p][rank, :(total * (p + 1) // world - total * p // world)] for p in range(world)]) if total else sums[rank, :0]
+    ctx.hist_install(rank, mine.contiguous())
+    if stats is not None:
+        stats["sharded_hist"] = stats.get("sharded_hist", 0) + 1
+    return bounds
+
+
 def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist, bounds=None, text_rounds: int = 0,
-                     d_grp=None, overlap=False, index_bytes: int = 4, state=None, verbose: int = 0, gather_rows: bool = True):
+                     d_grp=None, overlap=False, index_bytes: int = 4, state=None, verbose: int = 0, gather_rows: bool = True, stats=None,
+                     hist_group=None):
     """One step of the sharded build on this rank: sort my key range into my slice, all-gatherv the slices.
 
     Deep ties (long repeats) cannot be finished by key gathers.  With `d_grp` (int32 view of uint32, at least as many entries
@@ -311,8 +362,19 @@ def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist
 
     overlap=True: returns the pending exchange handles instead of waiting, so the caller can start the next build
     (into ANOTHER output buffer) while the slices travel; finish with `wait_all(works, d_sa_full)`.  If the build
-    turns out to need the doubling phase everything is completed here and [] is returned."""
+    turns out to need the doubling phase everything is completed here and [] is returned.
+
+    The build starts with plan_sharded where that pays (sharded_hist_enabled): the histogram counted 1/world per rank.  hist_group: a
+    process group of its own for those two small collectives - with overlap=True they would otherwise queue behind the previous
+    build's slices on the communicator's stream; stats["sharded_hist"] counts the builds that started this way."""
     import torch
+    if sharded_hist_enabled(world, n) and hasattr(ctx, "hist_part"):
+        # the histogram this build starts with, counted 1/world per rank (two small collectives; the shard build below consumes it)
+        planned = plan_sharded(ctx, d_text, n, rank, world, dist, stats=stats, group=hist_group, device=d_sa_full.device)
+        if planned is not None:
+            if bounds is not None and list(bounds) != planned:
+                raise _lib.MsufsortHipError("the bounds passed in are not the plan of this text")
+            bounds = planned
     if bounds is None:
         bounds = ctx.shard_bounds(d_text, n, world)
     if text_rounds <= 0:

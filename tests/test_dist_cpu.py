@@ -192,6 +192,36 @@ class _ModelEngine:
         else:
             rank[u[:count] & 0xFFFFFFFF] = u[:count] >> 32
 
+    # ---- the histogram computed sharded (dist.plan_sharded): 5 stripes of the text, the model's plan is self.rows ----
+    STRIPES = 5
+
+    def _stripe_counts(self, n, s, klo, khi):
+        pos = np.arange(n * s // self.STRIPES, n * (s + 1) // self.STRIPES)
+        key = (self.pad[pos].astype(np.int64) << 8) | self.pad[pos + 1]
+        return np.bincount(self.pad[pos][(key >= klo) & (key < khi)], minlength=256)
+
+    def hist_part(self, d_text, n, part, parts, d_hist):
+        self.s0, self.s1 = self.STRIPES * part // parts, self.STRIPES * (part + 1) // parts
+        pos = np.arange(n * self.s0 // self.STRIPES, n * self.s1 // self.STRIPES)
+        d_hist.numpy()[:] = np.bincount((self.pad[pos].astype(np.int64) << 8) | self.pad[pos + 1], minlength=65536)
+        return self.STRIPES, self.s0, self.s1
+
+    def hist_plan(self, d_text, n, n_shards, d_hist_sum, d_sums):
+        pos = np.arange(n)
+        assert (d_hist_sum.numpy() == np.bincount((self.pad[pos].astype(np.int64) << 8) | self.pad[pos + 1], minlength=65536)).all()
+        out = d_sums.numpy()
+        out[:] = 0
+        for g in range(n_shards):
+            for s in range(self.s0, self.s1):
+                out[g, s - self.s0] = self._stripe_counts(n, s, self.cuts[g], self.cuts[g + 1])
+        self.n = n
+        return list(self.rows)
+
+    def hist_install(self, shard, d_stripe_sums):
+        want = np.stack([self._stripe_counts(self.n, s, self.cuts[shard], self.cuts[shard + 1]) for s in range(self.STRIPES)])
+        assert d_stripe_sums.shape == (self.STRIPES, 256) and (d_stripe_sums.numpy() == want).all()
+        self.installed = getattr(self, "installed", 0) + 1
+
     def bwt_slice(self, d_text, n, d_sa_slice, lo, hi, d_row_bytes, index_bytes=4):
         sa = d_sa_slice.numpy()[:hi - lo].astype(np.int64)
         d_row_bytes.numpy()[:hi - lo] = np.where(sa > 0, self.t[np.maximum(sa - 1, 0)], 0)
@@ -202,7 +232,8 @@ class _ModelEngine:
 def _worker_doubling(rank, world, port, tmp, index_bytes):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      MSUFSORT_DIST_WINDOW="700")          # several update / group-head windows per step on a small input
+                      MSUFSORT_DIST_WINDOW="700",          # several update / group-head windows per step on a small input
+                      MSUFSORT_DIST_SHARDED_HIST="1")      # ... and the histogram counted 1/world per rank at any size
     import torch
     import torch.distributed as dist
 
@@ -222,8 +253,10 @@ def _worker_doubling(rank, world, port, tmp, index_bytes):
         rows_max = max(rows[g + 1] - rows[g] for g in range(world))
         d_grp = torch.zeros(rows_max, dtype=torch.int32)          # slice sized: NOT n + 1
         state = D.ShardState()
-        D.build_sa_sharded(eng, None, n, full, rank, world, dist, rows, d_grp=d_grp, index_bytes=index_bytes, state=state)
-        ok = bool((full.numpy() == want).all()) and state.stats["doubling_steps"] >= 2 and state.stats["updates"] > 0
+        hst = {}
+        D.build_sa_sharded(eng, None, n, full, rank, world, dist, rows, d_grp=d_grp, index_bytes=index_bytes, state=state, stats=hst)
+        ok = hst.get("sharded_hist") == 1 and eng.installed == 1      # the histogram was counted 1/world per rank and my shard's stripe sums arrived
+        ok = ok and bool((full.numpy() == want).all()) and state.stats["doubling_steps"] >= 2 and state.stats["updates"] > 0
         ok = ok and state.stats["windows"] > state.stats["doubling_steps"] and state.stats["index_bytes"] == index_bytes
         # rows kept distributed + the sharded forward transform: n bytes exchanged instead of the rows
         full2 = torch.full((n + 1,), -7, dtype=dt)

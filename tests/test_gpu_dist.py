@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_two_ranks_one_gpu():
-    env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", MSUFSORT_DIST_SHARDED_HIST="1")
     # `python bench.py --gpus 2` DIRECTLY, the way the driver calls it: bench.py starts its two ranks itself
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--size", str(1 << 24), "--no-cpu"]
@@ -24,6 +24,7 @@ def test_bench_two_ranks_one_gpu():
     assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["valid"] is True and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["histogram"].startswith("counted 1/2 per rank")          # (forced at this size: every build started with dist.plan_sharded)
     # (two ranks over gloo are not an RCCL communicator, and the line says so)
     assert d["config"]["ranks"] == 2 and d["config"]["rccl_ranks"] is None and d["config"]["backend"] == "gloo" and d["latency_ms"] > 0 and d["exchange_ms"] >= 0
     assert "1 GiB" not in d["metric"] and d["config"]["index"] == "int32"
@@ -38,7 +39,7 @@ def test_bench_four_and_eight_ranks_one_gpu(world, workload):
     of `python bench.py --gpus N` shares cuda:0 over gloo.  random: eight even key ranges; dna: 16 two-byte keys in all, so the
     cuts fall INSIDE heavy keys (deeper histogram, 4-byte-prefix ranges); dna_tandem: the shards stop unresolved and finish with
     the distributed prefix doubling.  The assembled array is checked on the device by rank 0 (`valid`)."""
-    env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MSUFSORT_BENCH_BACKEND="gloo", MSUFSORT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", MSUFSORT_DIST_SHARDED_HIST="1")
     n = 1 << 22 if workload == "dna_tandem" else 1 << 24          # (a dozen doubling steps through 4 - 8 python ranks: 80 s at 16 MiB)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0",
            "--size", str(n), "--workload", workload, "--no-cpu"]
@@ -49,6 +50,8 @@ def test_bench_four_and_eight_ranks_one_gpu(world, workload):
     assert d["n_gpus"] == world and d["config"]["ranks"] == world and d["valid"] is True
     rows = d["per_rank"]["rows"]
     assert len(rows) == world and sum(rows) == n + 1
+    if workload == "random":
+        assert d["histogram"].startswith(f"counted 1/{world} per rank")      # the histogram all-reduced, the stripe sums all-gathered
     if workload in ("random", "dna"):
         assert max(rows) <= 1.25 * (n / world) + 2, rows          # balanced, also where two-byte keys are heavier than a shard
     if workload == "dna_tandem":
@@ -218,7 +221,8 @@ def test_bench_dist_path_on_rccl_with_one_rank(args):
     callback, the distributed doubling's window loop with its collectives, the byte-slice exchange of the forward BWT - everything
     but the point-to-point sends (a one-rank all-gatherv posts none).  API misuse against RCCL shows here, not on the 8-GPU node."""
     env = {k: v for k, v in os.environ.items() if k not in ("MSUFSORT_BENCH_BACKEND", "MSUFSORT_BENCH_ONE_DEVICE")}
-    env.update(MSUFSORT_BENCH_FORCE_DIST="1", MSUFSORT_DIST_ALWAYS_COLLECTIVE="1", MSUFSORT_DIST_WINDOW="50000", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(MSUFSORT_BENCH_FORCE_DIST="1", MSUFSORT_DIST_ALWAYS_COLLECTIVE="1", MSUFSORT_DIST_WINDOW="50000", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MSUFSORT_DIST_SHARDED_HIST="1")          # (the histogram's all-reduce and all-gather on a communicator of their own, through RCCL)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29633",
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu", "--check-reference", *[str(a) for a in args]]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -226,3 +230,5 @@ def test_bench_dist_path_on_rccl_with_one_rank(args):
     assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads(lines[-1])
     assert d["valid"] is True and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1 and d["n_gpus"] == 1
+    if args[1] == "random":
+        assert d["histogram"].startswith("counted 1/1 per rank")      # hist_part -> all-reduce -> hist_plan -> all-gather -> hist_install, on RCCL

@@ -203,6 +203,109 @@ def test_device_api_and_checker(M, oracle_mod):
     assert (h.cpu().numpy() == np.bincount((tt[:-1] << 8) | tt[1:], minlength=65536)).all()
 
 
+def _sharded_hist_build(M, t, parts, wide=False):
+    """The three C-ABI calls of the sharded histogram with the two collectives done by hand (one context per rank, all on this
+    GPU): returns (bounds, rows) or (None, None) when the plan asks for the replicated histogram."""
+    import torch
+    n = t.size
+    d = _dev(M, t)
+    ctxs = [M.DeviceContext(0) for _ in range(parts)]
+    hs, geo = [], []
+    for p, c in enumerate(ctxs):
+        h = torch.full((65536,), -1, dtype=torch.int64, device="cuda")
+        geo.append(c.hist_part(d, n, p, parts, h))
+        hs.append(h)
+    total = geo[0][0]
+    assert all(g[0] == total for g in geo) and geo[0][1] == 0 and geo[-1][2] == total and all(a[2] == b[1] for a, b in zip(geo, geo[1:]))
+    tt = np.concatenate([t, np.zeros(1, np.uint8)]).astype(np.int64)
+    z = n - (int(np.max(np.nonzero(t)[0])) + 1 if t.any() else 0)
+    hsum = torch.stack(hs).sum(0)                                      # the all-reduce
+    assert (hsum.cpu().numpy() == np.bincount((tt[:n - z] << 8) | tt[1:n - z + 1], minlength=65536)).all()
+    per = max(1, -(-total // parts))
+    blocks, bounds = [], None
+    for c in ctxs:
+        sums = torch.full((parts, per, 256), -1, dtype=torch.int32, device="cuda")
+        b = c.hist_plan(d, n, parts, hsum, sums)
+        if b is None:
+            return None, None
+        assert bounds is None or b == bounds
+        bounds = b
+        blocks.append(sums)                                            # the all-gather
+    assert bounds == ctxs[0].shard_bounds(d, n, parts)                 # the plan of the replicated histogram
+    dt = torch.int64 if wide else torch.int32
+    full = torch.full((n + 1,), -1, dtype=dt, device="cuda")
+    for g, c in enumerate(ctxs):
+        mine = torch.cat([blocks[p][g, :geo[p][2] - geo[p][1]] for p in range(parts)]).contiguous()
+        c.hist_install(g, mine)
+        lo, hi = bounds[g], bounds[g + 1]
+        sl = full[lo:hi] if hi > lo else torch.empty(1, dtype=dt, device="cuda")
+        if wide:
+            grp = torch.empty(max(hi - lo, 1), dtype=torch.int32, device="cuda")
+            l2, h2, unresolved, _ = c.make_sa_shard_groups(d, n, sl, grp, max(hi - lo, 1), g, parts, text_rounds=16, index_bytes=8)
+            assert not unresolved
+        else:
+            l2, h2 = c.make_sa_shard(d, n, sl, max(hi - lo, 1), g, parts, text_rounds=16)
+        assert (l2, h2) == (lo, hi)
+    return bounds, full
+
+
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_histogram_counted_sharded(M, oracle_mod, parts):
+    """SURVEY 8(e) "Partitioning": every rank counts 1/G of the text's stripes, the totals are all-reduced, every rank plans the
+    same key ranges and gets the per-stripe counts of its range from the others (msufsort_hip_hist_part/_plan/_install_dev): the
+    shard builds then start without a pass over the text and the slices are the reference's rows.  Inputs: random bytes
+    (one stripe ... many stripes, fewer stripes than ranks), trailing zero bytes, int64 rows; DNA and text ask for the
+    replicated histogram (a boundary inside a heavy key)."""
+    cases = [gen.random_bytes(3 << 20, 31), gen.random_bytes(50_000, 5), gen.random_bytes(131072 * 3 + 17, 6),
+             np.concatenate([gen.random_bytes(1 << 20, 7), np.zeros(5, np.uint8)]), gen.random_bytes(40 << 20, 8)]
+    for i, t in enumerate(cases):
+        bounds, full = _sharded_hist_build(M, t, parts)
+        assert bounds is not None, i
+        if t.size <= 4 << 20:
+            assert (full.cpu().numpy() == _want(oracle_mod, t)).all(), (i, parts)
+        else:
+            ctx = M.DeviceContext(0)
+            assert ctx.validate_sa(_dev(M, t), t.size, full) == 0
+    bounds, full = _sharded_hist_build(M, cases[0], parts, wide=True)
+    assert (full.cpu().numpy() == _want(oracle_mod, cases[0])).all()
+    declined = 0
+    for t in (gen.dna_bytes(2 << 20, 3), gen.text_bytes(2 << 20, 4)):
+        bounds, full = _sharded_hist_build(M, t, parts)
+        declined += bounds is None                                     # (2 or 8 shards of DNA: 16 equal keys, the targets ARE key boundaries)
+        assert bounds is None or (full.cpu().numpy() == _want(oracle_mod, t)).all()
+    assert declined >= (0 if parts == 2 else 1)
+
+
+def test_histogram_state_is_dropped_by_any_other_call(M, oracle_mod):
+    """An installed plan serves exactly the shard build it was made for: another shard, another text or another shard count
+    drop it and count for themselves; calls out of order are refused."""
+    import torch
+    t = gen.random_bytes(1 << 20, 11)
+    n = t.size
+    d = _dev(M, t)
+    ctx = M.DeviceContext(0)
+    want = _want(oracle_mod, t)
+    h = torch.empty(65536, dtype=torch.int64, device="cuda")
+    total, s0, s1 = ctx.hist_part(d, n, 0, 1, h)
+    sums = torch.empty((2, total, 256), dtype=torch.int32, device="cuda")
+    with pytest.raises(M.MsufsortHipError):
+        ctx.hist_install(0, sums[0])                                   # no plan yet
+    total, s0, s1 = ctx.hist_part(d, n, 0, 1, h)
+    bounds = ctx.hist_plan(d, n, 2, h, sums)                           # one part counted everything; two shards planned
+    ctx.hist_install(1, sums[1].contiguous())
+    full = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+    for g in (0, 1):                                                   # shard 0 first: drops the state that was installed for shard 1
+        lo, hi = bounds[g], bounds[g + 1]
+        ctx.make_sa_shard(d, n, full[lo:hi], hi - lo, g, 2, text_rounds=16)
+    assert (full.cpu().numpy() == want).all()
+    with pytest.raises(M.MsufsortHipError):
+        ctx.hist_plan(d, n, 2, h, sums)                                # the part is gone as well
+    # a wrong sum is caught (it does not count the text's suffixes)
+    ctx.hist_part(d, n, 0, 2, h)
+    with pytest.raises(M.MsufsortHipError):
+        ctx.hist_plan(d, n, 2, h, sums)
+
+
 @pytest.mark.parametrize("shards", [2, 3, 8])
 def test_logical_shards_concatenate(M, oracle_mod, shards):
     """G logical shards on one device must reassemble to the full array."""
