@@ -295,14 +295,16 @@ def build_sa_two_stage_sharded(ctx, d_text, n: int, d_sa_full, d_bstar, rank: in
 
 def sharded_hist_enabled(world: int, n: int = None) -> bool:
     """Does a sharded build start with plan_sharded?  MSUFSORT_DIST_SHARDED_HIST=1 / 0: always / never.  Default: where it pays -
-    the replicated histogram costs 0.30 ms per GiB of text on every rank, the sharded one 1/world of that plus ~0.35 ms of fixed
-    cost (three calls with a stream synchronisation each, measured: tools/gpu_sharded_hist.py) and two small collectives: from
-    1.5 GiB of text counted by OTHER ranks (8 ranks: n >= 1.75 GiB; 2 ranks: n >= 3 GiB).  n = None: could any size take it?"""
+    the replicated histogram costs 0.30 ms per GiB of text on every rank, the sharded one 1/world of that plus ~0.17 ms of fixed
+    cost more than the replicated plan's (three calls with a stream synchronisation each; measured per rank, collectives not
+    included, tools/gpu_sharded_hist.py: 256 MiB / 8 ranks +0.03 ms, 1 GiB / 8 ranks -0.13 ms, 2 GiB / 8 ranks -0.40 ms) and two
+    small collectives (~0.1 ms): from 0.75 GiB of text counted by OTHER ranks (8 ranks: n >= 0.86 GiB; 4: 1 GiB; 2: 1.5 GiB).
+    n = None: could any size take it?"""
     import os
     e = os.environ.get("MSUFSORT_DIST_SHARDED_HIST", "")
     if not _many(world) or e == "0":
         return False
-    return e == "1" or n is None or n * (world - 1) >= world * (3 << 29)
+    return e == "1" or n is None or n * (world - 1) >= world * (3 << 28)
 
 
 def plan_sharded(ctx, d_text, n: int, rank: int, world: int, dist, stats=None, group=None, device=None):
