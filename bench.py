@@ -430,6 +430,35 @@ def kernels_json(kern):
     return out
 
 
+def random_access_ceiling(device_index):
+    """What the memory system gives a kernel whose every access is another line, measured LIVE on this GPU (tools/micro/window_gather.hip
+    built as build/librandom_access_probe.so by __graft_entry__.build(); 2^27 hashed indices per launch, best of 3): byte reads from a
+    1 GiB and a 4 GiB window, 4-byte writes into 256 MiB and 1 GiB.  The gather-bound kernels of the text path (key rounds, induction,
+    k_ibwt_walk, k_lcp) sit under THIS ceiling - ~52 G line requests/s whatever the window - not under the 8 TB/s of streaming reads:
+    their fractions of the HBM peak are one 64-byte request per useful byte, their fractions of this figure say how well they hide
+    the latency.  Measurement infrastructure: nothing in the product library calls it."""
+    import ctypes as C
+    path = os.path.join(ROOT, "build", "librandom_access_probe.so")
+    try:
+        f = C.CDLL(path).msufsort_probe_random_access
+    except (OSError, AttributeError) as e:
+        return {"error": f"{path}: {e} (run __graft_entry__.build())"}
+    f.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    out = {"unit": "G accesses/s", "accesses_per_launch": 1 << 27, "source": "tools/micro/window_gather.hip, live in this run"}
+    for name, window, mode in (("reads_1GiB_window", 1 << 30, 0), ("reads_4GiB_window", 4 << 30, 0), ("writes_256MiB_window", 256 << 20, 2), ("writes_1GiB_window", 1 << 30, 2)):
+        v = C.c_double(0)
+        out[name] = round(v.value, 1) if f(device_index, window, 1 << 27, mode, 3, C.byref(v)) == 0 else None
+    return out
+
+
+def request_bound(ceiling, key, accesses, ms, note):
+    """One gather-bound phase against the measured random-access ceiling: accesses / time, as a fraction of ceiling[key]."""
+    rate = accesses / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
+    top = ceiling.get(key) if isinstance(ceiling, dict) else None
+    return {"random_accesses": int(accesses), "ms": round(ms, 3), "G_per_s": round(rate, 1) if rate else None, "ceiling": key, "ceiling_G_per_s": top,
+            "frac_of_measured_ceiling": round(rate / top, 3) if rate and top else None, "counted": note}
+
+
 def config_lines(M, torch, ctx, dev, steps, no_cpu):
     """BASELINE configs 3 and 4 under the same clock as the headline: text, 2^30 - 1 bytes (the reference's ceiling): SA,
     forward BWT as one call, inverse BWT, LCP - all resident in HBM; reference hashes from tests/golden/golden_full.json."""
@@ -463,6 +492,23 @@ def config_lines(M, torch, ctx, dev, steps, no_cpu):
                          "launch_ms": round(walk_ms, 3), "algorithmic_bytes": 9 * n,
                          "line_GBps": round(128 * n / (walk_ms * 1e-3) / 1e9, 1) if walk_ms else None},
             "lcp_ms": round(lcp_ms, 3)}
+    # the gather-bound phases against the random-access ceiling measured in this run (their HBM fractions above are one 64-byte
+    # request per few useful bytes by construction)
+    ceil_ = random_access_ceiling(dev.index or 0)
+    cfg3["random_access_ceiling"] = ceil_
+    rb3 = {}
+    if two_stage:
+        rb3["induction"] = request_bound(ceil_, "reads_1GiB_window", mstar + (n - mstar) / 3, avg("other_ms"),
+                                         "one 4-byte text fetch per B* suffix and per third induced suffix (the rows carry three characters); the rest of the phase is "
+                                         "sequential rows, ranking and the look-back between tiles")
+    gathered = sum(p.gathered_records for p in S.phases) / K
+    if gathered:
+        rb3["key rounds"] = request_bound(ceil_, "reads_1GiB_window", gathered, avg("refine_ms"),
+                                          "one text line per gathered record; the time also holds the sorts of those records and the round whose keys came with the records")
+    cfg3["request_bound"] = rb3
+    cfg4["request_bound"] = {
+        "k_ibwt_walk": request_bound(ceil_, "reads_4GiB_window", n, walk_ms, "one hop = one dependent 8-byte read from the 4 n-byte link table"),
+        "k_lcp": request_bound(ceil_, "reads_1GiB_window", n, lcp_ms, "at least one text line per row (32 bytes from a random offset: 1.4 lines on average, PMC)")}
     if not no_cpu:
         try:
             cfg3["cpu_baseline"] = cpu_baseline(n, seed, "text", "fbwt", n)          # the WHOLE 2^30 - 1 text, like the GPU legs beside it (round-4 review)

@@ -200,3 +200,19 @@ def test_bench_labels_and_budget():
     assert b8["rows"] == (n + 1) * 8 and b8["text"] == n + 64
     b2 = bench.multi_gpu_budget(n, 2, 8, n >> 1, False, False, False)
     assert b2["total"] > 288e9                               # two ranks cannot hold it: bench.py refuses with the budget in the message
+
+
+def test_random_access_probe_builds_and_is_not_product_code():
+    """bench.py's live random-access ceiling comes from tools/micro/window_gather.hip built as build/librandom_access_probe.so by
+    __graft_entry__.build(): the symbol is there, bench.py degrades to an error entry without a GPU / without the file, and the
+    product library does not reference the probe."""
+    import ctypes as C
+    import bench
+    path = os.path.join(ROOT, "build", "librandom_access_probe.so")
+    assert os.path.exists(path), "run __graft_entry__.build()"
+    assert hasattr(C.CDLL(path), "msufsort_probe_random_access")
+    rb = bench.request_bound({"reads_1GiB_window": 50.0}, "reads_1GiB_window", 1_000_000_000, 25.0, "x")
+    assert rb["G_per_s"] == 40.0 and rb["frac_of_measured_ceiling"] == 0.8
+    assert bench.request_bound({"error": "no file"}, "reads_1GiB_window", 10, 1.0, "x")["frac_of_measured_ceiling"] is None
+    src = "".join(open(os.path.join(ROOT, "msufsort_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "msufsort_amd", "csrc")) if not f.endswith("Makefile"))
+    assert "msufsort_probe" not in src and "window_gather" not in src

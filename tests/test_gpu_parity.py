@@ -409,6 +409,16 @@ def test_tandem_progressions(M, oracle_mod, monkeypatch):
     assert sum(h > 0 for h in hits) >= 10, hits          # the shortcut really ran on most of these inputs
 
 
+def test_random_access_ceiling_probe():
+    """bench.py's live ceiling for the gather-bound kernels: plausible rates, and the effect the windowed rank-array build rests on
+    (random 4-byte writes into 256 MiB are absorbed by the memory-side cache, into 1 GiB they are not)."""
+    import bench
+    c = bench.random_access_ceiling(0)
+    assert "error" not in c, c
+    assert 10 < c["reads_1GiB_window"] < 1000 and 10 < c["reads_4GiB_window"] < 1000
+    assert c["writes_256MiB_window"] > 1.2 * c["writes_1GiB_window"] > 5
+
+
 @pytest.mark.parametrize("window_kib", [0, 64, 1000])
 def test_rank_array_built_in_windows(M, oracle_mod, monkeypatch, window_kib):
     """The switch to prefix doubling (narrow, one GPU) builds the rank array from the rows' group heads with one write per suffix,

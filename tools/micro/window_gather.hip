@@ -1,10 +1,12 @@
-// Micro-benchmark: random byte reads / 4-byte writes confined to a window of W MiB (is the memory-side cache a lever?).
-// hipcc --offload-arch=gfx950 -O3 tools/micro/window_gather.hip -o gpurun_out/window_gather && gpurun_out/window_gather
+// Micro-benchmark: random byte / 4-byte reads and 4-byte writes confined to a window of W bytes - what the memory system gives a
+// kernel whose every access is a different line (the key gathers of the text rounds, the induction's character fetches, k_ibwt_walk,
+// k_lcp; the rank array of the switch to prefix doubling for the writes).  Measurement infrastructure, not product code.
+//   stand-alone:  hipcc --offload-arch=gfx950 -O3 tools/micro/window_gather.hip -o /tmp/wg && /tmp/wg      (profiles/r05_window_gather.txt)
+//   as a library: hipcc ... -DPROBE_LIBRARY -fPIC -shared -o build/librandom_access_probe.so                (bench.py: "random_access")
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-#include <vector>
-#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 __global__ void k_fill_idx(uint32_t* idx, uint64_t n, uint64_t mask, uint64_t seed)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -27,29 +29,44 @@ __global__ void k_scatter_u32(const uint32_t* __restrict__ idx, uint32_t* __rest
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         dst[__builtin_nontemporal_load(idx + i) >> 2] = (uint32_t)i;
 }
-int main()
+
+// mode 0: byte reads, 1: 4-byte reads, 2: 4-byte writes; window_bytes a power of two <= 4 GiB; best of `reps` launches of `accesses`
+// accesses each, in G accesses / s.  Returns 0 or 1 (a HIP call failed: stderr says which).
+extern "C" int msufsort_probe_random_access(int device, uint64_t window_bytes, uint64_t accesses, int mode, int reps, double* g_per_s)
 {
-    const uint64_t n = 1ull << 28;
-    uint32_t *idx, *out32; uint8_t *src, *out8;
-    CK(hipMalloc(&idx, n * 4)); CK(hipMalloc(&out32, n * 4)); CK(hipMalloc(&out8, n)); CK(hipMalloc(&src, 4ull << 30));
-    CK(hipMemset(src, 1, 4ull << 30));
+    if (!g_per_s || mode < 0 || mode > 2 || reps < 1 || window_bytes < 4096 || (window_bytes & (window_bytes - 1)) || window_bytes > (4ull << 30) || accesses < 1) return 1;
+    CK(hipSetDevice(device));
+    uint32_t *idx = nullptr, *out = nullptr; uint8_t* win = nullptr;
+    CK(hipMalloc(&idx, accesses * 4)); CK(hipMalloc(&out, accesses * 4)); CK(hipMalloc(&win, window_bytes));
+    CK(hipMemset(win, 1, window_bytes));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     const int grid = 256 * 8;
-    printf("%8s %14s %14s %14s   (G accesses / s, n = 2^28 per launch)\n", "W MiB", "read u8", "read u32", "write u32");
+    hipLaunchKernelGGL(k_fill_idx, dim3(grid), dim3(256), 0, 0, idx, accesses, window_bytes - 1, window_bytes >> 20);
+    float best = 0;
+    for (int rep = 0; rep <= reps; ++rep) {          // (the first launch warms up)
+        CK(hipEventRecord(a));
+        if (mode == 0) hipLaunchKernelGGL(k_gather_u8, dim3(grid), dim3(256), 0, 0, idx, win, reinterpret_cast<uint8_t*>(out), accesses);
+        if (mode == 1) hipLaunchKernelGGL(k_gather_u32, dim3(grid), dim3(256), 0, 0, idx, reinterpret_cast<const uint32_t*>(win), out, accesses);
+        if (mode == 2) hipLaunchKernelGGL(k_scatter_u32, dim3(grid), dim3(256), 0, 0, idx, reinterpret_cast<uint32_t*>(win), accesses);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float t = 0; CK(hipEventElapsedTime(&t, a, b));
+        if (rep && (best == 0 || t < best)) best = t;
+    }
+    CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+    CK(hipFree(idx)); CK(hipFree(out)); CK(hipFree(win));
+    *g_per_s = (double)accesses / best / 1e6;
+    return 0;
+}
+
+#ifndef PROBE_LIBRARY
+int main()
+{
+    printf("%8s %14s %14s %14s   (G accesses / s, 2^28 per launch)\n", "W MiB", "read u8", "read u32", "write u32");
     for (uint64_t w = 16; w <= 4096; w *= 2) {
-        hipLaunchKernelGGL(k_fill_idx, dim3(grid), dim3(256), 0, 0, idx, n, (w << 20) - 1, w);
-        float t[3];
-        for (int k = 0; k < 3; ++k) {
-            for (int rep = 0; rep < 2; ++rep) {
-                CK(hipEventRecord(a));
-                if (k == 0) hipLaunchKernelGGL(k_gather_u8, dim3(grid), dim3(256), 0, 0, idx, src, out8, n);
-                if (k == 1) hipLaunchKernelGGL(k_gather_u32, dim3(grid), dim3(256), 0, 0, idx, (const uint32_t*)src, out32, n);
-                if (k == 2) hipLaunchKernelGGL(k_scatter_u32, dim3(grid), dim3(256), 0, 0, idx, (uint32_t*)src, n);
-                CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
-                CK(hipEventElapsedTime(&t[k], a, b));
-            }
-        }
-        printf("%8llu %14.1f %14.1f %14.1f\n", (unsigned long long)w, n / t[0] / 1e6, n / t[1] / 1e6, n / t[2] / 1e6);
+        double r[3];
+        for (int m = 0; m < 3; ++m) if (msufsort_probe_random_access(0, w << 20, 1ull << 28, m, 2, &r[m])) return 1;
+        printf("%8llu %14.1f %14.1f %14.1f\n", (unsigned long long)w, r[0], r[1], r[2]);
     }
     return 0;
 }
+#endif
