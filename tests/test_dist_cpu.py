@@ -283,6 +283,24 @@ def test_distributed_doubling_driver_gloo(world, index_bytes, tmp_path, oracle_m
         assert open(tmp_path / f"d{r}").read() == "ok"
 
 
+def test_sharded_histogram_policy(monkeypatch):
+    """dist.sharded_hist_enabled: on where >= 0.75 GiB of text are counted by the OTHER ranks (measured break-even, DESIGN 3.3b);
+    MSUFSORT_DIST_SHARDED_HIST=1 / 0 force it; one rank only under the always-collective hook."""
+    from msufsort_amd import dist as D
+    monkeypatch.delenv("MSUFSORT_DIST_SHARDED_HIST", raising=False)
+    monkeypatch.delenv("MSUFSORT_DIST_ALWAYS_COLLECTIVE", raising=False)
+    n1 = (1 << 30) - 1
+    assert D.sharded_hist_enabled(8, n1) and not D.sharded_hist_enabled(4, n1) and not D.sharded_hist_enabled(2, n1)
+    assert D.sharded_hist_enabled(4, 1 << 30) and D.sharded_hist_enabled(2, 3 << 29) and not D.sharded_hist_enabled(8, 1 << 28)
+    assert D.sharded_hist_enabled(8) and not D.sharded_hist_enabled(1, 1 << 33)
+    monkeypatch.setenv("MSUFSORT_DIST_SHARDED_HIST", "1")
+    assert D.sharded_hist_enabled(2, 1000) and not D.sharded_hist_enabled(1, 1 << 33)
+    monkeypatch.setenv("MSUFSORT_DIST_ALWAYS_COLLECTIVE", "1")
+    assert D.sharded_hist_enabled(1, 1000)
+    monkeypatch.setenv("MSUFSORT_DIST_SHARDED_HIST", "0")
+    assert not D.sharded_hist_enabled(8, 1 << 33)
+
+
 def test_update_offsets_and_bwt_bounds():
     """The two pieces of index arithmetic the ranks must agree on: word offsets of a window's updates (one word per update for
     int32 rows, two for int64 rows) and the byte ranges of the BWT slices around the removed sentinel row."""
