@@ -65,25 +65,39 @@ def cpu_reference_runs(workload, seed, n, runs, timeout_s):
     return json.loads(lines[-1]) if lines else []
 
 
-def cpu_baseline(sample_bytes, seed, workload="random", op="sa", full_n=None, all_threads=False):
-    """cpu_baseline object of the JSON line: the reference ("reference") with 32 threads and with every hardware thread,
-    or - when oracle/_ref is absent - our single-threaded C restatement ("port") on a bounded sample."""
+def cpu_baseline(sample_bytes, seed, workload="random", op="sa", full_n=None, all_threads=False, median_of=1, t1_prefix=0, counts=None):
+    """cpu_baseline object of the JSON line: the unmodified reference ("reference") on the host cores, or - when oracle/_ref is
+    absent - our single-threaded C restatement ("port") on a bounded sample.
+    SURVEY 8(d) protocol (median_of = 3, the headline): one run with 16 and one with 32 threads, then the faster count again until it
+    has `median_of` runs - `value` is the MEDIAN of those (the reference's spin-wait pool makes single draws noisy) -, plus ONE
+    single-thread run on the first `t1_prefix` bytes of the same stream (labelled; T = 1 on the whole GiB would take minutes)."""
     import oracle
     ncpu = os.cpu_count() or 1
     if oracle.have_reference():
         # The reference's workers spin-wait and its serial phases do not shrink: on the 2 x 128-thread host of the GPU box it is
         # FASTEST with about 16 threads (256 MiB: 146 MB/s with 16, 80 with 32, 26 with 64, 13 with 128, no end within 90 s with
-        # 192 or 256: profiles/r03_cpu_reference_threads.txt).  So: the whole sample with 16 and with 32 threads, the faster one
-        # is the value; every hardware thread on a small sample under a watchdog, reported next to it.
-        counts = sorted({max(1, min(16, ncpu)), max(1, min(32, ncpu))})
+        # 192 or 256: profiles/r03_cpu_reference_threads.txt).
+        counts = sorted(set(counts or [max(1, min(16, ncpu)), max(1, min(32, ncpu))]))
         res = cpu_reference_runs(workload, seed, sample_bytes, [(c_, op) for c_ in counts], timeout_s=420)
         if not res:
             return {"error": "the reference did not finish within 420 s", "host_cpus": ncpu}
         best = max(res, key=lambda r: r["MB/s"])
+        if median_of > 1:
+            more = cpu_reference_runs(workload, seed, sample_bytes, [(best["threads"], op)] * (median_of - 1), timeout_s=420)
+            res = res + more
+        at_best = sorted(r["MB/s"] for r in res if r["threads"] == best["threads"])
+        value = at_best[len(at_best) // 2] if len(at_best) % 2 else round((at_best[len(at_best) // 2 - 1] + at_best[len(at_best) // 2]) / 2, 2)
         what = {"sa": "make_suffix_array", "ibwt": "reverse_burrows_wheeler_transform"}.get(op, "forward_burrows_wheeler_transform")
         part = "the whole input" if full_n == sample_bytes else f"first {sample_bytes} bytes of the same stream"
-        out = {"value": best["MB/s"], "unit": "MB/s", "cores": best["threads"], "kind": "reference", "host_cpus": ncpu, "runs": res,
-               "sample": f"{part}, {what} wall time incl. allocation, one run per thread count ({', '.join(str(r['threads']) for r in res)}); value = the faster"}
+        how = (f"one run per thread count ({', '.join(str(c_) for c_ in counts)}), then the faster count repeated: value = median of its {len(at_best)} runs"
+               if median_of > 1 else f"one run per thread count ({', '.join(str(r['threads']) for r in res)}); value = the faster")
+        out = {"value": value, "unit": "MB/s", "cores": best["threads"], "kind": "reference", "host_cpus": ncpu, "runs": res,
+               "runs_at_reported_threads": len(at_best), "sample": f"{part}, {what} wall time incl. allocation (main.cpp:437-453), {how}"}
+        if t1_prefix:
+            small = min(sample_bytes, t1_prefix)
+            r1 = cpu_reference_runs(workload, seed, small, [(1, op)], timeout_s=240)
+            out["single_thread"] = (dict(r1[0], sample_bytes=small, sample=f"first {small} bytes of the same stream, one run") if r1 else
+                                    {"threads": 1, "sample_bytes": small, "error": "did not finish within 240 s"})
         if all_threads and ncpu > max(counts):
             small = min(sample_bytes, 1 << 25)
             r2 = cpu_reference_runs(workload, seed, small, [(ncpu, op)], timeout_s=45)
@@ -459,6 +473,106 @@ def request_bound(ceiling, key, accesses, ms, note):
             "frac_of_measured_ceiling": round(rate / top, 3) if rate and top else None, "counted": note}
 
 
+def config2_line(M, torch, ctx, dev, steps, no_cpu):
+    """BASELINE config 2: suffix array of 256 MiB of uniform random bytes (splitmix64 seed 12345, n = 2^28) on one GPU, resident in
+    HBM, timed like the headline (reference main.cpp:386,440-442: clock around the call); reference hash from golden_full.json."""
+    n, seed = 1 << 28, 12345
+    S = Single(M, torch, ctx, dev, "random", seed, n, ["sa"])
+    dt = S.run(steps, 2)
+    ok, against = S.validate()
+    kern, avg, _, _ = kernel_table(S.phases, steps, n, "random", ["sa"], [0, 0])
+    radix_ms = kern["k_hist16"][0] + kern["k_scatter0"][0]
+    cfg2 = {"workload": f"random bytes (splitmix64 seed {seed}), n={n}, int32 SA, one GPU", "valid": ok, "valid_against": against, "steps": steps,
+            "sa_ms": round(dt / steps * 1e3, 3), "sa_MBps": round(n / (dt / steps) / 1e6, 1), "sa_device_ms": round(avg("total_ms"), 3),
+            "roofline": roofline_of(kern, n, "random", True), "kernels": kernels_json(kern),
+            "radix_pass": {"read_bytes": 2 * n, "ms": round(radix_ms, 4),
+                           "read_frac_of_hbm_peak": round((2 * n / (radix_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4) if radix_ms > 0 else None},
+            "end_to_end": {"compulsory_bytes": 5 * n + 4, "frac_of_hbm_peak": round(((5 * n + 4) / (dt / steps) / 1e9) / HBM_PEAK_GBS, 5)},
+            "radix_bits": int(S.phases[-1].radix_bits), "bucket_sort_handed_back": int(S.phases[-1].bucket_sort_handed_back)}
+    del S
+    torch.cuda.empty_cache()
+    if not no_cpu:
+        try:
+            cfg2["cpu_baseline"] = cpu_baseline(n, seed, "random", "sa", n, counts=[min(16, os.cpu_count() or 1)])
+        except Exception as e:  # noqa: BLE001
+            cfg2["cpu_baseline"] = {"error": str(e)}
+    return cfg2, ok
+
+
+def config5_line(M, torch, ctx, dev, no_cpu):
+    """BASELINE config 5's workload at its full size on the ONE GPU of this run: 8 GiB of DNA with long tandem repeats (gen.dna_tandem_bytes
+    seed 9, n = 2^33: the stream whose first 2^28 bytes are the golden vector), int64 rows (wide engine: 40-bit indices; the reference's
+    int32 index with two flag bits stops at 2^30, msufsort.h:47, 84-93), the 8 GPUs' key-range shards as 32 logical shards that take
+    turns on the device, distributed prefix doubling between them.  Timed: the SECOND build (every buffer in place; the first one
+    allocates ~200 GB), clock around the call.  `valid`: the 64-bit on-device checker (order + permutation) on the full array, and
+    the input's first 2^28 bytes hashed against the golden vector's input.  The 8-GPU form of this config is `bench.py --gpus 8
+    --workload dna_tandem --size 8589934592` (dist.py)."""
+    from msufsort_amd import gen
+    n, seed, shards = 1 << 33, 9, 32
+    ctx.trim()
+    torch.cuda.empty_cache()
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    if free_b < (250 << 30):
+        return {"skipped": f"needs ~250 GiB of free HBM for the whole 8 GiB job on one GPU; {round(free_b / 2**30, 1)} GiB free of {round(total_b / 2**30, 1)}"}, True
+    t0 = time.perf_counter()
+    t = gen.dna_tandem_bytes(n, seed)
+    g = golden_entry("dna_tandem", seed, 1 << 28)
+    import oracle          # (the checker's hash routine, outside every timed part)
+    prefix_ok = g is None or ("%016x" % oracle.fnv1a64(t[: 1 << 28])) == g["input_fnv"]
+    d = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    for s0 in range(0, n, 1 << 30):
+        d[s0:s0 + (1 << 30)] = torch.from_numpy(t[s0:s0 + (1 << 30)]).to(dev)
+    del t
+    torch.cuda.synchronize(dev)
+    gen_s = time.perf_counter() - t0
+    sa = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    t1 = time.perf_counter()
+    ctx.make_sa_i64(d, n, sa, n_shards=shards)
+    first_s = time.perf_counter() - t1
+    sa.fill_(-1)
+    torch.cuda.synchronize(dev)
+    t2 = time.perf_counter()
+    ctx.make_sa_i64(d, n, sa, n_shards=shards)
+    second_s = time.perf_counter() - t2
+    tm = ctx.timings()
+    ctx.trim()
+    t3 = time.perf_counter()
+    errs = ctx.validate_sa(d, n, sa, index_bytes=8)
+    check_s = time.perf_counter() - t3
+    ok = errs == 0 and int(sa[0]) == n and prefix_ok
+    G = int(tm.logical_shards)
+    # ALGORITHMIC bytes (DESIGN section 2): the text is counted once (plan) and read by every shard's level-0 scatter; wide records are 8
+    # bytes, rows 8; a key round moves 16 + 4 bytes per still-tied suffix (index 8 -> record 8, key 8, row 8: billed as SURVEY's 16 + the wider
+    # index); a doubling step reads row + group head (12), gathers the rank of suffix + h (8) and writes row + head (12) per row it scans
+    m = int(tm.m)
+    dbl_rows = int(tm.doubling_records)
+    kern = {"k_hist16": (tm.hist16_ms, n),
+            f"k_scatter0 (x{G} shards)": (tm.scatter0_ms, G * n + 8 * m),
+            "k_partition(level 1)": (tm.scatter1_ms, 16 * m),
+            "round-0 LDS sorts (k_sort_mid/k_sort_tiny)": (tm.bucket_sort_ms, 16 * m),
+            "key rounds (k_refill + k_partition levels + LDS sorts)": (tm.refine_ms, 24 * int(tm.gathered_records)),
+            "distributed prefix doubling (k_import_groups, k_chain_resolve, k_refill_rows, LDS sorts, k_emit_updates, k_apply_updates)": (tm.other_ms, 32 * dbl_rows)}
+    kern = {k: v for k, v in kern.items() if v[0] > 0}
+    cfg5 = {"workload": f"dna_tandem (seed {seed}), n={n} (8 GiB), int64 SA, {G} logical key-range shards on one GPU (wide engine), distributed prefix doubling",
+            "valid": bool(ok), "valid_against": "64-bit on-device checker (adjacent-pair order by ranks + permutation) on all 2^33 + 1 rows; the input's first 2^28 bytes "
+                                                 "hash to the golden vector's input (tests/golden/golden_full.json: its rows are pinned by the reference in test_full_size_golden)",
+            "checker_errors": int(errs), "sa_ms": round(second_s * 1e3, 1), "sa_MBps": round(n / second_s / 1e6, 1), "first_build_ms_with_allocations": round(first_s * 1e3, 1),
+            "sa_device_ms": round(tm.total_ms, 1), "generate_and_upload_s": round(gen_s, 1), "check_s": round(check_s, 1),
+            "logical_shards": G, "stop_depth": int(tm.stop_depth), "doubling_steps": int(tm.doubling_rounds), "doubling_ms": round(tm.other_ms, 1),
+            "doubling_rows_scanned": dbl_rows, "key_rounds_gathered_records": int(tm.gathered_records), "unresolved_after_round0": int(tm.unresolved_after_round0),
+            "phases_ms": {k: round(v[0], 2) for k, v in kern.items()}, "kernels": kernels_json(kern),
+            "roofline": roofline_of(kern, n, "dna_tandem", True)}
+    del sa, d
+    ctx.trim()
+    torch.cuda.empty_cache()
+    if not no_cpu:
+        try:      # the reference cannot index 8 GiB (msufsort.h:47): a bounded sample of the same stream - its first 2^28 bytes, the golden vector
+            cfg5["cpu_baseline"] = cpu_baseline(1 << 28, seed, "dna_tandem", "sa", n, counts=[min(16, os.cpu_count() or 1)])
+        except Exception as e:  # noqa: BLE001
+            cfg5["cpu_baseline"] = {"error": str(e)}
+    return cfg5, ok
+
+
 def config_lines(M, torch, ctx, dev, steps, no_cpu):
     """BASELINE configs 3 and 4 under the same clock as the headline: text, 2^30 - 1 bytes (the reference's ceiling): SA,
     forward BWT as one call, inverse BWT, LCP - all resident in HBM; reference hashes from tests/golden/golden_full.json."""
@@ -562,9 +676,13 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip the config 3 / 4 lines")
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (PCIe inclusive) legs")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the config 5 line (8 GiB of tandem-repeat DNA on the one GPU: ~250 GiB of HBM, ~1 min)")
     ap.add_argument("--index", default="auto", choices=["auto", "int32", "int64"], help="N > 1: row width. auto = int64 (wide engine, 40-bit indices) beyond 2^31 - 2 bytes "
                     "(BASELINE config 5), int32 otherwise; int64 on a small input is the parity-test form of config 5")
     ap.add_argument("--check-reference", action="store_true", help="N > 1, after the timed region: rank 0 compares every row (and the BWT) with the CPU checker's (oracle/)")
+    ap.add_argument("--check-single", action="store_true", help="N > 1, after the timed region: rank 0 rebuilds the array with the single-process entry point "
+                    "(msufsort_hip_make_sa_i64_dev / _i32_dev: the path the parity tests pin to the reference) and compares every row (and the BWT) on the device - "
+                    "the check that still works beyond the reference's 2^30 - 1 bytes")
     ap.add_argument("--two-stage", type=int, default=0, help="N > 1: 0 = text-like inputs take the sharded B* sort + induction on every rank "
                     "(the library's size / alphabet policy), 1 = whenever possible, -1 = never (sort-all shards)")
     args = ap.parse_args()
@@ -646,6 +764,16 @@ def main():
                 ok = ok and cok
             except Exception as e:  # noqa: BLE001
                 out["configs"] = {"error": repr(e)}
+            for name, fn in (("cfg2", lambda: config2_line(M, torch, ctx, dev, 5, args.no_cpu)), ("cfg5", lambda: config5_line(M, torch, ctx, dev, args.no_cpu))):
+                if name == "cfg5" and args.no_cfg5:
+                    continue
+                try:
+                    out["configs"][name], cok = fn()
+                    ok = ok and cok
+                except Exception as e:  # noqa: BLE001
+                    out["configs"][name] = {"error": repr(e)}
+                    ok = False
+            out["configs"] = {k: out["configs"][k] for k in sorted(out["configs"], key=lambda k: (not k.startswith("cfg"), k))}
             if not args.no_host and "error" not in out["configs"]:
                 try:
                     floor = out.get("end_to_end_host", {}).get("pcie_floor") or pcie_floor(torch, dev, (1 << 30) - 1)
@@ -655,7 +783,8 @@ def main():
         if not args.no_cpu:
             try:
                 sample = args.cpu_sample or n
-                out["cpu_baseline"] = cpu_baseline(min(sample, n), args.seed, args.workload, "sa", n, all_threads=True)
+                out["cpu_baseline"] = cpu_baseline(min(sample, n), args.seed, args.workload, "sa", n, all_threads=True, median_of=3 if headline else 1,
+                                                    t1_prefix=(1 << 28) if headline else 0)
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
@@ -879,6 +1008,33 @@ def main():
             ok = ok and s_chk == pending["sentinel"] and bool(torch.equal(chk, d_bwt))
             against += " + BWT bytes and sentinel row equal to the transform read off the assembled rows"
             del chk
+        if args.check_single:
+            # the multi-process flow against the single-process build of the same library (pinned to the reference by tests/test_gpu_parity.py
+            # and test_gpu_full.py; beyond 2^31 - 2 bytes by the 64-bit checker in tests/test_gpu_big.py): every row, on the device
+            for k_ in ("isa", "grp_prev", "upd_local", "upd_all", "grp_all"):
+                setattr(shard_state, k_, None)
+            del sa_bufs[1:]
+            pending["buf"] = None
+            ctx.trim()
+            torch.cuda.empty_cache()
+            ref_rows = torch.empty(n + 1, dtype=row_dt, device=dev)
+            if wide:
+                ctx.make_sa_i64(d_text, n, ref_rows)
+            else:
+                ctx.make_sa(d_text, n, ref_rows)
+            same = bool(torch.equal(ref_rows, pending["last"]))
+            ok = ok and same
+            against += " + every row equal to the single-process build's (" + ("msufsort_hip_make_sa_i64_dev" if wide else "msufsort_hip_make_sa_i32_dev") + ")"
+            if want_bwt:
+                ctx.trim()
+                chk = torch.empty(n, dtype=torch.uint8, device=dev)
+                s_chk = ctx.bwt_from_sa(d_text, n, ref_rows, chk, index_bytes)
+                ok = ok and s_chk == pending["sentinel"] and bool(torch.equal(chk, d_bwt))
+                against += " + BWT bytes and sentinel row equal to the transform of the single-process rows"
+                del chk
+            del ref_rows
+            ctx.trim()
+            torch.cuda.empty_cache()
         e = golden_entry(args.workload, args.seed, n)
         if e is not None and not wide:
             try:

@@ -100,7 +100,8 @@ typedef struct msufsort_hip_timings {
     int64_t key1_records;      /* small alphabets (<= 84 codes), narrow records: suffixes whose key of the FIRST gather round was read off the
                                   text tile by k_scatter0 and carried through round 0 as a companion word (that round then gathers nothing:
                                   its records are not in gathered_records; round 0 moves 4 bytes more per suffix and pass); 0: every round gathered */
-    int64_t reserved[1];
+    int64_t doubling_records;  /* single-process sharded / wide builds (logical shards): rows the steps of the distributed prefix doubling scanned, summed
+                                  over steps and shards (each: row + group head read, the rank of suffix + h gathered, row + group head written) */
 } msufsort_hip_timings;
 /* The struct's size is part of the ABI (callers pass timings_out buffers): new fields only ever take reserved slots. */
 #ifdef __cplusplus
@@ -291,7 +292,10 @@ int msufsort_hip_bwt_slice_dev(msufsort_hip_ctx* ctx, const uint8_t* d_text, int
 /* One process, the listed devices (as msufsort_hip_make_sa_multi: NULL / 0 = MSUFSORT_DEVICES, else all visible GPUs), host bytes
  * in place: key-range shards, and what leaves a device is the BYTE in front of every suffix of a finished slice - n bytes over PCIe
  * instead of 4 (n + 1), streamed while the remaining shards are sorted (nothing lands in the caller's buffer before every device has
- * read the text from it).  Text-like and small inputs take msufsort_hip_forward_bwt on the first device. */
+ * read the text from it).  Text-like and small inputs take msufsort_hip_forward_bwt on the first device.
+ * On error the contents of `inout` are UNDEFINED: byte slices of shards that finished before a device failed have already replaced
+ * the text there (workers stop queuing copies as soon as any device has failed; the single-device msufsort_hip_forward_bwt and the
+ * reference write nothing before the whole transform exists). */
 int msufsort_hip_forward_bwt_multi(const int32_t* devices, int32_t n_dev, uint8_t* inout, int64_t n, int64_t* sentinel_row,
                                    const msufsort_hip_opts* opts, msufsort_hip_timings* timings_out);
 

@@ -30,7 +30,7 @@ class Timings(C.Structure):
                 ("ibwt_walk_us", C.c_int64), ("ibwt_total_us", C.c_int64), ("bstar_suffixes", C.c_int64),
                 ("induction_launches", C.c_int64), ("b_suffixes", C.c_int64), ("front_ms", C.c_double), ("fallbacks", C.c_int64),
                 ("progression_suffixes", C.c_int64), ("bucket_sort_handed_back", C.c_int64), ("hist17_ms", C.c_double), ("radix_bits", C.c_int64),
-                ("key1_records", C.c_int64), ("reserved", C.c_int64 * 1)]
+                ("key1_records", C.c_int64), ("doubling_records", C.c_int64)]
 
 
 # every symbol include/msufsort_hip.h declares (checked by tests/test_cabi.py)

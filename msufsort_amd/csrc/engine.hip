@@ -1518,7 +1518,7 @@ int build_logical(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* 
         if (r < 0) return r;
         acc.hist16_ms += c->tm.hist16_ms; acc.scatter0_ms += c->tm.scatter0_ms; acc.scatter1_ms += c->tm.scatter1_ms;
         acc.bucket_sort_ms += c->tm.bucket_sort_ms; acc.refine_ms += c->tm.refine_ms; acc.rounds = std::max(acc.rounds, c->tm.rounds);
-        acc.unresolved_after_round0 += c->tm.unresolved_after_round0;
+        acc.unresolved_after_round0 += c->tm.unresolved_after_round0; acc.gathered_records += c->tm.gathered_records;
         if (r == MSUFSORT_HIP_UNRESOLVED) {
             const u64 d = (u64)c->tm.stop_depth;
             if (any && d != depth) { set_error("shards stopped at different depths (%llu, %llu)", (unsigned long long)depth, (unsigned long long)d); return MSUFSORT_HIP_ERR_INTERNAL; }
@@ -1551,6 +1551,7 @@ int build_logical(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* 
                 u64 t = 0;
                 TRY((double_sort<W>(c, c->active[g], n, d_sa + lo, grp + lo, grp_prev + lo, hi - lo, isa, h, verbose, &t, &items[g])));
                 if (t == 0) live[g] = 0;           // (nothing tied: no updates either)
+                else acc.doubling_records += (int64_t)items[g];
             }
             // the ranks are read-only while ANY shard still sorts with them: the updates of all shards are applied afterwards
             for (int g = 0; g < G; ++g) {

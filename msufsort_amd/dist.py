@@ -112,24 +112,30 @@ def _window_rows(default: int) -> int:
 class ShardState:
     """Per-rank buffers of the distributed prefix doubling (allocated on first use, reused by later builds).
     Sizes for n = 2^33 over 8 ranks (BASELINE config 5; rows_max = 2^30): rank replica 8(n+2) = 64 GiB, grp_prev 4 GiB,
-    update windows 0.5 + 4 GiB, group-head windows 0.25 + 2 GiB (DESIGN.md section 3.7 has the whole budget)."""
+    update windows 0.5 + 4 GiB, group-head windows 0.25 + 2 GiB (DESIGN.md section 3.7 has the whole budget).
+    MSUFSORT_DIST_WINDOW (test hook) must be set alike on every rank: the windows size the receive buffers, and
+    _distributed_doubling checks that the ranks agree before anything travels."""
 
     def __init__(self):
         self.isa = None
         self.grp_prev = None
         self.upd_local = None
         self.upd_all = None
-        self.grp_mine = None
         self.grp_all = None
         self.stats = {}
 
     @staticmethod
+    def windows(rows_max, index_bytes):
+        """(rows per update window, rows per group-head window, 64-bit words per update) - the one place both ensure() and
+        bytes_needed() take them from."""
+        e = 2 if index_bytes == 8 else 1          # one update = ONE 64-bit word for int32 rows (new_row << 32 | suffix), TWO for int64 rows
+        return max(1, min(rows_max, _window_rows(1 << 25))), max(1, min(rows_max, _window_rows(1 << 26))), e
+
+    @staticmethod
     def bytes_needed(n, rows_max, world, index_bytes):
         """What ensure() allocates (bench.py's memory check)."""
-        e = 2 if index_bytes == 8 else 1
-        win = max(1, min(rows_max, _window_rows(1 << 25)))
-        gwin = max(1, min(rows_max, _window_rows(1 << 26)))
-        return (n + 2) * index_bytes + max(rows_max, 1) * 4 + win * e * 8 * (world + 1) + gwin * 4 * (world + 1)
+        win, gwin, e = ShardState.windows(rows_max, index_bytes)
+        return (n + 2) * index_bytes + max(rows_max, 1) * 4 + win * e * 8 * (world + 1) + gwin * 4 * world
 
     def ensure(self, n, rows_max, world, index_bytes, device):
         import torch
@@ -139,14 +145,11 @@ class ShardState:
             self.isa = torch.empty(n + 2, dtype=dt, device=device)
         if self.grp_prev is None or self.grp_prev.numel() < rows_max:
             self.grp_prev = torch.empty(max(rows_max, 1), dtype=torch.int32, device=device)
-        # one update = ONE 64-bit word for int32 rows (new_row << 32 | suffix), TWO for int64 rows ({suffix, new_row})
-        e = 2 if index_bytes == 8 else 1
-        self.win = max(1, min(rows_max, _window_rows(1 << 25)))
+        self.win, self.gwin, e = ShardState.windows(rows_max, index_bytes)
         if self.upd_local is None or self.upd_local.numel() < self.win * e:
             self.upd_local = torch.empty(self.win * e, dtype=torch.int64, device=device)
         if self.upd_all is None or self.upd_all.numel() < self.win * e * world:
             self.upd_all = torch.empty(self.win * e * world, dtype=torch.int64, device=device)
-        self.gwin = max(1, min(rows_max, _window_rows(1 << 26)))
         if self.grp_all is None or self.grp_all.numel() < self.gwin * world:
             self.grp_all = torch.empty(self.gwin * world, dtype=torch.int32, device=device)
 
@@ -176,10 +179,11 @@ def _replicate_ranks(ctx, d_sa_full, d_grp, bounds, rank, world, dist, state, in
             pre.append(pre[-1] + x)
         if cnt[rank]:
             stage[pre[rank]:pre[rank + 1]] = d_grp[w0:w0 + cnt[rank]]
+        if stage.is_cuda:
+            # the copy above ran on torch's stream; the exchange runs on the communicator's, isa_from_slice on the engine's
+            import torch
+            torch.cuda.current_stream(stage.device).synchronize()
         if _many(world):
-            if stage.is_cuda:
-                import torch
-                torch.cuda.current_stream(stage.device).synchronize()
             allgatherv_slices(stage, pre, dist)
         for g in range(world):
             if cnt[g]:
@@ -206,6 +210,14 @@ def _distributed_doubling(ctx, n, d_sa_full, d_grp, bounds, rank, world, dist, d
     sl = d_sa_full[lo:hi] if hi > lo else one
     gl = d_grp[:hi - lo] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
     gp = state.grp_prev
+    if _many(world):
+        # the exchange windows size every rank's receive buffers: the ranks must have derived the same ones (MSUFSORT_DIST_WINDOW is
+        # read per process)
+        w = torch.tensor([state.win, -state.win, state.gwin, -state.gwin], dtype=torch.int64, device=dev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        w = w.tolist()
+        if w[0] != -w[1] or w[2] != -w[3]:
+            raise _lib.MsufsortHipError(f"exchange windows differ between ranks (updates {-w[1]} .. {w[0]}, group heads {-w[3]} .. {w[2]}): set MSUFSORT_DIST_WINDOW alike everywhere")
     _replicate_ranks(ctx, d_sa_full, d_grp, bounds, rank, world, dist, state, index_bytes)
     st = {"doubling_steps": 0, "sort_ms": 0.0, "exchange_ms": 0.0, "updates": 0, "depth": depth, "index_bytes": index_bytes, "windows": 0}
     win = state.win
@@ -319,27 +331,69 @@ def plan_sharded(ctx, d_text, n: int, rank: int, world: int, dist, stats=None, g
     if n < 1:
         return None
     dev = device if device is not None else d_text.device
-    h = torch.empty(65536, dtype=torch.int64, device=dev)
-    total, s0, s1 = ctx.hist_part(d_text, n, rank, world, h)
-    if total == 0:          # (nothing but zero bytes: every rank sees that alike)
+
+    def sync():          # the collectives run on the communicator's stream, torch's copies on torch's, the C calls on the engine's
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+
+    # A rank-local failure between the collectives (an allocation, a C call) must not leave the peers blocked in the next one:
+    # every rank's status travels WITH the data (a spare word of the totals; a 4-byte all-reduce before the all-gather) and all
+    # ranks leave together - the same relay the two-stage exchange has (build_sa_two_stage_sharded).
+    h = torch.zeros(65537, dtype=torch.int64, device=dev)          # [65536]: ranks that failed counting their part
+    total = 0
+    err = None
+    try:
+        total, s0, s1 = ctx.hist_part(d_text, n, rank, world, h[:65536])
+    except Exception as e:  # noqa: BLE001
+        err = e
+        h.zero_()
+        h[65536] = 1
+    if total == 0 and err is None:          # (nothing but zero bytes: every rank sees that alike)
         return None
     if _many(world):
+        sync()
         dist.all_reduce(h, group=group)
+    sync()                                   # hist_plan reads the reduced totals on the engine's stream
+    if err is not None or int(h[65536].item()):
+        raise err if err is not None else _lib.MsufsortHipError("sharded histogram: a peer failed counting its stripes")
     per = max(1, -(-total // world))
-    sums = torch.empty((world, per, 256), dtype=torch.int32, device=dev)
-    bounds = ctx.hist_plan(d_text, n, world, h, sums)
-    if bounds is None:
+    bounds, sums = None, None
+    status = 0                               # 0 planned, 1 the plan needs a replicated histogram (every rank alike), 2 failed here
+    try:
+        sums = torch.empty((world, per, 256), dtype=torch.int32, device=dev)
+        bounds = ctx.hist_plan(d_text, n, world, h[:65536], sums)
+        if bounds is None:
+            status = 1
+    except Exception as e:  # noqa: BLE001
+        err, status = e, 2
+    if _many(world):
+        flag = torch.tensor([status], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        agreed = int(flag.item())
+    else:
+        agreed = status
+    if agreed == 2:
+        raise err if err is not None else _lib.MsufsortHipError("sharded histogram: a peer failed planning the shards")
+    if agreed == 1:
         return None
     if world > 1:
         got = [torch.empty_like(sums) for _ in range(world)]
+        sync()
         dist.all_gather(got, sums, group=group)
     else:
         if _many(world):
+            sync()
             dist.all_gather([torch.empty_like(sums)], sums, group=group)        # (the one-rank RCCL hook: the collective is issued all the same)
         got = [sums]
     # part p counted the stripes [total p / world, total (p + 1) / world): its block for MY shard, in text order
     mine = torch.cat([got[p][rank, :(total * (p + 1) // world - total * p // world)] for p in range(world)]) if total else sums[rank, :0]
-    ctx.hist_install(rank, mine.contiguous())
+    mine = mine.contiguous()
+    sync()                                   # (the gathered blocks assembled on torch's stream before the engine's stream reads them)
+    try:
+        ctx.hist_install(rank, mine)
+    except _lib.MsufsortHipError:
+        # local and recoverable: nothing collective depends on it - this rank's shard build counts for itself (same plan: same totals)
+        return bounds
     if stats is not None:
         stats["sharded_hist"] = stats.get("sharded_hist", 0) + 1
     return bounds

@@ -313,3 +313,53 @@ def test_update_offsets_and_bwt_bounds():
     assert D.bwt_slice_bounds([0, 3, 7, 11], 3) == [0, 3, 6, 10]          # sentinel = first row of a slice
     assert D.bwt_slice_bounds([0, 3, 7, 11], 10) == [0, 3, 7, 10]         # ... = last row of all
     assert D.ShardState.bytes_needed(1 << 33, 1 << 30, 8, 8) < 80 << 30   # 64 GiB replica + windows
+
+
+def _worker_hist_failure(rank, world, port, tmp, stage):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), MSUFSORT_DIST_SHARDED_HIST="1")
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    from msufsort_amd import _lib
+    from msufsort_amd import dist as D
+    from msufsort_amd import gen
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        t = gen.random_bytes(20000, 5)
+        n = t.size
+        cuts, rows = D.plan_cuts(_bstart(t), n, 0, world)
+        eng = _ModelEngine(t, oracle.make_suffix_array(t), cuts, rows, depth=6)
+        if rank == 1:          # ONE rank fails, in the C call of the given stage
+            def boom(*a, **k):
+                raise _lib.MsufsortHipError("injected failure in " + stage)
+            setattr(eng, stage, boom)
+        out = "returned"
+        try:
+            got = D.plan_sharded(eng, torch.zeros(1, dtype=torch.uint8), n, rank, world, dist)
+            out = "bounds" if got == list(rows) else f"other {got}"
+        except _lib.MsufsortHipError as e:
+            out = "raised: " + str(e)
+        open(os.path.join(tmp, f"h{rank}"), "w").write(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stage", ["hist_part", "hist_plan", "hist_install"])
+def test_sharded_histogram_failure_on_one_rank_reaches_every_rank(stage, tmp_path, oracle_mod):
+    """dist.plan_sharded: a rank-local failure between its collectives must not leave the peers blocked in the next one (round-5
+    advisor finding).  hist_part / hist_plan: every rank raises (the status travels with the totals / ahead of the all-gather);
+    hist_install comes after the last collective: the failing rank alone falls back to counting for itself - same plan."""
+    import torch.multiprocessing as mp
+    world = 3
+    port = 29300 + os.getpid() % 500 + {"hist_part": 0, "hist_plan": 1, "hist_install": 2}[stage]
+    mp.spawn(_worker_hist_failure, args=(world, port, str(tmp_path), stage), nprocs=world, join=True)
+    res = [open(tmp_path / f"h{r}").read() for r in range(world)]
+    if stage == "hist_install":
+        assert res == ["bounds"] * world, res
+    else:
+        assert all(r.startswith("raised") for r in res), res
+        assert "injected failure" in res[1] and "a peer failed" in res[0] and "a peer failed" in res[2], res

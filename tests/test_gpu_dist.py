@@ -232,3 +232,46 @@ def test_bench_dist_path_on_rccl_with_one_rank(args):
     assert d["valid"] is True and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1 and d["n_gpus"] == 1
     if args[1] == "random":
         assert d["histogram"].startswith("counted 1/1 per rank")      # hist_part -> all-reduce -> hist_plan -> all-gather -> hist_install, on RCCL
+
+
+@pytest.mark.parametrize("window", [0, 1 << 23])
+def test_bench_int64_rows_at_a_size_that_needs_them_on_rccl(window):
+    """BASELINE config 5's own code path (`bench.py --gpus N --index auto` -> dist.build_sa_sharded(index_bytes=8), ShardState,
+    _replicate_ranks, _distributed_doubling, forward_bwt_sharded) at a size that NEEDS int64 rows: n = 2^31 + 12,345 bytes of
+    tandem-repeat DNA, ONE rank on RCCL forced through the N > 1 flow with every collective issued - nothing travels between ranks, but
+    every offset, window count, update and bounds[] entry of the Python flow is beyond 32 bits for real (the reference's index is
+    int32 with two flag bits: msufsort.h:47, 84-93).  Checked on the device: the 64-bit checker, every row equal to the single-process
+    build's (msufsort_hip_make_sa_i64_dev, the path test_gpu_big.py / test_gpu_parity.py pin), BWT bytes + sentinel row likewise.
+    window = 0: the default exchange windows (2^25 updates, 2^26 group heads: dozens per step at this size); 2^23: four times as many."""
+    import gc
+
+    import torch
+    sys.path.insert(0, ROOT)
+    from msufsort_amd import _lib
+    gc.collect()
+    torch.cuda.empty_cache()
+    _lib.lib().msufsort_hip_release_cached()          # (what earlier tests of this process left in the one-shot entry points' contexts)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 235 << 30:
+        pytest.skip(f"needs ~225 GiB of free HBM ({free >> 30} GiB free)")
+    n = (1 << 31) + 12345
+    env = {k: v for k, v in os.environ.items() if k not in ("MSUFSORT_BENCH_BACKEND", "MSUFSORT_BENCH_ONE_DEVICE", "MSUFSORT_DIST_WINDOW")}
+    env.update(MSUFSORT_BENCH_FORCE_DIST="1", MSUFSORT_DIST_ALWAYS_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if window:
+        env["MSUFSORT_DIST_WINDOW"] = str(window)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29641",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu", "--check-single", "--workload", "dna_tandem", "--size", str(n),
+           "--index", "auto", "--op", "sa,fbwt"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=2400, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[-1])
+    assert d["valid"] is True and "single-process" in d["valid_against"] and "BWT" in d["valid_against"]
+    assert d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1 and d["config"]["index"] == "int64" and d["config"]["n"] == n
+    db = d["doubling"]
+    assert db["index_bytes"] == 8 and db["doubling_steps"] >= 2 and db["updates"] > (1 << 28)
+    assert db["windows"] >= db["doubling_steps"] + (32 if window else 8)            # several exchange windows in the steps that have work
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, f"r06_one_rank_rccl_int64_2pow31_window{window}.json"), "w") as f:
+            f.write(lines[-1] + "\n")
