@@ -82,7 +82,7 @@ struct Copier;        // thread that sends finished row ranges to the host while
 // build, not in its rounds) - they are test hooks and A/B levers, not part of the C-ABI.
 struct Switches {
     bool no_refine = false, safe_rank = false, bucket_fast2 = false, no_fast = false, force_fast = false, no_chains = false;
-    bool force_retry = false, no_pack = false, no_fuse = false, ind_classic = false, no_ring = false;
+    bool force_retry = false, no_pack = false, no_fuse = false, ind_classic = false, no_ring = false, mid_single = false;
     int text_rounds = 0;         // MSUFSORT_HIP_TEXT_ROUNDS (0: unset)
     int digit_bits = 24;         // MSUFSORT_HIP_DIGIT_BITS
     int two_stage = 0; bool two_stage_set = false;      // MSUFSORT_HIP_TWO_STAGE overrides opts->two_stage
@@ -105,7 +105,7 @@ struct Switches {
         { const char* e = getenv("MSUFSORT_HIP_BUCKET_SORT"); bucket_fast2 = e && !strcmp(e, "fast2"); }
         no_fast = on("MSUFSORT_HIP_NO_FAST"); force_fast = on("MSUFSORT_HIP_FORCE_FAST"); no_chains = on("MSUFSORT_HIP_NO_CHAINS");
         force_retry = on("MSUFSORT_HIP_FORCE_RETRY"); no_pack = on("MSUFSORT_HIP_NO_PACK"); no_fuse = on("MSUFSORT_HIP_NO_FUSE");
-        ind_classic = on("MSUFSORT_HIP_IND_CLASSIC"); no_ring = on("MSUFSORT_HIP_NO_RING");
+        ind_classic = on("MSUFSORT_HIP_IND_CLASSIC"); no_ring = on("MSUFSORT_HIP_NO_RING"); mid_single = on("MSUFSORT_HIP_MID_SINGLE");
         text_rounds = std::max(0, num("MSUFSORT_HIP_TEXT_ROUNDS", 0));
         digit_bits = std::min(24, std::max(2, num("MSUFSORT_HIP_DIGIT_BITS", 24)));
         two_stage_set = on("MSUFSORT_HIP_TWO_STAGE"); two_stage = num("MSUFSORT_HIP_TWO_STAGE", 0);
@@ -932,7 +932,14 @@ struct Rounds {
                     bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, emB, counters, ids, (u32)C_FBB, gather, code);
                 DBG("k_sort_mid B");
             }
-            if (nA && ax0) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W, !W><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
+            // class A (33 .. 512 records): several segments per wave (k_sort_mid_tiles, round 6); MSUFSORT_HIP_MID_SINGLE=1: one segment
+            // at a time (the 64-thread instance of k_sort_mid, rounds 2 - 5)
+            const u32 gridA = std::min<u32>(cdiv(nA, MIDT_BUN), 8192u);
+            if (nA && !c->sw.mid_single && ax0) k_sort_mid_tiles<W, !W><<<dim3(gridA), dim3(64), 0, st>>>(
+                        bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, gather, code);
+            else if (nA && !c->sw.mid_single) k_sort_mid_tiles<W><<<dim3(gridA), dim3(64), 0, st>>>(
+                        bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, gather, code);
+            else if (nA && ax0) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W, !W><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
                         bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, (const u32*)nullptr, 0u, gather, code);
             else if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
                         bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, (const u32*)nullptr, 0u, gather, code);
@@ -1220,6 +1227,12 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
                 HIP_TRY(hipGetLastError());
                 float ms_ = 0;
                 (void)hipEventElapsedTime(&ms_, c->ev[0], c->ev[5]); tm.total_ms = ms_;
+                // (the phase clocks of a shard that hands over to the distributed doubling: what build_logical sums into the line of BASELINE config 5)
+                (void)hipEventElapsedTime(&ms_, c->ev[0], c->ev[1]); tm.hist16_ms = ms_;
+                (void)hipEventElapsedTime(&ms_, c->ev[1], c->ev[2]); tm.scatter0_ms = ms_;
+                (void)hipEventElapsedTime(&ms_, c->ev[2], c->ev[3]); tm.scatter1_ms = ms_;
+                (void)hipEventElapsedTime(&ms_, c->ev[3], c->ev[4]); tm.bucket_sort_ms = ms_;
+                (void)hipEventElapsedTime(&ms_, c->ev[4], c->ev[5]); tm.refine_ms = ms_;
                 tm.stop_depth = (int64_t)depth;
                 return MSUFSORT_HIP_UNRESOLVED;
             }

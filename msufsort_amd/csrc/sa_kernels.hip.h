@@ -2480,6 +2480,413 @@ __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Class-A segments (33 .. 512 records), SEVERAL PER WAVE (round 6; the role of multikey_insertion_sort / the small
+// partitions of multikey_quicksort, reference cpp:223-312, cpp:488-642).
+// The one-wave instance of k_sort_mid handles one segment at a time: a chain of four or five dependent memory round trips
+// (descriptor -> records -> keys -> reservation -> emitted records) per ~100 records, ~46 K cycles whatever the length
+// (profiles/r05_mid_prof_text.txt) - the largest single kernel of the text build.  Here a wave takes a BUNDLE of 16
+// consecutive descriptors (one coalesced 256-byte load, the next bundle's in flight while this one is sorted) and packs
+// them greedily into TILES of up to 8 segments / 512 records; a tile goes through every phase ONCE:
+//   * all its records are loaded (and, in text rounds, all its keys gathered) in one round trip;
+//   * ONE least-significant-digit sort of the tile on the virtual key  segment number : key bits that vary inside some
+//     segment  (bits above the highest varying bit are constant inside every segment, so the segment number takes their
+//     place: text keys of 29 bits + 3 bits of segment number are the same four 8-bit passes one segment needs);
+//     what is permuted per pass is (key, slot): the slot word names the record's place in the loaded tile (and its
+//     segment), the suffix index and the companion are fetched through LDS once, after the last pass;
+//   * equal-key runs from ballot bitmaps as in sort_mid_segment, with a run boundary forced at every segment boundary;
+//   * ONE reservation and ONE compaction of the still-tied runs for the whole tile.
+// Rows, ranks, group heads, emitted records and descriptors are what sort_mid_segment writes for the same segments.
+// ------------------------------------------------------------------------------------------------
+#define MIDT_BUN 16          // descriptors per bundle
+#define MIDT_KMAX 8          // segments per tile
+#ifndef MIDT_WAVES
+#define MIDT_WAVES 4         // waves per SIMD the register allocation aims at (128 VGPRs)
+#endif
+template <bool W, bool AUX = false>
+__global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs, const Desc* __restrict__ list, u32 nseg,
+                                                      typename Wd<W>::sa_t* __restrict__ sa_out, u32* __restrict__ isa, u32 mode,
+                                                      Emit em, u32* __restrict__ counters, GatherSpec g, const u8* __restrict__ code)
+{
+    constexpr u32 KL = klow<W>();
+    constexpr int ITEMS = 8, CAP = 512, NW = 8;
+    __shared__ __attribute__((aligned(16))) u32 ex[CAP];
+    __shared__ u32 wcnt[256];
+    __shared__ u64 bm_eq[NW], bm_tiny[NW], bm_seg[NW];
+    __shared__ u32 pre_tiny[NW], pre_seg[NW];
+    __shared__ u32 misc[8], ach[24];
+    __shared__ Desc dtab[MIDT_BUN];
+    __shared__ u32 st_pre[MIDT_KMAX + 1], st_sab[MIDT_KMAX], st_flag[MIDT_KMAX], st_key0[MIDT_KMAX];
+    __shared__ u32 st_roff[MIDT_KMAX];                        // first record of the segment (in its record buffer) minus its first tile position
+    __shared__ u8 s_code[256];
+#ifdef MID_PROF
+    __shared__ unsigned long long mprof[16];
+    if (threadIdx.x == 0) { for (int i = 0; i < 15; ++i) mprof[i] = 0; mprof[15] = clock64(); }
+#endif
+    const u32 lane = threadIdx.x;
+    const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    if (lane < 24) ach[lane] = 0;
+    if (g.text) for (u32 i = lane; i < 256u; i += 64u) s_code[i] = code[i];
+    const u32 nbun = (nseg + MIDT_BUN - 1) / MIDT_BUN;
+    const u32 rank0 = counters[C_RANK0];
+    Desc dn = {0, 0, 0, 0};
+    { const u64 i = (u64)blockIdx.x * MIDT_BUN + lane; if (lane < MIDT_BUN && i < nseg) dn = list[i]; }
+    for (u32 b = blockIdx.x; b < nbun; b += gridDim.x) {
+        __syncthreads();
+        if (lane < MIDT_BUN) dtab[lane] = dn;
+        {   // the next bundle's descriptors travel while this one is sorted
+            const u64 i = ((u64)b + gridDim.x) * MIDT_BUN + lane;
+            const Desc z = {0, 0, 0, 0};
+            dn = z;
+            if (lane < MIDT_BUN && i < nseg) dn = list[i];
+        }
+        __syncthreads();
+        u32 start = 0;
+        while (start < MIDT_BUN) {
+            // ---- pack the next tile: consecutive descriptors while they fit (neutral entries, len 0, are skipped) ----
+            u32 e = start, T = 0, K = 0;
+            while (e < MIDT_BUN) {
+                const u32 l = dtab[e].len;
+                if (l != 0) {
+                    if (K == MIDT_KMAX || T + l > (u32)CAP) break;
+                    if (lane == 0) {
+                        const Desc d = dtab[e];
+                        st_pre[K] = T; st_sab[K] = d.sa_off - T; st_flag[K] = d.buf; st_roff[K] = d.rec_off - T;
+                    }
+                    T += l; ++K;
+                }
+                ++e;
+            }
+            start = e;
+            if (K == 0) break;
+            if (lane <= MIDT_KMAX && lane >= K) st_pre[lane] = lane == K ? T : 0xffffffffu;
+            if (lane < 8) misc[lane] = 0;
+            __syncthreads();
+            MPROF(6);
+#ifdef MID_PROF
+            if (threadIdx.x == 0) { mprof[8] += 1; mprof[9] += T; }
+#endif
+            const int rows = (int)((T + 63u) / 64u);
+            // segment of every tile position this lane holds (3 bits per slot; the same before and after the sort)
+            u32 segpack = 0;
+            {
+                u32 pk[MIDT_KMAX - 1];
+#pragma unroll
+                for (int k = 0; k < MIDT_KMAX - 1; ++k) pk[k] = st_pre[k + 1];
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    const u32 p = j * 64 + lane;
+                    u32 sg = 0;
+#pragma unroll
+                    for (int k = 0; k < MIDT_KMAX - 1; ++k) sg += p >= pk[k] ? 1u : 0u;
+                    segpack |= sg << (3 * j);
+                }
+            }
+#define MIDT_SEG(j) ((segpack >> (3 * (j))) & 7u)
+            u32 key[ITEMS], idx[ITEMS], slot[ITEMS], pos[ITEMS];
+            u32 ax[AUX ? ITEMS : 1];
+            // ---- all records of the tile in one round trip ----
+            if (g.text == nullptr) {
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    const u32 p = j * 64 + lane;
+                    key[j] = 0xffffffffu; idx[j] = 0xffffffffu; slot[j] = 0xffffffffu;
+                    if constexpr (AUX) ax[j] = 0;
+                    if (j < rows && p < T) {
+                        const u32 sg = MIDT_SEG(j);
+                        const u32 bi = st_flag[sg] & 3u, ro = st_roff[sg] + p;
+                        const u64 r = (bi == 0u ? bufs.p[0] : (bi == 1u ? bufs.p[1] : bufs.p[2]))[ro];
+                        key[j] = (u32)(r >> 32); idx[j] = (u32)r; slot[j] = p | (sg << 16);
+                        if constexpr (AUX) ax[j] = (bi == 0u ? bufs.x[0] : (bi == 1u ? bufs.x[1] : bufs.x[2]))[ro];
+                    }
+                }
+            } else {        // text round: the records carry the suffix index only, the keys are gathered here
+                typename Wd<W>::sa_t fi[ITEMS];
+                bool valid[ITEMS];
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    const u32 p = j * 64 + lane;
+                    valid[j] = j < rows && p < T;
+                    const u32 sg = MIDT_SEG(j);
+                    const u32 bi = st_flag[sg] & 3u, ro = st_roff[sg] + p;
+                    fi[j] = valid[j] ? rec_idx<W>((bi == 0u ? bufs.p[0] : (bi == 1u ? bufs.p[1] : bufs.p[2]))[ro]) : 0;
+                    slot[j] = valid[j] ? (p | (sg << 16)) : 0xffffffffu;
+                }
+#ifdef MID_PROF
+                asm volatile("" :: "v"(fi[0]));
+                MPROF(0);
+#endif
+                gather_keys<W, ITEMS, 8>(g, s_code, fi, valid, key);
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    idx[j] = valid[j] ? (u32)fi[j] : 0xffffffffu;
+                    if constexpr (W) { if (valid[j]) key[j] = (key[j] & 0xffffff00u) | (u32)(fi[j] >> 32); }      // the index byte rides in the key word
+                }
+            }
+            // ---- key bits that vary inside some segment (against each segment's first key) ----
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 p = j * 64 + lane;
+                if (j < rows && p < T) { const u32 sg = MIDT_SEG(j); if (p == st_pre[sg]) st_key0[sg] = key[j]; }
+            }
+            __syncthreads();
+            u32 diff = 0;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 p = j * 64 + lane;
+                if (j < rows && p < T) diff |= key[j] ^ st_key0[MIDT_SEG(j)];
+            }
+            diff = wave_or(diff) & (0xffffffffu << KL);      // (wide: the index byte never decides a pass; equal keys keep their order)
+            MPROF(1);
+            if (diff) {
+                // virtual key = segment : key bits [tz, hb]; the records start out in segment order, so without varying bits nothing moves
+                const u32 tz = (u32)__ffs((int)diff) - 1u, hb = 31u - (u32)__clz((int)diff);
+                const u32 nbits = hb - tz + 1u;
+                const u32 sbits = K > 1u ? 32u - (u32)__clz((int)(K - 1u)) : 0u;
+                const u32 kmask = nbits >= 32u ? 0xffffffffu : ((1u << nbits) - 1u);
+                const u32 dvar = diff >> tz;
+#pragma nounroll
+                for (u32 sh = 0; sh < nbits + sbits; sh += 8) {
+                    if (sh + 8u <= nbits && ((dvar >> sh) & 255u) == 0u) continue;      // byte equal inside every segment, no segment bits in it
+                    for (u32 i = lane; i < 256u; i += 64u) wcnt[i] = 0;
+                    __syncthreads();
+#define MIDT_DIGIT(j) ((u32)(((((u64)(slot[j] >> 16)) << nbits) | (u64)((key[j] >> tz) & kmask)) >> sh) & 255u)
+                    if (!em.safe_rank) {
+                        // stable rank inside the wave = what a returning LDS atomic hands back (see sort_mid_segment)
+#pragma unroll
+                        for (int j = 0; j < ITEMS; ++j)
+                            if (j < rows) { const u32 dg = MIDT_DIGIT(j); pos[j] = atomicAdd(&wcnt[dg], 1u) | (dg << 16); }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < ITEMS; ++j) {
+                            if (j < rows) {
+                                const u32 dg = MIDT_DIGIT(j);
+                                u64 mask = ~0ull;
+#pragma unroll
+                                for (int bb = 0; bb < 8; ++bb) {
+                                    const bool bit = (dg >> bb) & 1u;
+                                    const u64 bal = __ballot(bit);
+                                    mask &= bit ? bal : ~bal;
+                                }
+                                const int leader = __ffsll((long long)mask) - 1;
+                                u32 old = 0;
+                                if ((int)lane == leader) old = atomicAdd(&wcnt[dg], (u32)__popcll(mask));
+                                old = __shfl(old, leader, 64);
+                                pos[j] = (old + (u32)__popcll(mask & lt_mask)) | (dg << 16);
+                            }
+                        }
+                    }
+#undef MIDT_DIGIT
+                    __syncthreads();
+                    scan256_first_wave(wcnt, wcnt);      // in place: a lane reads its four counts, then writes their prefixes
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < ITEMS; ++j)
+                        if (j < rows) { pos[j] = (pos[j] & 0xffffu) + wcnt[pos[j] >> 16]; ex[pos[j]] = key[j]; }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < ITEMS; ++j) if (j < rows) key[j] = ex[j * 64 + lane];
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[pos[j]] = slot[j];
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < ITEMS; ++j) if (j < rows) slot[j] = ex[j * 64 + lane];
+                    __syncthreads();
+                }
+                // the suffix indices (and companions) follow their records: one exchange, whatever the number of passes
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[j * 64 + lane] = idx[j];
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) if (j < rows) idx[j] = slot[j] != 0xffffffffu ? ex[slot[j] & 0xffffu] : 0xffffffffu;
+                __syncthreads();
+                if constexpr (AUX) {
+#pragma unroll
+                    for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[j * 64 + lane] = ax[j];
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < ITEMS; ++j) if (j < rows) ax[j] = slot[j] != 0xffffffffu ? ex[slot[j] & 0xffffu] : 0u;
+                    __syncthreads();
+                }
+            }
+            MPROF(2);
+            // ---- equal-key runs (never across a segment boundary) ----
+            u32 rs[ITEMS], rl[ITEMS];
+            bool any_eq = false;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[j * 64 + lane] = key[j];
+            if (lane < (u32)NW) { bm_eq[lane] = 0; bm_tiny[lane] = 0; bm_seg[lane] = 0; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = j * 64 + lane;
+                    const bool inner = (p < T) && (p + 1u != st_pre[MIDT_SEG(j) + 1u]);        // my right neighbour belongs to my segment
+                    const u32 nk = ex[p + 1u < (u32)CAP ? p + 1u : (u32)CAP - 1u] >> KL;
+                    const bool eqn = inner && ((key[j] >> KL) == nk);
+                    if (inner && ((key[j] >> KL) > nk)) atomicOr(&counters[C_ERR], 0x200u);      // not sorted: the LDS-atomic ranks were not stable after all
+                    const u64 bal = __ballot(eqn);
+                    if (lane == 0) bm_eq[j] = bal;
+                    any_eq |= (bal != 0);
+                }
+            __syncthreads();
+            {   // pre_tiny[w] = start of a run that enters word w from the left, pre_seg[w] = end of a run that leaves it to the right
+                const int w = (int)lane;
+                const u64 z = w < NW ? ~bm_eq[w] : ~0ull;
+                const u32 vs = z ? (u32)((w << 6) + 64 - __clzll((long long)z)) : 0u;
+                const u32 ve = z ? (u32)((w << 6) + __ffsll((long long)z) - 1) : 0xffffffffu;
+                const u32 pmx = wave_incl_scan_max_dpp(vs);
+                const u32 smn = ~(u32)__shfl(wave_incl_scan_max_dpp(~(u32)__shfl(ve, 63 - (int)lane, 64)), 63 - (int)lane, 64);
+                u32 run_s = __shfl_up(pmx, 1, 64); if (lane == 0) run_s = 0;
+                u32 run_e = __shfl_down(smn, 1, 64); if (lane == 63) run_e = 0xffffffffu;
+                if (w < NW) { pre_tiny[w] = run_s; pre_seg[w] = run_e; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = j * 64 + lane;
+                    rs[j] = p; rl[j] = 1;
+                    if (p < T) {
+                        const u32 w = p >> 6, bit = p & 63u;
+                        const u64 z = ~bm_eq[w];
+                        const u64 below = bit ? (z & (~0ull >> (64 - bit))) : 0ull;
+                        const u64 above = z & (~0ull << bit);
+                        const u32 s = below ? (u32)((w << 6) + 64 - __clzll((long long)below)) : pre_tiny[w];
+                        const u32 e2 = above ? (u32)((w << 6) + __ffsll((long long)above) - 1) : pre_seg[w];
+                        rs[j] = s; rl[j] = e2 - s + 1;
+                        const u32 sg = MIDT_SEG(j);
+                        const u32 sab = st_sab[sg];                     // the segment's first row minus its first tile position
+                        sa_out[sab + p] = full_idx<W>(key[j], idx[j]);
+                        if (mode == MODE_ISA && (s != st_pre[sg] || (st_flag[sg] & DESC_STALE))) isa[idx[j]] = rank0 + sab + s + 1u;
+                        if (mode == MODE_DEFER) em.grp_out[sab + p] = sab + s;
+                    }
+                }
+            MPROF(3);
+            if (em.discard || !any_eq) continue;           // (any_eq is wave-uniform: it comes from ballots)
+
+            // ---- compact the still-tied runs of the whole tile into next round's structures: ONE reservation ----
+            u32 hc[3] = {0, 0, 0};           // run heads per size class (wave-uniform)
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = j * 64 + lane;
+                    const bool tied = (p < T) && rl[j] > 1;
+                    const u64 bt = __ballot(tied && rl[j] <= TINY_MAX);
+                    const u64 bs = __ballot(tied && rl[j] > TINY_MAX);
+                    if (lane == 0) { bm_tiny[j] = bt; bm_seg[j] = bs; }
+                    if (bs) {
+                        const bool head = tied && rl[j] > TINY_MAX && p == rs[j];
+                        const u32 cls = class_of(rl[j]);
+#pragma unroll
+                        for (u32 k = 0; k < 3; ++k) hc[k] += (u32)__popcll(__ballot(head && cls == k));
+                    }
+                }
+            __syncthreads();
+            {
+                const int w = (int)lane;
+                const u32 ct = w < NW ? (u32)__popcll(bm_tiny[w]) : 0u;
+                const u32 cs = w < NW ? (u32)__popcll(bm_seg[w]) : 0u;
+                u32 tt, ts;
+                const u32 et = wave_excl_scan(ct, tt);
+                const u32 es = wave_excl_scan(cs, ts);
+                if (w < NW) { pre_tiny[w] = et; pre_seg[w] = es; }
+                if (lane == 0) {
+                    u32 bt = 0, bs = 0, bad = 0;
+                    u32* pf = ach + 10;                       // pending fills: (begin, end) x {pool, seg, desc A, desc B, desc C}
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) pf[k] = 0;
+                    if (tt) {
+                        if (ach[0] + tt > ach[1]) {
+                            pf[0] = ach[0]; pf[1] = ach[1];
+                            const u32 sz = tt > em.pool_chunk ? tt : em.pool_chunk;
+                            const u32 b0 = atomicAdd(&counters[em.pool_cnt_idx], sz);
+                            if ((u64)b0 + sz > em.pool_cap) { atomicOr(&counters[C_ERR], 32u); bad = 1; ach[0] = 0; ach[1] = 0; }
+                            else { ach[0] = b0; ach[1] = b0 + sz; }
+                        }
+                        if (!bad) { bt = ach[0]; ach[0] += tt; }
+                    }
+                    if (ts) {
+                        if (ach[2] + ts > ach[3]) {
+                            pf[2] = ach[2]; pf[3] = ach[3];
+                            const u32 sz = ts > em.seg_chunk ? ts : em.seg_chunk;
+                            const u32 b0 = atomicAdd(&counters[em.seg_cnt_idx], sz);
+                            if ((u64)b0 + sz > em.seg_cap) { atomicOr(&counters[C_ERR], 64u); bad = 1; ach[2] = 0; ach[3] = 0; }
+                            else { ach[2] = b0; ach[3] = b0 + sz; }
+                        }
+                        if (!bad) { bs = ach[2]; ach[2] += ts; }
+#pragma unroll
+                        for (u32 k = 0; k < 3; ++k) {
+                            const u32 need = hc[k];
+                            if (need && ach[4 + 2 * k] + need > ach[5 + 2 * k]) {
+                                pf[4 + 2 * k] = ach[4 + 2 * k]; pf[5 + 2 * k] = ach[5 + 2 * k];
+                                const u32 dch = em.seg_chunk ? (k == 0 ? 64u : (k == 1 ? 16u : 4u)) : 0u;      // (chunk per DESTINATION class: sort_mid_segment)
+                                const u32 sz = need > dch ? need : dch;
+                                const u32 b0 = atomicAdd(&counters[em.lists.cnt_idx + k], sz);
+                                if ((u64)b0 + sz > em.lists.cap[k]) { atomicOr(&counters[C_ERR], 1u); bad = 1; ach[4 + 2 * k] = 0; ach[5 + 2 * k] = 0; }
+                                else { ach[4 + 2 * k] = b0; ach[5 + 2 * k] = b0 + sz; }
+                            }
+                        }
+                    }
+                    misc[1] = bt; misc[2] = bs; misc[3] = bad;
+                }
+            }
+            __syncthreads();
+            MPROF(4);
+            if (misc[3]) continue;
+            {   // neutral-fill the chunk tails that were just abandoned
+                const u32* pf = ach + 10;
+                for (u32 i = pf[0] + lane; i < pf[1]; i += 64u) { em.pool_rec[i] = 0; em.pool_hdr[i] = 0; }
+                for (u32 i = pf[2] + lane; i < pf[3]; i += 64u) em.seg_rec[i] = 0;
+#pragma unroll
+                for (u32 k = 0; k < 3; ++k)
+                    for (u32 i = pf[4 + 2 * k] + lane; i < pf[5 + 2 * k]; i += 64u) { const Desc z = {0, 0, 0, 0}; em.lists.cls[k][i] = z; }
+            }
+            const u32 base_t = misc[1], base_s = misc[2];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j < rows) {
+                    const u32 p = j * 64 + lane;
+                    if (p < T && rl[j] > 1) {
+                        const u32 sab = st_sab[MIDT_SEG(j)];
+                        if (rl[j] <= TINY_MAX) {
+                            const u32 o = base_t + pre_tiny[j] + (u32)__popcll(bm_tiny[j] & lt_mask);
+                            u64 r = (u64)full_idx<W>(key[j], idx[j]);
+                            if constexpr (AUX) r |= (u64)ax[j] << 32;        // next round's key comes with the record
+                            em.pool_rec[o] = r;
+                            em.pool_hdr[o] = pack_hdr(sab + rs[j], rl[j], p - rs[j]);
+                        } else {
+                            const u32 o = base_s + pre_seg[j] + (u32)__popcll(bm_seg[j] & lt_mask);
+                            u64 r = (u64)full_idx<W>(key[j], idx[j]);
+                            if constexpr (AUX) r |= (u64)ax[j] << 32;
+                            em.seg_rec[o] = r;
+                            if (p == rs[j]) {
+                                const Desc nd = {o, rl[j], sab + rs[j], em.seg_buf};
+                                const u32 cls = class_of(rl[j]);
+                                em.lists.cls[cls][atomicAdd(&ach[4 + 2 * cls], 1u)] = nd;      // room was reserved above
+                            }
+                        }
+                    }
+                }
+            MPROF(5);
+#undef MIDT_SEG
+            __syncthreads();
+        }
+    }
+#ifdef MID_PROF
+    if (threadIdx.x == 0) for (int i = 0; i < 15; ++i) atomicAdd(&g_mid_prof[0][i], mprof[i]);
+#endif
+    __syncthreads();
+    // give back what is left of my chunks as neutral entries
+    for (u32 i = ach[0] + lane; i < ach[1]; i += 64u) { em.pool_rec[i] = 0; em.pool_hdr[i] = 0; }
+    for (u32 i = ach[2] + lane; i < ach[3]; i += 64u) em.seg_rec[i] = 0;
+#pragma unroll
+    for (u32 k = 0; k < 3; ++k)
+        for (u32 i = ach[4 + 2 * k] + lane; i < ach[5 + 2 * k]; i += 64u) { const Desc z = {0, 0, 0, 0}; em.lists.cls[k][i] = z; }
+}
+
+
 // length of the common prefix of the suffixes a and b (8 bytes per step)
 __device__ __forceinline__ u32 dev_match_length(const u8* __restrict__ text, u64 n, u64 a, u64 b)
 {
