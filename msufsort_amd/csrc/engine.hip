@@ -82,7 +82,7 @@ struct Copier;        // thread that sends finished row ranges to the host while
 // build, not in its rounds) - they are test hooks and A/B levers, not part of the C-ABI.
 struct Switches {
     bool no_refine = false, safe_rank = false, bucket_fast2 = false, no_fast = false, force_fast = false, no_chains = false;
-    bool force_retry = false, no_pack = false, no_fuse = false, ind_classic = false, no_ring = false, mid_single = false;
+    bool force_retry = false, no_pack = false, no_fuse = false, ind_classic = false, no_ring = false, mid_single = false, no_pcw = false;
     int text_rounds = 0;         // MSUFSORT_HIP_TEXT_ROUNDS (0: unset)
     int digit_bits = 24;         // MSUFSORT_HIP_DIGIT_BITS
     int two_stage = 0; bool two_stage_set = false;      // MSUFSORT_HIP_TWO_STAGE overrides opts->two_stage
@@ -105,7 +105,7 @@ struct Switches {
         { const char* e = getenv("MSUFSORT_HIP_BUCKET_SORT"); bucket_fast2 = e && !strcmp(e, "fast2"); }
         no_fast = on("MSUFSORT_HIP_NO_FAST"); force_fast = on("MSUFSORT_HIP_FORCE_FAST"); no_chains = on("MSUFSORT_HIP_NO_CHAINS");
         force_retry = on("MSUFSORT_HIP_FORCE_RETRY"); no_pack = on("MSUFSORT_HIP_NO_PACK"); no_fuse = on("MSUFSORT_HIP_NO_FUSE");
-        ind_classic = on("MSUFSORT_HIP_IND_CLASSIC"); no_ring = on("MSUFSORT_HIP_NO_RING"); mid_single = on("MSUFSORT_HIP_MID_SINGLE");
+        ind_classic = on("MSUFSORT_HIP_IND_CLASSIC"); no_ring = on("MSUFSORT_HIP_NO_RING"); mid_single = on("MSUFSORT_HIP_MID_SINGLE"); no_pcw = on("MSUFSORT_HIP_NO_PCW");
         text_rounds = std::max(0, num("MSUFSORT_HIP_TEXT_ROUNDS", 0));
         digit_bits = std::min(24, std::max(2, num("MSUFSORT_HIP_DIGIT_BITS", 24)));
         two_stage_set = on("MSUFSORT_HIP_TWO_STAGE"); two_stage = num("MSUFSORT_HIP_TWO_STAGE", 0);
@@ -155,6 +155,9 @@ struct msufsort_hip_ctx {
     // B* suffixes, preceding characters of the rows, per-tile counts and the state of the induction passes
     DevBuf ind_sbits, sel_partial, sel_hist, ind_sstar, ind_pc, ind_tiles, ind_state, ind_tables;
     const u8* sel_bits = nullptr;                 // != nullptr: build_sa sorts only the positions whose bit is set
+    u32* sel_pc = nullptr;                        // two-stage builds: side array next to the sorted B* suffixes - the characters in front of every suffix
+                                                  // whose final row was written by a sort that gathered its key (GatherSpec::pc_out), PC_UNKNOWN elsewhere
+    DevBuf ind_spc;
     u32* h_ind = nullptr;                         // pinned staging for the induction tables
     u32 ind_resident = 0;                         // workgroups of k_ind_fused the device holds at once (occupancy x CUs), asked once
     DevBuf sub_partial, sub_hist, sub_saved;      // deeper histogram of ONE two-byte key (shard boundaries inside heavy keys)
@@ -291,7 +294,7 @@ struct msufsort_hip_ctx {
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
         grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release(); xh_hist.release(); xh_sums.release(); xh.reset();
         sub_partial.release(); sub_hist.release(); sub_saved.release(); sub_key = -1;
-        ind_sbits.release(); sel_partial.release(); sel_hist.release(); ind_sstar.release();
+        ind_sbits.release(); sel_partial.release(); sel_hist.release(); ind_sstar.release(); ind_spc.release();
         ind_pc.release(); ind_tiles.release(); ind_state.release(); ind_tables.release();
         for (auto& a : active) a.release();
         active.clear();
@@ -309,7 +312,7 @@ struct msufsort_hip_ctx {
         for (int s = 0; s < 2; ++s) { for (int k = 0; k < 3; ++k) b += lists[s][k].bytes; b += large_round[s].bytes + lvl[s].bytes; }
         b += isa.bytes + grp_full.bytes + grp_prev.bytes + upd.bytes + sub_partial.bytes + hist_partial.bytes + seg_hist.bytes + child_start.bytes + cursor.bytes;
         b += doneB.bytes + doneC.bytes + aux0.bytes + aux1.bytes + aux2.bytes + aux3.bytes + sa_own.bytes + text_own.bytes;
-        b += ind_sbits.bytes + sel_partial.bytes + ind_sstar.bytes + ind_pc.bytes + ind_tiles.bytes + h17_partial.bytes;
+        b += ind_sbits.bytes + sel_partial.bytes + ind_sstar.bytes + ind_spc.bytes + ind_pc.bytes + ind_tiles.bytes + h17_partial.bytes;
         for (auto& a : active) b += a.act[0].bytes + a.act[1].bytes + a.prev.bytes;
         return b;
     }
@@ -670,7 +673,7 @@ struct Rounds {
     }
     u32 nA = 0, nB = 0, nC = 0, nP = 0;
     u32 deep_cap = 0;                    // != 0: k_sort_tiny finishes its runs by comparing the suffixes themselves (two-stage builds)
-    GatherSpec gather{nullptr, 0, {}};   // text rounds: the sorts (and the first partition level) gather the keys themselves
+    GatherSpec gather{nullptr, 0, {}, nullptr};   // text rounds: the sorts (and the first partition level) gather the keys themselves
     const u8* code = nullptr;            // dense alphabet code (device)
 
     // k_sort_fast needs spread-out keys.  The 16-bit histogram already tells: if its largest bucket is far
@@ -845,6 +848,9 @@ struct Rounds {
             const bool spread = keys_spread();
             const bool ax0 = round == 0 && aux_on;      // round 0 of a small alphabet: the sorts emit next round's records WITH their keys
             const bool use_fast = wants_fast() && !ax0; // (... which only k_sort_mid / k_sort_tiny know how to do)
+            // the companion slot of the LDS sorts has a second use: in the gather rounds of a two-stage build it carries the characters in
+            // front of the suffix to the row a record ends up in (GatherSpec::pc_out) - the same instances
+            const bool axp = ax0 || (!W && gather.text != nullptr && gather.pc_out != nullptr);
             // k_sort_bits (round 3) where the keys are spread like random bytes; k_sort_fast2 for the dense base-sigma keys of later
             // rounds (random DNA at depth 18: an eighth of the records of a segment tie - more than the dirty list of k_sort_bits
             // holds - and k_sort_fast2 sorts such segments in 2.4 ms per GiB where k_sort_mid takes 3.8) and on request
@@ -890,7 +896,7 @@ struct Rounds {
                         ids = c->doneC.template as<u32>();
                     }
                 }
-                if (ax0) k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W, !W><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
+                if (axp) k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W, !W><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
                     bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, emC, counters, ids, (u32)C_FBC, gather, code);
                 else k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
                     bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, emC, counters, ids, (u32)C_FBC, gather, code);
@@ -926,7 +932,7 @@ struct Rounds {
                         ids = c->doneB.template as<u32>();
                     }
                 }
-                if (ax0) k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W, !W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
+                if (axp) k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W, !W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
                     bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, emB, counters, ids, (u32)C_FBB, gather, code);
                 else k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
                     bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, emB, counters, ids, (u32)C_FBB, gather, code);
@@ -935,11 +941,11 @@ struct Rounds {
             // class A (33 .. 512 records): several segments per wave (k_sort_mid_tiles, round 6); MSUFSORT_HIP_MID_SINGLE=1: one segment
             // at a time (the 64-thread instance of k_sort_mid, rounds 2 - 5)
             const u32 gridA = std::min<u32>(cdiv(nA, MIDT_BUN), 8192u);
-            if (nA && !c->sw.mid_single && ax0) k_sort_mid_tiles<W, !W><<<dim3(gridA), dim3(64), 0, st>>>(
+            if (nA && !c->sw.mid_single && axp) k_sort_mid_tiles<W, !W><<<dim3(gridA), dim3(64), 0, st>>>(
                         bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, gather, code);
             else if (nA && !c->sw.mid_single) k_sort_mid_tiles<W><<<dim3(gridA), dim3(64), 0, st>>>(
                         bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, gather, code);
-            else if (nA && ax0) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W, !W><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
+            else if (nA && axp) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W, !W><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
                         bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, (const u32*)nullptr, 0u, gather, code);
             else if (nA) k_sort_mid<CLS_A_THREADS, CLS_A_ITEMS, W><<<dim3(std::min<u32>(nA, 8192u)), dim3(CLS_A_THREADS), sort_mid_lds_bytes<CLS_A_THREADS, CLS_A_ITEMS>(), st>>>(
                         bufs, c->lists[cur][0].template as<Desc>(), nA, sa_local, isa32, mode, em, counters, (const u32*)nullptr, 0u, gather, code);
@@ -1294,7 +1300,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         const bool fuse = R.mode == MODE_TEXT && !keyed && !R.wants_fast() && !c->sw.no_fuse;
         R.round = round;
         R.code = c->alpha.as<u8>();
-        R.gather = GatherSpec{fuse ? d_text : nullptr, n, ks};
+        R.gather = GatherSpec{fuse ? d_text : nullptr, n, ks, (fuse && c->sel_pc) ? c->sel_pc + (1 + rank0 - slice_row_lo) : nullptr};
         // tandem repeats: tie groups that are one arithmetic progression of positions are finished at once (k_chain_resolve)
         if constexpr (!W) {
             if (R.mode == MODE_ISA && depth <= 4096) {

@@ -200,25 +200,19 @@ __device__ __forceinline__ bool ind_failed(const IndState* st) { return (__hip_a
 __device__ __forceinline__ u64 ind_status(u64 flag, u32 epoch, u64 value) { return (flag << 62) | ((u64)(epoch & 0x3fffu) << 48) | value; }
 
 // sorted B* suffixes -> the left ends of their sub-buckets; one workgroup per non-empty (c0,c1)
-__global__ __launch_bounds__(256) void k_place_bstar(const u32* __restrict__ sstar, const u32* __restrict__ keys, IndTables tb, u32* __restrict__ sa)
+// ... and what the first stage already knows about the characters in front of them (spc: GatherSpec::pc_out of the sorts, PC_UNKNOWN where
+// a suffix became final without a gather; nullptr: nothing is known) - the first level of pass B fetches only the unknown ones
+__global__ __launch_bounds__(256) void k_place_bstar(const u32* __restrict__ sstar, const u32* __restrict__ spc, const u32* __restrict__ keys, IndTables tb,
+                                                     u32* __restrict__ sa, u32* __restrict__ pc)
 {
     const u32 key = keys[blockIdx.x];
     const u32 cnt = tb.sub_bs[key], src = tb.bs_off[key], dst = tb.sub_start[key];
-    for (u32 i = blockIdx.y * 256u + threadIdx.x; i < cnt; i += gridDim.y * 256u) sa[dst + i] = sstar[src + i];
+    for (u32 i = blockIdx.y * 256u + threadIdx.x; i < cnt; i += gridDim.y * 256u) { sa[dst + i] = sstar[src + i]; pc[dst + i] = spc ? spc[src + i] : PC_UNKNOWN; }
 }
 
-// the (up to) three characters in front of suffix j and how many there are
-__device__ __forceinline__ u32 ind_fetch(const u8* __restrict__ text, u32 j)
-{
-    if (j >= 4u) {
-        u32 w;
-        __builtin_memcpy(&w, text + j - 4u, 4);
-        return (__builtin_bswap32(w) & 0xffffffu) | (3u << 24);
-    }
-    u32 v = 0;
-    for (u32 k = 0; k < j && k < 3u; ++k) v |= (u32)text[j - 1u - k] << (8u * k);
-    return v | ((j < 3u ? j : 3u) << 24);
-}
+// the (up to) three characters in front of suffix j and how many there are: pc_fetch (sa_kernels.hip.h; the sorts of the first stage
+// read them next to the keys they gather)
+__device__ __forceinline__ u32 ind_fetch(const u8* __restrict__ text, u32 j) { return pc_fetch(text, j); }
 
 #define IND_ITEMS 16
 #define IND_TILE (256u * IND_ITEMS)      // sources per tile: 256 threads x 16, wave-major rows of 64
@@ -302,7 +296,10 @@ __global__ __launch_bounds__(256) void k_ind_count(const IndState* __restrict__ 
         }
 #pragma unroll
         for (int i = 0; i < IND_ITEMS; ++i)
-            if (row[i] != 0xffffffffu) pcv[i] = star[i] ? ind_fetch(text, j[i]) : pc[row[i]];
+            if (row[i] != 0xffffffffu) { pcv[i] = pc[row[i]]; star[i] = star[i] && pcv[i] == PC_UNKNOWN; }
+#pragma unroll
+        for (int i = 0; i < IND_ITEMS; ++i)
+            if (row[i] != 0xffffffffu && star[i]) pcv[i] = ind_fetch(text, j[i]);
 #pragma unroll
         for (int i = 0; i < IND_ITEMS; ++i) {
             const bool in = row[i] != 0xffffffffu;
@@ -398,22 +395,19 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
         j[i] = 0; bin[i] = 256u; npc[i] = 0;
         if (q < cnt) j[i] = sa[lv.pass_b ? hi - 1u - q : lo + q];
     }
+    // the characters in front of the sources: with the rows (pc[]); B* rows (level 0 of pass B) whose first-stage sort did not
+    // leave them (PC_UNKNOWN, k_place_bstar) fetch them from the text here - and only those
+#pragma unroll
+    for (int i = 0; i < IND_ITEMS; ++i) {
+        const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
+        if (q < cnt) npc[i] = pc[lv.pass_b ? hi - 1u - q : lo + q];
+    }
     if (OWN_STARS && lv.stars) {
 #pragma unroll
         for (int i = 0; i < IND_ITEMS; ++i) {
             const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
-            if (q < cnt) {
-                const u32 r = hi - 1u - q;                    // (B* rows are sources of pass B only)
-                u32 a = lv.c, b = 256u;
-                while (b - a > 1u) { const u32 mid = (a + b) >> 1; if (s_sub[mid] <= r) a = mid; else b = mid; }
-                if (r < s_sub[a] + tb.sub_bs[lv.c * 256u + a]) starmask |= 1u << i;
-            }
+            if (q < cnt && npc[i] == PC_UNKNOWN) { starmask |= 1u << i; npc[i] = ind_fetch(text, j[i]); }
         }
-    }
-#pragma unroll
-    for (int i = 0; i < IND_ITEMS; ++i) {
-        const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
-        if (q < cnt) npc[i] = ((starmask >> i) & 1u) ? ind_fetch(text, j[i]) : pc[lv.pass_b ? hi - 1u - q : lo + q];
     }
 #pragma unroll
     for (int i = 0; i < IND_ITEMS; ++i) {

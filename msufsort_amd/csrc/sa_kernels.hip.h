@@ -983,7 +983,27 @@ struct GatherSpec {
     const u8* text;       // nullptr: keys are already in the records
     u64 n;
     KeySpec ks;
+    u32* pc_out;          // two-stage builds (narrow; nullptr: off): a sort that gathers a record's key ALSO reads the three characters in
+                          // front of the suffix (pc_fetch: the same 128-byte line in four cases of five) and, when the record comes out
+                          // FINAL (a tie run of one), leaves them at pc_out[row] next to the row - so that the induction's first level
+                          // does not fetch them with a random text access per B* suffix (reference: the entries of the multi-threaded
+                          // induction cache their preceding symbol, msufsort.cpp:674-790).  Written at most once per row, together with
+                          // the row's final write; rows finalised by a kernel that gathered nothing keep PC_UNKNOWN.
 };
+#define PC_UNKNOWN 0xffffffffu
+
+// the (up to) three characters in front of suffix j and how many there are: T[j-1] | T[j-2] << 8 | T[j-3] << 16 | count << 24
+__device__ __forceinline__ u32 pc_fetch(const u8* __restrict__ text, u32 j)
+{
+    if (j >= 4u) {
+        u32 w;
+        __builtin_memcpy(&w, text + j - 4u, 4);
+        return (__builtin_bswap32(w) & 0xffffffu) | (3u << 24);
+    }
+    u32 v = 0;
+    for (u32 k = 0; k < j && k < 3u; ++k) v |= (u32)text[j - 1u - k] << (8u * k);
+    return v | ((j < 3u ? j : 3u) << 24);
+}
 
 // key of ONE suffix from its window; `code` = dense alphabet code (LDS), used when ks.cpk is not a plain window
 template <bool W>
@@ -1735,6 +1755,10 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
         asm volatile("" :: "v"(fi[0]));
         MPROF(0);
 #endif
+        if constexpr (AUX) {        // (gather rounds of a two-stage build: the companion slot carries the characters in front of the suffix)
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) ax[j] = (valid[j] && g.pc_out) ? pc_fetch(g.text, (u32)fi[j]) : PC_UNKNOWN;
+        }
         gather_keys<W, ITEMS, (ITEMS > 8 ? 6 : 8)>(g, s_code, fi, valid, key);
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -1904,6 +1928,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                 const u32 e = above ? (u32)((w << 6) + __ffsll((long long)above) - 1) : pre_seg[w];
                 rs[j] = s; rl[j] = e - s + 1;
                 sa_out[d.sa_off + p] = full_idx<W>(key[j], idx[j]);
+                if constexpr (AUX) { if (g.text && g.pc_out && rl[j] == 1u) g.pc_out[d.sa_off + p] = ax[j]; }
                 if (mode == MODE_ISA && (s != 0 || (d.buf & DESC_STALE))) isa[idx[j]] = rank0 + d.sa_off + s + 1u;
                 if (mode == MODE_DEFER) em.grp_out[d.sa_off + p] = d.sa_off + s;
             }
@@ -1942,6 +1967,7 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                 if (W) key[j] = ex[384 + p];             // (the index byte travels with the key word)
                 if constexpr (AUX) ax[j] = ex[384 + p];
                 sa_out[d.sa_off + p] = full_idx<W>(key[j], idx[j]);
+                if constexpr (AUX) { if (g.text && g.pc_out && rl[j] == 1u) g.pc_out[d.sa_off + p] = ax[j]; }
                 if (mode == MODE_ISA && (rs[j] != 0 || (d.buf & DESC_STALE))) isa[idx[j]] = rank0 + d.sa_off + rs[j] + 1u;
                 if (mode == MODE_DEFER) em.grp_out[d.sa_off + p] = d.sa_off + rs[j];
                 any_eq |= rl[j] > 1;
@@ -2064,13 +2090,13 @@ __device__ __forceinline__ void sort_mid_segment(const RecBufs& bufs, const Desc
                 if (rl[j] <= TINY_MAX) {
                     const u32 o = base_t + pre_tiny[w] + (u32)__popcll(bm_tiny[w] & lt_mask);
                     u64 r = (u64)full_idx<W>(key[j], idx[j]);
-                    if constexpr (AUX) r |= (u64)ax[j] << 32;        // next round's key comes with the record
+                    if constexpr (AUX) { if (!g.text) r |= (u64)ax[j] << 32; }        // next round's key comes with the record
                     em.pool_rec[o] = r;
                     em.pool_hdr[o] = pack_hdr(d.sa_off + rs[j], rl[j], p - rs[j]);
                 } else {
                     const u32 o = base_s + pre_seg[w] + (u32)__popcll(bm_seg[w] & lt_mask);
                     u64 r = (u64)full_idx<W>(key[j], idx[j]);
-                    if constexpr (AUX) r |= (u64)ax[j] << 32;
+                    if constexpr (AUX) { if (!g.text) r |= (u64)ax[j] << 32; }
                     em.seg_rec[o] = r;
                     if (p == rs[j]) {
                         const Desc nd = {o, rl[j], d.sa_off + rs[j], em.seg_buf};
@@ -2616,6 +2642,10 @@ __global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs,
                 asm volatile("" :: "v"(fi[0]));
                 MPROF(0);
 #endif
+                if constexpr (AUX) {        // (gather rounds of a two-stage build: the companion slot carries the characters in front of the suffix)
+#pragma unroll
+                    for (int j = 0; j < ITEMS; ++j) ax[j] = (valid[j] && g.pc_out) ? pc_fetch(g.text, (u32)fi[j]) : PC_UNKNOWN;
+                }
                 gather_keys<W, ITEMS, 8>(g, s_code, fi, valid, key);
 #pragma unroll
                 for (int j = 0; j < ITEMS; ++j) {
@@ -2759,6 +2789,7 @@ __global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs,
                         const u32 sg = MIDT_SEG(j);
                         const u32 sab = st_sab[sg];                     // the segment's first row minus its first tile position
                         sa_out[sab + p] = full_idx<W>(key[j], idx[j]);
+                        if constexpr (AUX) { if (g.text && g.pc_out && rl[j] == 1u) g.pc_out[sab + p] = ax[j]; }
                         if (mode == MODE_ISA && (s != st_pre[sg] || (st_flag[sg] & DESC_STALE))) isa[idx[j]] = rank0 + sab + s + 1u;
                         if (mode == MODE_DEFER) em.grp_out[sab + p] = sab + s;
                     }
@@ -2853,13 +2884,13 @@ __global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs,
                         if (rl[j] <= TINY_MAX) {
                             const u32 o = base_t + pre_tiny[j] + (u32)__popcll(bm_tiny[j] & lt_mask);
                             u64 r = (u64)full_idx<W>(key[j], idx[j]);
-                            if constexpr (AUX) r |= (u64)ax[j] << 32;        // next round's key comes with the record
+                            if constexpr (AUX) { if (!g.text) r |= (u64)ax[j] << 32; }        // next round's key comes with the record
                             em.pool_rec[o] = r;
                             em.pool_hdr[o] = pack_hdr(sab + rs[j], rl[j], p - rs[j]);
                         } else {
                             const u32 o = base_s + pre_seg[j] + (u32)__popcll(bm_seg[j] & lt_mask);
                             u64 r = (u64)full_idx<W>(key[j], idx[j]);
-                            if constexpr (AUX) r |= (u64)ax[j] << 32;
+                            if constexpr (AUX) { if (!g.text) r |= (u64)ax[j] << 32; }
                             em.seg_rec[o] = r;
                             if (p == rs[j]) {
                                 const Desc nd = {o, rl[j], sab + rs[j], em.seg_buf};
@@ -2978,6 +3009,9 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
             typename Wd<W>::sa_t fi[2] = {rec_idx<W>(rec[0]), rec_idx<W>(rec[1])};
             const bool valid[2] = {have[0] && ((hdr[0] >> 32) & 255ull) != 0, have[1] && ((hdr[1] >> 32) & 255ull) != 0};      // (len 0 = neutral entry)
             u32 key[2];
+            if constexpr (!W) {      // two-stage builds: the characters in front of the suffix, for the records that come out final (GatherSpec::pc_out)
+                if (g.pc_out) { ax[0] = valid[0] ? pc_fetch(g.text, (u32)fi[0]) : PC_UNKNOWN; ax[1] = valid[1] ? pc_fetch(g.text, (u32)fi[1]) : PC_UNKNOWN; }
+            }
             gather_keys<W, 2, 2>(g, s_code, fi, valid, key);
 #pragma unroll
             for (int k = 0; k < 2; ++k) if (have[k]) lkey[t + k * WIN] = key[k] >> KL;
@@ -3017,6 +3051,7 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
                     }
                     const u32 row = sa_start + n_lt[k] + n_eqb[k];
                     sa_out[row] = rec_idx<W>(rec[k]);
+                    if constexpr (!W) { if (g.text && g.pc_out && n_eq[k] == 1u) g.pc_out[row] = ax[k]; }
                     if (mode == MODE_ISA && (n_lt[k] != 0 || ((hdr[k] >> 48) & 1ull))) isa[(u32)rec[k]] = rank0 + sa_start + n_lt[k] + 1u;
                     if (mode == MODE_DEFER) grp_out[row] = sa_start + n_lt[k];
                     if (!discard && n_eq[k] > 1 && n_eqb[k] == 0) lrun[e] = atomicAdd(&s_total, n_eq[k]);

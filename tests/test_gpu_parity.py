@@ -1297,7 +1297,9 @@ def test_key1_from_the_sequential_pass(M, oracle_mod, monkeypatch, kind):
             off, on = got[("-1", two_stage)], got[("0", two_stage)]
             assert on[1] == off[1]                                                              # same rounds either way
             if kind == "sigma85" or off[0] == 0:
-                assert on[0] == off[0]
+                # (the figure counts reserved slots: the unused tails of the sorts' output chunks are part of it, and how the class-A
+                # segments fall into tiles depends on the order their descriptors were pushed in - equal up to that slack)
+                assert abs(on[0] - off[0]) <= 64 + off[0] // 50 and (off[0] != 0 or on[0] == 0), (kind, n, two_stage, on, off)
             elif not (two_stage == 1 and on[2]):                                                # (a declined two-stage attempt reports the sort-all build)
                 assert on[0] < off[0], (kind, n, two_stage, on, off)
         monkeypatch.setenv("MSUFSORT_HIP_KEY1", "0")
