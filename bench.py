@@ -858,7 +858,12 @@ def main():
         dist.broadcast(d_text, src=0)
     torch.cuda.synchronize(dev)          # the engine works on its own HIP stream: the text must have landed
     ctx = M.DeviceContext(local, 0)
-    bounds = ctx.shard_bounds(d_text, n, world)
+    # every rank sorts its key range as k sub-shards: sub-slice j travels (one group of sends / receives) while sub-shard j + 1 is sorted
+    # (dist.build_sa_sharded, sub_bounds; reference: threads leave their partitions while others still sort, msufsort.cpp:1652-1683)
+    k_sub = mdist.sub_shards_for(world, n)
+    bounds, sub_bounds = mdist.plan_sub_bounds(ctx, d_text, n, world, k_sub)
+    if k_sub <= 1:
+        sub_bounds = None
     rows_max = max(bounds[g + 1] - bounds[g] for g in range(world))
     budget, msg = hbm_short(rows_max, n + 64)
     if msg:
@@ -883,7 +888,7 @@ def main():
     ts_stats, bwt_stats, hist_stats = {}, {}, {}
     # the histogram a sharded build starts with is counted 1/N per rank (dist.plan_sharded): its all-reduce and all-gather get a
     # communicator of their own, so that in the pipelined figure they do not queue behind the previous build's slices
-    hist_group = dist.new_group(ranks=list(range(backend_world))) if mdist.sharded_hist_enabled(world, n) else None
+    hist_group = dist.new_group(ranks=list(range(backend_world))) if (mdist.sharded_hist_enabled(world, n) or k_sub > 1) else None
 
     def build_rows(out, gather_rows=True):
         """True: the two-stage sharded build ran (every rank holds ALL rows); False: the sort-all shards ran."""
@@ -892,7 +897,7 @@ def main():
         if d_bstar is not None and ts_stats.get("two_stage_status") != 1 and mdist.build_sa_two_stage_sharded(ctx, d_text, n, out, d_bstar, rank, world, dist, two_stage=args.two_stage, stats=ts_stats):
             return True
         mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp=d_grp, overlap=False, index_bytes=index_bytes, state=shard_state,
-                               gather_rows=gather_rows, stats=hist_stats, hist_group=hist_group)
+                               gather_rows=gather_rows, stats=hist_stats, hist_group=hist_group, sub_bounds=sub_bounds)
         return False
 
     def step():
@@ -916,7 +921,7 @@ def main():
         out = sa_bufs[pending["k"] & 1]
         pending["k"] += 1
         works = mdist.build_sa_sharded(ctx, d_text, n, out, rank, world, dist, bounds, d_grp=d_grp, overlap=True, index_bytes=index_bytes, state=shard_state,
-                                       stats=hist_stats, hist_group=hist_group)
+                                       stats=hist_stats, hist_group=hist_group, sub_bounds=sub_bounds)
         mdist.wait_all(pending["works"], pending["buf"])        # the previous exchange overlapped with this build
         pending["works"], pending["buf"], pending["last"] = works, out, out
 
@@ -977,7 +982,7 @@ def main():
             barrier()
             a = time.perf_counter()
             w = mdist.build_sa_sharded(ctx, d_text, n, sa_bufs[0], rank, world, dist, bounds, d_grp=d_grp, overlap=True, index_bytes=index_bytes, state=shard_state,
-                                       stats=hist_stats, hist_group=hist_group)
+                                       stats=hist_stats, hist_group=hist_group, sub_bounds=sub_bounds)
             torch.cuda.synchronize(dev)
             b = time.perf_counter()
             mdist.wait_all(w, sa_bufs[0])
@@ -1078,6 +1083,10 @@ def main():
             "config": {"workload": f"{args.workload} bytes (splitmix64 seed {args.seed}), n={n}, {index_name} SA, 4-byte-prefix range sharding x{world}",
                        "n": n, "index": index_name, "ops": ops, "allgatherv": exchange, "rccl_ranks": rccl_ranks_of(backend, backend_world), "ranks": backend_world,
                        "pipelined": False, "backend": backend,
+                       "overlap": {"sub_shards_per_rank": k_sub,
+                                   "what": ("every rank sorts its key range as %d sub-shards; sub-slice j is posted (grouped sends / receives) as soon as it is sorted and "
+                                            "travels while sub-shard j + 1 is sorted; `value` stays the latency of complete builds" % k_sub) if k_sub > 1 else
+                                           "none: the slice is posted when the whole key range is sorted (small input, one rank, or rows kept distributed)"},
                        "step": ("B* suffixes of my key range sorted + all-gatherv of the sorted-B* slices (4|B*| bytes) + induction of all rows on every rank" if used_two_stage else
                                 "sort of my key range + all-gatherv of the slices, complete on every rank (latency of one build)") +
                                ("; then the forward BWT as one call: its own sharded sort, rows kept distributed, n/G-byte slices all-gathered" if want_bwt else "")},

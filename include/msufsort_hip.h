@@ -59,7 +59,13 @@ typedef struct msufsort_hip_opts {
                                   cpp:646-1057) when the input looks like text or DNA (4..128 byte values in use; at least 80 MiB,
                                   320 MiB below 16 values; no very long runs of one byte), 1 = whenever possible, -1 = never; inputs that do not suit (or
                                   whose B* suffixes tie too deep) are sorted completely, as before */
-    int32_t reserved[9];
+    int32_t reuse_plan;        /* msufsort_hip_make_sa_shard*_dev: 1 = this call builds ANOTHER shard of the text the previous shard call on this
+                                  context planned (same buffer, same n, same n_shards, contents unchanged - the caller's promise): the 16-bit
+                                  histogram and the plan of the cuts are taken from that call instead of a new pass over the text.  A rank
+                                  that sorts its key range as several sub-shards so that finished sub-slices travel while the next one is
+                                  sorted (msufsort_amd/dist.py, sub_shards) sets it from its second sub-shard on; ignored (a full plan runs)
+                                  when the context holds no matching plan */
+    int32_t reserved[8];
 } msufsort_hip_opts;
 
 /* Per-phase device time of the last build on this context (hipEvent, milliseconds), plus

@@ -18,7 +18,8 @@ TEXT_PAD = 64
 
 class Opts(C.Structure):
     _fields_ = [("device", C.c_int32), ("shard", C.c_int32), ("n_shards", C.c_int32),
-                ("text_rounds", C.c_int32), ("verbose", C.c_int32), ("force_wide", C.c_int32), ("two_stage", C.c_int32), ("reserved", C.c_int32 * 9)]
+                ("text_rounds", C.c_int32), ("verbose", C.c_int32), ("force_wide", C.c_int32), ("two_stage", C.c_int32), ("reuse_plan", C.c_int32),
+                ("reserved", C.c_int32 * 8)]
 
 
 class Timings(C.Structure):

@@ -35,10 +35,11 @@ def _u8(data) -> np.ndarray:
     return a
 
 
-def _opts(device=0, verbose=0, text_rounds=0, shard=0, n_shards=1, force_wide=0, two_stage=0) -> Opts:
+def _opts(device=0, verbose=0, text_rounds=0, shard=0, n_shards=1, force_wide=0, two_stage=0, reuse_plan=0) -> Opts:
     o = Opts()
     o.device, o.verbose, o.text_rounds, o.shard, o.n_shards, o.force_wide = device, verbose, text_rounds, shard, n_shards, int(force_wide)
     o.two_stage = int(two_stage)
+    o.reuse_plan = int(reuse_plan)
     return o
 
 
@@ -245,18 +246,20 @@ class DeviceContext:
         assert d_stripe_sums.dim() == 2 and d_stripe_sums.shape[1] == 256 and d_stripe_sums.element_size() == 4 and d_stripe_sums.is_contiguous()
         _lib.check(self._L.msufsort_hip_hist_install_dev(self._h, shard, self._ptr(d_stripe_sums), int(d_stripe_sums.shape[0])), "hist_install")
 
-    def make_sa_shard(self, d_text, n: int, d_slice, capacity: int, shard: int, n_shards: int, *, verbose=0, text_rounds=0):
-        o = _opts(self.device, verbose, text_rounds, shard, n_shards)
+    def make_sa_shard(self, d_text, n: int, d_slice, capacity: int, shard: int, n_shards: int, *, verbose=0, text_rounds=0, reuse_plan=False):
+        """reuse_plan: this is ANOTHER shard of the text the previous shard call on this context planned (same n_shards, contents
+        unchanged): histogram and cuts are taken from that call (msufsort_hip_opts.reuse_plan)."""
+        o = _opts(self.device, verbose, text_rounds, shard, n_shards, reuse_plan=reuse_plan)
         lo, hi = C.c_int64(0), C.c_int64(0)
         _lib.check(self._L.msufsort_hip_make_sa_shard_dev(self._h, self._ptr(d_text), n, self._ptr(d_slice), capacity,
                                                           C.byref(lo), C.byref(hi), C.byref(o)), "make_sa_shard")
         return int(lo.value), int(hi.value)
 
     def make_sa_shard_groups(self, d_text, n: int, d_slice, d_grp_slice, capacity: int, shard: int, n_shards: int, *, verbose=0, text_rounds=0,
-                             index_bytes=4):
+                             index_bytes=4, reuse_plan=False):
         """Like make_sa_shard, plus the tie-group heads of the slice rows (uint32, relative to the slice).  index_bytes = 8:
         the wide engine (int64 rows).  Returns (lo, hi, unresolved, depth)."""
-        o = _opts(self.device, verbose, text_rounds, shard, n_shards)
+        o = _opts(self.device, verbose, text_rounds, shard, n_shards, reuse_plan=reuse_plan)
         lo, hi, depth = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         f = self._L.msufsort_hip_make_sa_shard_groups_i64_dev if index_bytes == 8 else self._L.msufsort_hip_make_sa_shard_groups_dev
         r = f(self._h, self._ptr(d_text), n, self._ptr(d_slice), self._ptr(d_grp_slice), capacity, C.byref(lo), C.byref(hi), C.byref(depth), C.byref(o))

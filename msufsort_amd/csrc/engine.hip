@@ -178,6 +178,15 @@ struct msufsort_hip_ctx {
         void reset() { stage = 0; text = nullptr; shard = -1; }
     } xh;
     DevBuf xh_hist, xh_sums;         // 65,536 x u64 totals; [stripes][256] x u32
+    // the plan of the last per-shard call (msufsort_hip_make_sa_shard*_dev): with opts->reuse_plan the next shard of the SAME text takes
+    // histogram and cuts from it (the histogram's buffers stay as that call left them: only shard calls run in between)
+    struct PlanCache {
+        bool valid = false; bool wide = false;
+        const u8* text = nullptr; u64 n = 0, z = 0; int n_shards = 0;
+        bool small_alphabet = false;
+        std::vector<u64> cuts, rows, rank0;
+        void reset() { valid = false; text = nullptr; }
+    } plan_cache;
     bool ext_stripe_sums = false;    // the next run_scan takes xh_sums instead of reducing hist_partial
     u32* h_counters = nullptr;   // pinned
     u64* h_hist = nullptr;       // pinned, 65536 (the 16-bit histogram on the host: shard planning)
@@ -292,7 +301,7 @@ struct msufsort_hip_ctx {
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
         h17_partial.release(); h17_fb.release(); h17.release(); child_start17.release(); child_cnt17.release(); cursor17.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
-        grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release(); xh_hist.release(); xh_sums.release(); xh.reset();
+        grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release(); xh_hist.release(); xh_sums.release(); xh.reset(); plan_cache.reset();
         sub_partial.release(); sub_hist.release(); sub_saved.release(); sub_key = -1;
         ind_sbits.release(); sel_partial.release(); sel_hist.release(); ind_sstar.release(); ind_spc.release();
         ind_pc.release(); ind_tiles.release(); ind_state.release(); ind_tables.release();
@@ -442,6 +451,7 @@ template <bool W>
 int run_hist(msufsort_hip_ctx* c, const u8* d_text, u64 m)
 {
     u32 hchunks = 0;
+    c->plan_cache.reset();          // (the histogram buffers a cached shard plan relies on are rewritten here)
     TRY(plan_stripes(c, m, &hchunks));
     const u32 per = c->hist_per;
     const u64 chunk_len = c->chunk_len;
@@ -531,6 +541,7 @@ int run_hist17(msufsort_hip_ctx* c, const u8* d_text, u64 m, bool first)
     // chunks = the stripes of the level-0 scatter cut into q pieces of at most H17_CHUNK bytes (multiples of 16 KiB: a workgroup reads
     // 16 KiB per iteration); q even, so that 128 stripes give a multiple of 256 chunks: whole rounds of one workgroup per CU
     const u32 stripe_len = c->chunk_len;
+    c->plan_cache.reset();
     u32 q = std::max<u32>(1, cdiv(stripe_len, H17_CHUNK));
     if (q > 1 && (q & 1u)) ++q;
     const u32 sub_len = (cdiv(stripe_len, q) + 16383u) & ~16383u;
@@ -1902,6 +1913,7 @@ int msufsort_hip_hist_part_dev(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, 
     TRY(check_n64(n));
     HIP_TRY(hipSetDevice(c->device));
     c->xh.reset();
+    c->plan_cache.reset();
     TRY(zero_pad(c, d_text, (u64)n));
     u64 z = 0;
     TRY(trailing_zeros(c, d_text, (u64)n, &z));
@@ -2029,6 +2041,9 @@ int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, typename
     ShardCuts sc;
     bool ext_sums = false;
     HIP_TRY(hipEventRecord(c->ev[8], c->stream));
+    auto& pcache = c->plan_cache;
+    const bool cached = !planned && opts->reuse_plan && pcache.valid && pcache.wide == W && pcache.text == d_text && pcache.n == (u64)n && pcache.z == z &&
+                        pcache.n_shards == opts->n_shards && m > 0;
     if (planned && m > 0) {
         // the histogram was computed sharded and all-reduced, the plan is made, my shard's stripe sums are here: no pass over the text
         sc.cuts = c->xh.cuts; sc.rows = c->xh.rows; sc.rank0 = c->xh.rank0;
@@ -2036,10 +2051,21 @@ int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, typename
         c->plan_small_alphabet = c->xh.small_alphabet;
         ext_sums = true;
         c->sub_key = -1;
+        // the plan stays (stage 2): the stripe sums of ANOTHER shard of this text may be installed next (a rank that sorts its key range
+        // as several sub-shards, dist.py); any other call drops it
+        c->xh.stage = 2; c->xh.shard = -1;
+        pcache.reset();
+    } else if (cached) {
+        // another shard of the text the previous shard call planned: its histogram (c->hist, c->hist_partial) and cuts serve this one
         c->xh.reset();
+        sc.cuts = pcache.cuts; sc.rows = pcache.rows; sc.rank0 = pcache.rank0;
+        c->plan_small_alphabet = pcache.small_alphabet;
     } else {
         c->xh.reset();
+        pcache.reset();
         TRY(plan_shards<W>(c, d_text, (u64)n, z, opts->n_shards, sc));
+        pcache.valid = true; pcache.wide = W; pcache.text = d_text; pcache.n = (u64)n; pcache.z = z; pcache.n_shards = opts->n_shards;
+        pcache.small_alphabet = c->plan_small_alphabet; pcache.cuts = sc.cuts; pcache.rows = sc.rows; pcache.rank0 = sc.rank0;
     }
     HIP_TRY(hipEventRecord(c->ev[9], c->stream));
     const int g = opts->shard;

@@ -58,6 +58,43 @@ def select_exchange(dist, device):
     return _MODE["mode"]
 
 
+def allgatherv_ranges(full, ranges, dist, group=None, wait=True):
+    """The grouped exchange behind allgatherv_slices for arbitrary row ranges: rank g has filled full[ranges[g][0]:ranges[g][1]]
+    (ranges need not be adjacent: the j-th sub-slices of all ranks, posted while the next sub-shards are still being sorted)."""
+    world = len(ranges)
+    rank = dist.get_rank(group)
+    if _MODE["mode"] == "bcast":
+        works = [dist.broadcast(full[ranges[g][0]:ranges[g][1]], src=g, group=group, async_op=True) for g in range(world) if ranges[g][1] > ranges[g][0]]
+    else:
+        ops = []
+        lo, hi = ranges[rank]
+        for step in range(1, world):
+            dst = (rank + step) % world
+            src = (rank - step) % world
+            if hi > lo:
+                ops.append(dist.P2POp(dist.isend, full[lo:hi], dst, group))
+            if ranges[src][1] > ranges[src][0]:
+                ops.append(dist.P2POp(dist.irecv, full[ranges[src][0]:ranges[src][1]], src, group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+    if not wait:
+        return works
+    wait_all(works, full)
+    return full
+
+
+def sub_shards_for(world: int, n: int, gather_rows: bool = True) -> int:
+    """Sub-shards a rank cuts its key range into so that finished sub-slices travel while the next sub-shard is sorted (round 6; the
+    reference's threads pop partitions and leave their rows while others still sort, msufsort.cpp:1652-1683).  Every sub-shard reads
+    the whole text once more in its level-0 scatter (~0.3 ms per GiB) and costs ~0.1 ms of host round trips, the histogram and the
+    plan are shared (msufsort_hip_opts.reuse_plan): four where rows are exchanged and the input is at least 64 MiB, else one.
+    MSUFSORT_DIST_SUBSHARDS=k forces k (tests: small inputs)."""
+    import os
+    e = int(os.environ.get("MSUFSORT_DIST_SUBSHARDS", "0") or 0)
+    if e > 0:
+        return e
+    return 4 if (world > 1 and gather_rows and n >= (64 << 20)) else 1
+
+
 def allgatherv_slices(full, bounds, dist, group=None, wait=True):
     """All-gatherv of SA slices IN PLACE: rank g has filled full[bounds[g]:bounds[g+1]]; afterwards every rank
     holds the whole array.  RCCL has no v-variant: every rank posts, as ONE group (ncclGroupStart/End through
@@ -319,14 +356,17 @@ def sharded_hist_enabled(world: int, n: int = None) -> bool:
     return e == "1" or n is None or n * (world - 1) >= world * (3 << 28)
 
 
-def plan_sharded(ctx, d_text, n: int, rank: int, world: int, dist, stats=None, group=None, device=None):
+def plan_sharded(ctx, d_text, n: int, rank: int, world: int, dist, stats=None, group=None, device=None, sub: int = 1):
     """The 16-bit histogram of a sharded build computed SHARDED (SURVEY.md section 8(e) "Partitioning"): every rank counts 1/world
     of the text's scatter stripes, ONE all-reduce (512 KiB) gives everybody the totals, every rank plans the same key ranges
     from them, and ONE all-gather (128 KiB per rank) hands every shard the per-stripe first-byte counts of its key range that
     its scatter needs from the stripes the others counted.  The shard build that follows on this context then starts without
     a pass over the whole text (reference: per-thread counts summed, msufsort.cpp:1496-1521, :1603-1630).
     Returns the slice bounds, or None when the plan needs a boundary inside a heavy two-byte key (DNA, text): every rank gets the
-    same answer (same totals), nothing is kept and the shard builds compute their own histogram as before."""
+    same answer (same totals), nothing is kept and the shard builds compute their own histogram as before.
+    sub > 1: the plan is made for world * sub shards (rank g sorts the shards g * sub .. g * sub + sub - 1 one after the other, its
+    finished sub-slices travelling meanwhile); returns (bounds of the world * sub shards, the stripe sums of my sub-shards - the first
+    is installed, the caller installs the next one before it builds that sub-shard)."""
     import torch
     if n < 1:
         return None
@@ -357,11 +397,12 @@ def plan_sharded(ctx, d_text, n: int, rank: int, world: int, dist, stats=None, g
     if err is not None or int(h[65536].item()):
         raise err if err is not None else _lib.MsufsortHipError("sharded histogram: a peer failed counting its stripes")
     per = max(1, -(-total // world))
+    nsh = world * max(1, sub)
     bounds, sums = None, None
     status = 0                               # 0 planned, 1 the plan needs a replicated histogram (every rank alike), 2 failed here
     try:
-        sums = torch.empty((world, per, 256), dtype=torch.int32, device=dev)
-        bounds = ctx.hist_plan(d_text, n, world, h[:65536], sums)
+        sums = torch.empty((nsh, per, 256), dtype=torch.int32, device=dev)
+        bounds = ctx.hist_plan(d_text, n, nsh, h[:65536], sums)
         if bounds is None:
             status = 1
     except Exception as e:  # noqa: BLE001
@@ -385,23 +426,23 @@ def plan_sharded(ctx, d_text, n: int, rank: int, world: int, dist, stats=None, g
             sync()
             dist.all_gather([torch.empty_like(sums)], sums, group=group)        # (the one-rank RCCL hook: the collective is issued all the same)
         got = [sums]
-    # part p counted the stripes [total p / world, total (p + 1) / world): its block for MY shard, in text order
-    mine = torch.cat([got[p][rank, :(total * (p + 1) // world - total * p // world)] for p in range(world)]) if total else sums[rank, :0]
-    mine = mine.contiguous()
+    # part p counted the stripes [total p / world, total (p + 1) / world): its block for each of MY shards, in text order
+    mine = [torch.cat([got[p][rank * max(1, sub) + j, :(total * (p + 1) // world - total * p // world)] for p in range(world)]).contiguous()
+            for j in range(max(1, sub))]
     sync()                                   # (the gathered blocks assembled on torch's stream before the engine's stream reads them)
     try:
-        ctx.hist_install(rank, mine)
+        ctx.hist_install(rank * max(1, sub), mine[0])
     except _lib.MsufsortHipError:
-        # local and recoverable: nothing collective depends on it - this rank's shard build counts for itself (same plan: same totals)
-        return bounds
+        # local and recoverable: nothing collective depends on it - this rank's shard builds count for themselves (same plan: same totals)
+        return bounds if sub <= 1 else (bounds, None)
     if stats is not None:
         stats["sharded_hist"] = stats.get("sharded_hist", 0) + 1
-    return bounds
+    return bounds if sub <= 1 else (bounds, mine)
 
 
 def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist, bounds=None, text_rounds: int = 0,
                      d_grp=None, overlap=False, index_bytes: int = 4, state=None, verbose: int = 0, gather_rows: bool = True, stats=None,
-                     hist_group=None):
+                     hist_group=None, sub_bounds=None):
     """One step of the sharded build on this rank: sort my key range into my slice, all-gatherv the slices.
 
     Deep ties (long repeats) cannot be finished by key gathers.  With `d_grp` (int32 view of uint32, at least as many entries
@@ -416,50 +457,106 @@ def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist
     gather_rows=False: the rows stay distributed (every rank's slice d_sa_full[bounds[rank]:bounds[rank+1]] is final on return;
     the other slices hold provisional rows or nothing) - for consumers that exchange something smaller, like forward_bwt_sharded.
 
+    sub_bounds (round 6; plan_sub_bounds): the row bounds of world * k shards - rank g sorts the k SUB-SHARDS g k .. g k + k - 1 of its
+    key range one after the other and posts sub-slice j (one group of direct sends / receives, like the whole slice before) as soon
+    as it is sorted: the links carry it while sub-shard j + 1 is sorted on the engine's stream (the reference's workers leave
+    their partitions while others still sort, msufsort.cpp:1652-1683).  `bounds` must then be sub_bounds[::k].  The return value and
+    the latency semantics are unchanged: without overlap=True the call returns when every rank holds every row.
+
     overlap=True: returns the pending exchange handles instead of waiting, so the caller can start the next build
     (into ANOTHER output buffer) while the slices travel; finish with `wait_all(works, d_sa_full)`.  If the build
     turns out to need the doubling phase everything is completed here and [] is returned.
 
     The build starts with plan_sharded where that pays (sharded_hist_enabled): the histogram counted 1/world per rank.  hist_group: a
-    process group of its own for those two small collectives - with overlap=True they would otherwise queue behind the previous
-    build's slices on the communicator's stream; stats["sharded_hist"] counts the builds that started this way."""
+    process group of its own for those two small collectives (and for the 16-byte agreement on the shards' status) - they would
+    otherwise queue behind slices on the communicator's stream; stats["sharded_hist"] counts the builds that started this way."""
     import torch
+    k = 1
+    if sub_bounds is not None:
+        if (len(sub_bounds) - 1) % world:
+            raise ValueError("sub_bounds must hold the bounds of world * k shards")
+        k = (len(sub_bounds) - 1) // world
+        if bounds is not None and list(bounds) != list(sub_bounds[::k]):
+            raise ValueError("bounds must be sub_bounds[::k]")
+        bounds = list(sub_bounds[::k])
+    installs = None
     if sharded_hist_enabled(world, n) and hasattr(ctx, "hist_part"):
-        # the histogram this build starts with, counted 1/world per rank (two small collectives; the shard build below consumes it)
-        planned = plan_sharded(ctx, d_text, n, rank, world, dist, stats=stats, group=hist_group, device=d_sa_full.device)
+        # the histogram this build starts with, counted 1/world per rank (two small collectives; the shard builds below consume it)
+        planned = plan_sharded(ctx, d_text, n, rank, world, dist, stats=stats, group=hist_group, device=d_sa_full.device, sub=k)
         if planned is not None:
-            if bounds is not None and list(bounds) != planned:
-                raise _lib.MsufsortHipError("the bounds passed in are not the plan of this text")
-            bounds = planned
+            if k > 1:
+                planned, installs = planned
+                if list(sub_bounds) != list(planned):
+                    raise _lib.MsufsortHipError("the sub-shard bounds passed in are not the plan of this text")
+            else:
+                if bounds is not None and list(bounds) != planned:
+                    raise _lib.MsufsortHipError("the bounds passed in are not the plan of this text")
+                bounds = planned
     if bounds is None:
         bounds = ctx.shard_bounds(d_text, n, world)
+    if sub_bounds is None:
+        sub_bounds = bounds
     if text_rounds <= 0:
         text_rounds = 3 if index_bytes == 8 else 8
+    nsh = world * k
     lo, hi = bounds[rank], bounds[rank + 1]
     dev = d_sa_full.device
-    sl = d_sa_full[lo:hi] if hi > lo else torch.empty(1, dtype=d_sa_full.dtype, device=dev)
-    if d_grp is None:
-        if index_bytes != 4:
-            raise ValueError("int64 rows run the wide engine, which always publishes its tie groups: pass d_grp")
-        ctx.make_sa_shard(d_text, n, sl, max(hi - lo, 1), rank, world, text_rounds=text_rounds)
-        if _many(world) and gather_rows:
-            works = allgatherv_slices(d_sa_full, bounds, dist, wait=not overlap)
-            return works if overlap else []
-        return []
-    if d_grp.numel() < max(hi - lo, 1):
+    if d_grp is None and index_bytes != 4:
+        raise ValueError("int64 rows run the wide engine, which always publishes its tie groups: pass d_grp")
+    if d_grp is not None and d_grp.numel() < max(hi - lo, 1):
         raise ValueError(f"d_grp holds {d_grp.numel()} group heads, my slice has {hi - lo} rows")
-    gl = d_grp[:hi - lo] if hi > lo else torch.empty(1, dtype=torch.int32, device=dev)
-    _, _, unresolved, depth = ctx.make_sa_shard_groups(d_text, n, sl, gl, max(hi - lo, 1), rank, world, text_rounds=text_rounds,
-                                                       index_bytes=index_bytes, verbose=verbose)
+    exchanging = _many(world) and gather_rows
+    works = []
+    unresolved_any, depth = False, 0
+
+    def post(j):
+        return allgatherv_ranges(d_sa_full, [(sub_bounds[g * k + j], sub_bounds[g * k + j + 1]) for g in range(world)], dist, wait=False)
+
+    for j in range(k):
+        sh = rank * k + j
+        slo, shi = sub_bounds[sh], sub_bounds[sh + 1]
+        reuse = j > 0
+        if installs is not None and j > 0:          # (the first sub-shard's stripe sums were installed by plan_sharded)
+            try:
+                ctx.hist_install(sh, installs[j])
+                reuse = False
+            except _lib.MsufsortHipError:
+                installs = None                      # local and recoverable: the remaining sub-shards count for themselves
+                reuse = False
+        elif installs is not None:
+            reuse = False
+        sl = d_sa_full[slo:shi] if shi > slo else torch.empty(1, dtype=d_sa_full.dtype, device=dev)
+        if d_grp is None:
+            ctx.make_sa_shard(d_text, n, sl, max(shi - slo, 1), sh, nsh, text_rounds=text_rounds, reuse_plan=reuse)
+        else:
+            gl = d_grp[slo - lo:shi - lo] if shi > slo else torch.empty(1, dtype=torch.int32, device=dev)
+            _, _, unresolved, dep = ctx.make_sa_shard_groups(d_text, n, sl, gl, max(shi - slo, 1), sh, nsh, text_rounds=text_rounds,
+                                                             index_bytes=index_bytes, verbose=verbose, reuse_plan=reuse)
+            if shi > slo and slo > lo:
+                gl += (slo - lo)                     # tie-group heads relative to MY slice (a tie group never spans two sub-shards)
+            if unresolved:
+                if unresolved_any and dep != depth:
+                    raise _lib.MsufsortHipError(f"sub-shards stopped their key rounds at different depths ({depth}, {dep})")
+                unresolved_any, depth = True, dep
+        if j + 1 < k and exchanging:
+            works += post(j)                         # travels while the next sub-shard is sorted
+    if d_grp is None:
+        if exchanging:
+            works += post(k - 1)
+            if overlap:
+                return works
+            wait_all(works, d_sa_full)
+        return []
     # every unresolved rank stopped at the same depth (same number of rounds, same symbols per key): check it instead of
     # trusting it - doubling from a depth some group does not share would mis-sort silently
     big = 1 << 62
-    flag = torch.tensor([depth if unresolved else 0, -(depth if unresolved else big)], dtype=torch.int64, device=dev)
-    works = []
+    flag = torch.tensor([depth if unresolved_any else 0, -(depth if unresolved_any else big)], dtype=torch.int64, device=dev)
     if _many(world):
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)       # (16 bytes; completed before the slices are posted: see the note in DESIGN 3.3)
+        # (16 bytes; on the communicator of the small collectives where there is one - behind the sub-slices already posted it would
+        # wait for them; and before the last sub-slice is posted: see the note in DESIGN 3.3)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=hist_group)
         if gather_rows:
-            works = allgatherv_slices(d_sa_full, bounds, dist, wait=False)
+            works += post(k - 1)
     dmax, dmin = int(flag[0].item()), -int(flag[1].item())
     if dmax > 0:
         if dmin != dmax:
@@ -477,6 +574,14 @@ def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist
         return works
     wait_all(works, d_sa_full)
     return []
+
+
+def plan_sub_bounds(ctx, d_text, n: int, world: int, k: int):
+    """(bounds of the `world` rank slices, bounds of the world * k sub-shards) from ONE plan: the rank slices are unions of their
+    sub-shards (the cuts of a world-shard plan need not be cuts of the finer plan: where a heavy two-byte key is refined, the
+    tolerance follows the shard count)."""
+    sub = ctx.shard_bounds(d_text, n, world * max(1, k))
+    return list(sub[::max(1, k)]), list(sub)
 
 
 def bwt_slice_bounds(bounds, sentinel_row: int):

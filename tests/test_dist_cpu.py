@@ -131,7 +131,9 @@ class _ModelEngine:
     def shard_bounds(self, d_text, n, world):
         return list(self.rows)
 
-    def make_sa_shard_groups(self, d_text, n, sl, gl, capacity, shard, n_shards, *, verbose=0, text_rounds=0, index_bytes=4):
+    def make_sa_shard_groups(self, d_text, n, sl, gl, capacity, shard, n_shards, *, verbose=0, text_rounds=0, index_bytes=4, reuse_plan=False):
+        assert n_shards == len(self.rows) - 1
+        self.calls = getattr(self, "calls", []) + [(shard, bool(reuse_plan))]
         lo, hi = self.rows[shard], self.rows[shard + 1]
         assert sl.dtype == (__import__("torch").int64 if index_bytes == 8 else __import__("torch").int32) and capacity >= hi - lo
         final = self.want[lo:hi].astype(np.int64)
@@ -229,7 +231,7 @@ class _ModelEngine:
         return int(lo + z[0]) if len(z) else -1
 
 
-def _worker_doubling(rank, world, port, tmp, index_bytes):
+def _worker_doubling(rank, world, port, tmp, index_bytes, k=1):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       MSUFSORT_DIST_WINDOW="700",          # several update / group-head windows per step on a small input
@@ -246,21 +248,28 @@ def _worker_doubling(rank, world, port, tmp, index_bytes):
         n = t.size
         want = oracle.make_suffix_array(t)
         wb, ws = oracle.forward_bwt(t)
-        cuts, rows = D.plan_cuts(_bstart(t), n, 0, world)
-        eng = _ModelEngine(t, want, cuts, rows, depth=6)
+        # k sub-shards per rank (dist.sub_shards_for): the model's plan is the plan of world * k shards, a rank's slice their union
+        cuts, sub_rows = D.plan_cuts(_bstart(t), n, 0, world * k)
+        eng = _ModelEngine(t, want, cuts, sub_rows, depth=6)
+        rows = sub_rows[::k]
+        sub_arg = sub_rows if k > 1 else None
         dt = torch.int64 if index_bytes == 8 else torch.int32
         full = torch.full((n + 1,), -7, dtype=dt)
         rows_max = max(rows[g + 1] - rows[g] for g in range(world))
         d_grp = torch.zeros(rows_max, dtype=torch.int32)          # slice sized: NOT n + 1
         state = D.ShardState()
         hst = {}
-        D.build_sa_sharded(eng, None, n, full, rank, world, dist, rows, d_grp=d_grp, index_bytes=index_bytes, state=state, stats=hst)
-        ok = hst.get("sharded_hist") == 1 and eng.installed == 1      # the histogram was counted 1/world per rank and my shard's stripe sums arrived
+        D.build_sa_sharded(eng, None, n, full, rank, world, dist, rows, d_grp=d_grp, index_bytes=index_bytes, state=state, stats=hst, sub_bounds=sub_arg)
+        ok = hst.get("sharded_hist") == 1 and eng.installed == k      # the histogram was counted 1/world per rank and the stripe sums of each of my sub-shards arrived
+        ok = ok and eng.calls == [(rank * k + j, False) for j in range(k)]      # (installed stripe sums: no sub-shard reuses a plan)
         ok = ok and bool((full.numpy() == want).all()) and state.stats["doubling_steps"] >= 2 and state.stats["updates"] > 0
         ok = ok and state.stats["windows"] > state.stats["doubling_steps"] and state.stats["index_bytes"] == index_bytes
         # rows kept distributed + the sharded forward transform: n bytes exchanged instead of the rows
         full2 = torch.full((n + 1,), -7, dtype=dt)
-        D.build_sa_sharded(eng, None, n, full2, rank, world, dist, rows, d_grp=d_grp, index_bytes=index_bytes, state=state, gather_rows=False)
+        eng.calls = []
+        os.environ["MSUFSORT_DIST_SHARDED_HIST"] = "0"          # replicated histogram: the first sub-shard plans, the others reuse its plan
+        D.build_sa_sharded(eng, None, n, full2, rank, world, dist, rows, d_grp=d_grp, index_bytes=index_bytes, state=state, gather_rows=False, sub_bounds=sub_arg)
+        ok = ok and eng.calls == [(rank * k + j, j > 0) for j in range(k)]
         lo, hi = rows[rank], rows[rank + 1]
         ok = ok and bool((full2.numpy()[lo:hi] == want[lo:hi]).all())
         bwt = torch.zeros(n, dtype=torch.uint8)
@@ -272,13 +281,14 @@ def _worker_doubling(rank, world, port, tmp, index_bytes):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,index_bytes", [(2, 4), (2, 8), (3, 8), (4, 4)])
-def test_distributed_doubling_driver_gloo(world, index_bytes, tmp_path, oracle_mod):
+@pytest.mark.parametrize("world,index_bytes,k", [(2, 4, 1), (2, 8, 2), (3, 8, 1), (4, 4, 3)])
+def test_distributed_doubling_driver_gloo(world, index_bytes, k, tmp_path, oracle_mod):
     """dist.build_sa_sharded -> _distributed_doubling -> forward_bwt_sharded with int32 and int64 rows (BASELINE config 5 is the
-    int64 flavour over 8 ranks): result == the oracle's suffix array and BWT on every rank."""
+    int64 flavour over 8 ranks): result == the oracle's suffix array and BWT on every rank.  k > 1: every rank sorts its key range as
+    k sub-shards and posts each sub-slice while the next one is sorted (round 6) - same rows, group heads moved to the rank's slice."""
     import torch.multiprocessing as mp
     port = 29900 + os.getpid() % 1000 + 8 * world + index_bytes
-    mp.spawn(_worker_doubling, args=(world, port, str(tmp_path), index_bytes), nprocs=world, join=True)
+    mp.spawn(_worker_doubling, args=(world, port, str(tmp_path), index_bytes, k), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"d{r}").read() == "ok"
 
