@@ -861,6 +861,8 @@ struct Rounds {
             const bool use_fast = wants_fast() && !ax0; // (... which only k_sort_mid / k_sort_tiny know how to do)
             // the companion slot of the LDS sorts has a second use: in the gather rounds of a two-stage build it carries the characters in
             // front of the suffix to the row a record ends up in (GatherSpec::pc_out) - the same instances
+            // (class A and the tiny pool only: the larger segments' sorts would pay one more LDS exchange per LSD pass for the few records
+            // they finish - measured: +1.1 ms on the 1 GiB text for 6 % of the characters)
             const bool axp = ax0 || (!W && gather.text != nullptr && gather.pc_out != nullptr);
             // k_sort_bits (round 3) where the keys are spread like random bytes; k_sort_fast2 for the dense base-sigma keys of later
             // rounds (random DNA at depth 18: an eighth of the records of a segment tie - more than the dirty list of k_sort_bits
@@ -907,7 +909,7 @@ struct Rounds {
                         ids = c->doneC.template as<u32>();
                     }
                 }
-                if (axp) k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W, !W><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
+                if (ax0) k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W, !W><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
                     bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, emC, counters, ids, (u32)C_FBC, gather, code);
                 else k_sort_mid<CLS_C_THREADS, CLS_C_ITEMS, W><<<dim3(std::min<u32>(nC, 256u)), dim3(CLS_C_THREADS), sort_mid_lds_bytes<CLS_C_THREADS, CLS_C_ITEMS>(), st>>>(
                     bufs, c->lists[cur][2].template as<Desc>(), nC, sa_local, isa32, mode, emC, counters, ids, (u32)C_FBC, gather, code);
@@ -943,7 +945,7 @@ struct Rounds {
                         ids = c->doneB.template as<u32>();
                     }
                 }
-                if (axp) k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W, !W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
+                if (ax0) k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W, !W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
                     bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, emB, counters, ids, (u32)C_FBB, gather, code);
                 else k_sort_mid<CLS_B_THREADS, CLS_B_ITEMS, W><<<dim3(std::min<u32>(nB, 1024u)), dim3(CLS_B_THREADS), sort_mid_lds_bytes<CLS_B_THREADS, CLS_B_ITEMS>(), st>>>(
                     bufs, c->lists[cur][1].template as<Desc>(), nB, sa_local, isa32, mode, emB, counters, ids, (u32)C_FBB, gather, code);

@@ -2541,7 +2541,7 @@ __global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs,
     __shared__ u64 bm_eq[NW], bm_tiny[NW], bm_seg[NW];
     __shared__ u32 pre_tiny[NW], pre_seg[NW];
     __shared__ u32 misc[8], ach[24];
-    __shared__ Desc dtab[MIDT_BUN];
+    __shared__ __attribute__((aligned(16))) Desc dtab[MIDT_BUN];
     __shared__ u32 st_pre[MIDT_KMAX + 1], st_sab[MIDT_KMAX], st_flag[MIDT_KMAX], st_key0[MIDT_KMAX];
     __shared__ u32 st_roff[MIDT_KMAX];                        // first record of the segment (in its record buffer) minus its first tile position
     __shared__ u8 s_code[256];
@@ -2555,16 +2555,18 @@ __global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs,
     if (g.text) for (u32 i = lane; i < 256u; i += 64u) s_code[i] = code[i];
     const u32 nbun = (nseg + MIDT_BUN - 1) / MIDT_BUN;
     const u32 rank0 = counters[C_RANK0];
-    Desc dn = {0, 0, 0, 0};
-    { const u64 i = (u64)blockIdx.x * MIDT_BUN + lane; if (lane < MIDT_BUN && i < nseg) dn = list[i]; }
+    // (the descriptor in flight is held as four plain words: a struct assigned under a condition lands in scratch memory, with a wait
+    // for the load right behind it)
+    const uint4* list4 = reinterpret_cast<const uint4*>(list);
+    u32 dn0 = 0, dn1 = 0, dn2 = 0, dn3 = 0;
+    { const u64 i = (u64)blockIdx.x * MIDT_BUN + lane; if (lane < MIDT_BUN && i < nseg) { const uint4 v = list4[i]; dn0 = v.x; dn1 = v.y; dn2 = v.z; dn3 = v.w; } }
     for (u32 b = blockIdx.x; b < nbun; b += gridDim.x) {
         __syncthreads();
-        if (lane < MIDT_BUN) dtab[lane] = dn;
+        if (lane < MIDT_BUN) *reinterpret_cast<uint4*>(&dtab[lane]) = make_uint4(dn0, dn1, dn2, dn3);
         {   // the next bundle's descriptors travel while this one is sorted
             const u64 i = ((u64)b + gridDim.x) * MIDT_BUN + lane;
-            const Desc z = {0, 0, 0, 0};
-            dn = z;
-            if (lane < MIDT_BUN && i < nseg) dn = list[i];
+            dn0 = dn1 = dn2 = dn3 = 0;
+            if (lane < MIDT_BUN && i < nseg) { const uint4 v = list4[i]; dn0 = v.x; dn1 = v.y; dn2 = v.z; dn3 = v.w; }
         }
         __syncthreads();
         u32 start = 0;
