@@ -158,6 +158,7 @@ struct msufsort_hip_ctx {
     u32* sel_pc = nullptr;                        // two-stage builds: side array next to the sorted B* suffixes - the characters in front of every suffix
                                                   // whose final row was written by a sort that gathered its key (GatherSpec::pc_out), PC_UNKNOWN elsewhere
     DevBuf ind_spc;
+    bool sel_pc_used = false;                     // the last build_sa call wrote to its slice of sel_pc (it then set the whole slice to PC_UNKNOWN first)
     u32* h_ind = nullptr;                         // pinned staging for the induction tables
     u32 ind_resident = 0;                         // workgroups of k_ind_fused the device holds at once (occupancy x CUs), asked once
     DevBuf sub_partial, sub_hist, sub_saved;      // deeper histogram of ONE two-byte key (shard boundaries inside heavy keys)
@@ -1064,6 +1065,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     // the caller has seen (byte values of a tail sample, or the host's histogram); the device decides for good (<= 84 codes).
     const bool hint = c->hint_small_alphabet;
     c->hint_small_alphabet = false;
+    c->sel_pc_used = false;
     if constexpr (!W) {
         R.aux_cand = !R.no_pack && !c->sw.force_fast && !c->sw.no_fuse && c->sw.key1 >= 0 && (hint || c->sw.key1 > 0) && ms >= 4096;
         if (R.aux_cand) {
@@ -1313,7 +1315,15 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
         const bool fuse = R.mode == MODE_TEXT && !keyed && !R.wants_fast() && !c->sw.no_fuse;
         R.round = round;
         R.code = c->alpha.as<u8>();
-        R.gather = GatherSpec{fuse ? d_text : nullptr, n, ks, (fuse && c->sel_pc) ? c->sel_pc + (1 + rank0 - slice_row_lo) : nullptr};
+        // two-stage builds: the gathering sorts also pick up the characters in front of the suffixes they finish (GatherSpec::pc_out) - in rounds
+        // that gather for at least an eighth of the build's suffixes (a DNA's gather rounds hold 1 % of them: not worth a second load per record);
+        // the slice is set to PC_UNKNOWN right before the first such round (rows that became final earlier hold nothing yet)
+        u32* pc_out = nullptr;
+        if (fuse && c->sel_pc && (actP + actS) * 8 >= ms) {
+            pc_out = c->sel_pc + (1 + rank0 - slice_row_lo);
+            if (!c->sel_pc_used) { HIP_TRY(hipMemsetAsync(pc_out, 0xff, (size_t)ms * 4, st)); c->sel_pc_used = true; }
+        }
+        R.gather = GatherSpec{fuse ? d_text : nullptr, n, ks, pc_out};
         // tandem repeats: tie groups that are one arithmetic progression of positions are finished at once (k_chain_resolve)
         if constexpr (!W) {
             if (R.mode == MODE_ISA && depth <= 4096) {

@@ -358,10 +358,13 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
         if (t < 8) s_present[t] = 0;
         __syncthreads();
         u64 base = cbeg + (u64)t * 16u;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        u32 nx = 0;
+        uint4 v = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
+        u32 nx = 0, nx2 = 0;
         u32 counted = 0;
+        // TWO loads in flight per lane (round 6): with one, a CU had 20 KiB on the way - at 13 GB/s per CU and ~2 us of loaded HBM latency it
+        // waited for its text (tools/microbench/exp_lds_hist_ceiling.hip: the same adds without the loads run a third faster)
         if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = *reinterpret_cast<const u32*>(text + base + 16); }   // (the text is padded)
+        if (base + 16384u < cend) { v2 = *reinterpret_cast<const uint4*>(text + base + 16384u); nx2 = *reinterpret_cast<const u32*>(text + base + 16384u + 16); }
 #pragma unroll 1
         for (u64 sub = cbeg; sub < cend; sub += H16_SUB) {
 #pragma unroll 1
@@ -371,7 +374,8 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
                 const u32 cn = nx;
                 const u64 cb = base;
                 base += 16384u;
-                if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = *reinterpret_cast<const u32*>(text + base + 16); }   // prefetch
+                v = v2; nx = nx2;
+                if (base + 16384u < cend) { v2 = *reinterpret_cast<const uint4*>(text + base + 16384u); nx2 = *reinterpret_cast<const u32*>(text + base + 16384u + 16); }   // prefetch
                 const u32 w[6] = {cv.x, cv.y, cv.z, cv.w, cn, 0u};
                 const u32 lim = cend - cb >= 16 ? 16u : (u32)(cend - cb);
                 u32 pb = 0xffffu;
@@ -2536,7 +2540,8 @@ __global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs,
 {
     constexpr u32 KL = klow<W>();
     constexpr int ITEMS = 8, CAP = 512, NW = 8;
-    __shared__ __attribute__((aligned(16))) u32 ex[CAP];
+    __shared__ __attribute__((aligned(16))) u64 ex2[CAP];      // LSD passes: (key, slot) pairs travel as one 8-byte word
+    u32* const ex = reinterpret_cast<u32*>(ex2);                 // ... everything else uses the first CAP 32-bit words
     __shared__ u32 wcnt[256];
     __shared__ u64 bm_eq[NW], bm_tiny[NW], bm_seg[NW];
     __shared__ u32 pre_tiny[NW], pre_seg[NW];
@@ -2714,16 +2719,10 @@ __global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs,
                     __syncthreads();
 #pragma unroll
                     for (int j = 0; j < ITEMS; ++j)
-                        if (j < rows) { pos[j] = (pos[j] & 0xffffu) + wcnt[pos[j] >> 16]; ex[pos[j]] = key[j]; }
+                        if (j < rows) { pos[j] = (pos[j] & 0xffffu) + wcnt[pos[j] >> 16]; ex2[pos[j]] = ((u64)slot[j] << 32) | key[j]; }
                     __syncthreads();
 #pragma unroll
-                    for (int j = 0; j < ITEMS; ++j) if (j < rows) key[j] = ex[j * 64 + lane];
-                    __syncthreads();
-#pragma unroll
-                    for (int j = 0; j < ITEMS; ++j) if (j < rows) ex[pos[j]] = slot[j];
-                    __syncthreads();
-#pragma unroll
-                    for (int j = 0; j < ITEMS; ++j) if (j < rows) slot[j] = ex[j * 64 + lane];
+                    for (int j = 0; j < ITEMS; ++j) if (j < rows) { const u64 v = ex2[j * 64 + lane]; key[j] = (u32)v; slot[j] = (u32)(v >> 32); }
                     __syncthreads();
                 }
                 // the suffix indices (and companions) follow their records: one exchange, whatever the number of passes
@@ -3286,9 +3285,16 @@ __global__ __launch_bounds__(256) void k_emit_updates(const typename Wd<W>::sa_t
         if (threadIdx.x == 0) {
             s_base = s_cnt ? atomicAdd(&cnt[0], (unsigned long long)s_cnt) : 0ull;
             s_abase = 0;
-            if (s_tied) { tied_total += s_tied; if (act_next) s_abase = atomicAdd(&cnt[2], (unsigned long long)s_tied); }
+            if (s_tied) {
+                tied_total += s_tied;
+                if (act_next) {
+                    s_abase = atomicAdd(&cnt[2], (unsigned long long)s_tied);
+                    if (s_abase + s_tied > act_cap) { cnt[3] = 1ull; s_abase = ~0ull; }      // next step's list overflows: ONE store says so, nothing of this tile is listed
+                }
+            }
         }
         __syncthreads();
+        const bool list_next = act_next != nullptr && s_abase != ~0ull;          // (workgroup-uniform)
 #pragma unroll
         for (int k = 0; k < UPD_K; ++k) {
             if ((mchg >> k) & 1u) {
@@ -3298,10 +3304,7 @@ __global__ __launch_bounds__(256) void k_emit_updates(const typename Wd<W>::sa_t
                     else out[o] = ((slice_lo + g[k]) << 32) | (u64)sa_rows[r[k]];
                 }
             }
-            if (((mtied >> k) & 1u) && act_next) {
-                const u64 o = s_abase + tbase + ot[k];
-                if (o < act_cap) act_next[o] = r[k]; else cnt[3] = 1ull;
-            }
+            if (((mtied >> k) & 1u) && list_next) act_next[s_abase + tbase + ot[k]] = r[k];
         }
         __syncthreads();
     }
@@ -3333,14 +3336,18 @@ __global__ __launch_bounds__(256) void k_list_tied(const u32* __restrict__ grp, 
         if (lane_id() == 0 && wt) tbase = atomicAdd(&s_tied, wt);
         tbase = __shfl(tbase, 0, 64);
         __syncthreads();
-        if (threadIdx.x == 0) s_base = s_tied ? atomicAdd(&cnt[2], (unsigned long long)s_tied) : 0ull;
+        if (threadIdx.x == 0) {
+            s_base = s_tied ? atomicAdd(&cnt[2], (unsigned long long)s_tied) : 0ull;
+            // the list does not hold this tile: ONE store says so (round 6: every lane of every overflowing tile stored the flag - hundreds
+            // of millions of stores to one address on a slice that is mostly tied: 4.9 ms per 2^28-row shard of the 8 GiB DNA job)
+            if (s_tied && s_base + s_tied > act_cap) cnt[3] = 1ull;
+        }
         __syncthreads();
+        if (s_tied && s_base + s_tied > act_cap) break;          // (workgroup-uniform; the counter only grows: every later tile overflows as well,
+                                                                 // and a list that overflowed is not used)
 #pragma unroll
         for (int k = 0; k < UPD_K; ++k)
-            if ((mtied >> k) & 1u) {
-                const u64 o = s_base + tbase + ot[k];
-                if (o < act_cap) act[o] = (u32)(b + (u64)k * 256u + threadIdx.x); else cnt[3] = 1ull;
-            }
+            if ((mtied >> k) & 1u) act[s_base + tbase + ot[k]] = (u32)(b + (u64)k * 256u + threadIdx.x);
         __syncthreads();
     }
 }
