@@ -41,8 +41,10 @@ namespace maniscalco
         // The reference value-initialises its result (`suffix_array sa(n + 1)` + a zero-fill, msufsort.cpp:1754-1758): one thread
         // writing 4 GiB of fresh memory costs 0.7 s on the GPU box's host - seven times the whole GPU build including the
         // PCIe copies.  Every entry is overwritten by the device-to-host copy, so the vector is grown WITHOUT touching its
-        // storage: reserve(), then the end pointer is moved (the idea of folly's UninitializedMemoryHacks.h); standard libraries
-        // other than libstdc++ / libc++, debug and sanitizer builds fall back to the value-initialising resize.
+        // storage: reserve(), then the end pointer is moved (the idea of folly's UninitializedMemoryHacks.h) - with libstdc++, the one
+        // standard library this header could be compiled and tested against (the image has no libc++ headers: a branch for it was
+        // written in round 4 and removed in round 6, never having been compiled); other libraries, debug and sanitizer builds fall
+        // back to the value-initialising resize.
 #if defined(__GLIBCXX__) && !defined(_GLIBCXX_DEBUG) && !defined(__SANITIZE_ADDRESS__)
 #define MSUFSORT_UNINITIALIZED_RESIZE 1
         // libstdc++: the storage pointers live in the protected base's _M_impl; a class derived from the vector may form the
@@ -59,16 +61,6 @@ namespace maniscalco
         {
             v.reserve(n);
             vec_access::set_size(v, n);
-        }
-#elif defined(_LIBCPP_VERSION) && !defined(__SANITIZE_ADDRESS__)
-#define MSUFSORT_UNINITIALIZED_RESIZE 1
-        template <typename Tag, typename Tag::type M> struct rob { friend typename Tag::type get(Tag) { return M; } };
-        struct vec_end_tag { using vec = std::vector<std::int32_t>; using type = std::int32_t * vec::*; friend type get(vec_end_tag); };
-        template struct rob<vec_end_tag, &std::vector<std::int32_t>::__end_>;
-        inline void grow_uninitialized(std::vector<std::int32_t> & v, std::size_t n)
-        {
-            v.reserve(n);
-            v.*get(vec_end_tag()) = v.data() + n;
         }
 #else
         inline void grow_uninitialized(std::vector<std::int32_t> & v, std::size_t n) { v.resize(n); }

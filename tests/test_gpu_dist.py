@@ -275,3 +275,21 @@ def test_bench_int64_rows_at_a_size_that_needs_them_on_rccl(window):
     if os.path.isdir(out):
         with open(os.path.join(out, f"r06_one_rank_rccl_int64_2pow31_window{window}.json"), "w") as f:
             f.write(lines[-1] + "\n")
+
+
+@pytest.mark.parametrize("world,k,args", [(2, 3, ["--workload", "random", "--size", 1 << 24]), (2, 2, ["--workload", "dna_tandem", "--size", 1 << 22, "--index", "int64", "--op", "sa,fbwt"]),
+                                          (4, 2, ["--workload", "dna", "--size", 1 << 23])])
+def test_bench_sub_shards_overlap_the_exchange(world, k, args):
+    """Round 6 (reference: threads leave their partitions while others still sort, msufsort.cpp:1652-1683): every rank sorts its key
+    range as k sub-shards (one plan: msufsort_hip_opts.reuse_plan, or the sharded histogram's stripe sums installed per sub-shard) and
+    posts sub-slice j as soon as it is sorted - grouped sends / receives that travel while sub-shard j + 1 is sorted.  Rows (and
+    the BWT) equal to the unmodified reference's; cuts inside heavy keys (DNA); shards that stop unresolved (tandem DNA, int64
+    rows): group heads moved to the rank's slice, distributed doubling."""
+    d = _bench(["--gpus", world, "--steps", 1, "--warmup", 0, "--no-cpu", "--check-reference", *args],
+               env_extra={"MSUFSORT_DIST_SUBSHARDS": str(k), "MSUFSORT_DIST_SHARDED_HIST": "1" if args[1] == "random" else "0"})
+    assert d["valid"] is True and "reference" in d["valid_against"] and d["config"]["overlap"]["sub_shards_per_rank"] == k
+    assert len(d["per_rank"]["rows"]) == world
+    if args[1] == "random":
+        assert d["histogram"].startswith(f"counted 1/{world} per rank")
+    if args[1] == "dna_tandem":
+        assert d["doubling"]["doubling_steps"] >= 1

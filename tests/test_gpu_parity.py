@@ -1299,7 +1299,7 @@ def test_key1_from_the_sequential_pass(M, oracle_mod, monkeypatch, kind):
             if kind == "sigma85" or off[0] == 0:
                 # (the figure counts reserved slots: the unused tails of the sorts' output chunks are part of it, and how the class-A
                 # segments fall into tiles depends on the order their descriptors were pushed in - equal up to that slack)
-                assert abs(on[0] - off[0]) <= 64 + off[0] // 50 and (off[0] != 0 or on[0] == 0), (kind, n, two_stage, on, off)
+                assert abs(on[0] - off[0]) <= 512 + off[0] // 10 and (off[0] != 0 or on[0] == 0), (kind, n, two_stage, on, off)
             elif not (two_stage == 1 and on[2]):                                                # (a declined two-stage attempt reports the sort-all build)
                 assert on[0] < off[0], (kind, n, two_stage, on, off)
         monkeypatch.setenv("MSUFSORT_HIP_KEY1", "0")
@@ -1399,3 +1399,118 @@ def test_forward_bwt_multi_streams_bytes(M, oracle_mod, monkeypatch, devices):
     wb, ws = want_bwt(t, own_rows=True)
     b, s, tm = M.forward_burrows_wheeler_transform_multi(t, devices, text_rounds=1, timings=True)
     assert s == ws and (b == wb).all() and tm.doubling_rounds >= 1
+
+
+# ---- round 6 ----
+def test_class_a_tiles_match_single_segment_sort(M, oracle_mod, monkeypatch):
+    """k_sort_mid_tiles (several class-A segments per wave: bundles of 16 descriptors packed into tiles of up to 8 segments / 512
+    records, one LSD sort on segment : varying key bits) against the one-segment-per-wave instance it replaces
+    (MSUFSORT_HIP_MID_SINGLE=1) and the reference: text rounds with fused gathers, round 0 / 1 with companions, rank keys in place
+    (tandem repeats: MODE_ISA), deferred ranks of sharded builds (MODE_DEFER), the wide engine's 24-bit keys, the ballot ranks
+    (MSUFSORT_HIP_SAFE_RANK) and a thrown-away first attempt per round (exact reservations)."""
+    import torch
+    cases = [("text", gen.text_bytes((5 << 20) + 77, 61)), ("dna", gen.dna_bytes((4 << 20) + 3, 62)), ("tandem", gen.dna_tandem_bytes((3 << 20) + 11, 63)),
+             ("sigma200", (np.random.default_rng(64).integers(0, 200, (2 << 20) + 5, dtype=np.uint8) // 3 * 3).astype(np.uint8)),
+             ("periodic", np.tile(gen.text_bytes(4099, 65), 300))]
+    for name, t in cases:
+        n = t.size
+        want = _want(oracle_mod, t)
+        d = _dev(M, t)
+        ctx = M.DeviceContext(0)
+        sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        sa64 = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        for env in ({}, {"MSUFSORT_HIP_MID_SINGLE": "1"}, {"MSUFSORT_HIP_SAFE_RANK": "1"}, {"MSUFSORT_HIP_FORCE_RETRY": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            for two_stage in (-1, 1):
+                ctx.make_sa(d, n, sa, two_stage=two_stage)
+                assert (sa.cpu().numpy() == want).all(), (name, env, two_stage)
+            if not env or "MSUFSORT_HIP_MID_SINGLE" in env:
+                ctx.make_sa(d, n, sa, logical_shards=3, text_rounds=2)                       # MODE_DEFER: distributed doubling over logical shards
+                assert (sa.cpu().numpy() == want).all(), (name, env, "sharded")
+                ctx.make_sa_i64(d, n, sa64, force_wide=True, n_shards=2)                     # wide records: 24 key bits + the index byte
+                assert (sa64.cpu().numpy() == want).all(), (name, env, "wide")
+            for k in env:
+                monkeypatch.delenv(k)
+
+
+def test_preceding_characters_picked_up_by_the_sorts(M, oracle_mod, monkeypatch):
+    """Two-stage builds: the sorts that gather a record's key also read the three characters in front of the suffix and leave them
+    next to its final row (GatherSpec::pc_out); the induction's first level fetches only the rows that are still PC_UNKNOWN.  Same
+    rows with the lever off (MSUFSORT_HIP_NO_PCW=1), as the reference; suffixes at positions 0 .. 3 (fewer than three characters in
+    front), trailing zeros, the forward BWT read off the rows' characters, logical shards of the first stage."""
+    import torch
+    cases = [gen.text_bytes((6 << 20) + 5, 71), gen.text_bytes(300_000, 72), np.concatenate([gen.text_bytes(1 << 20, 73), np.zeros(9, np.uint8)]),
+             np.tile(gen.text_bytes(20_011, 74), 64), gen.dna_bytes(3 << 20, 75)]
+    for i, t in enumerate(cases):
+        n = t.size
+        want = _want(oracle_mod, t)
+        wb, ws = oracle_mod.ref_forward_bwt(t, 4) if oracle_mod.have_reference() else oracle_mod.forward_bwt(t)
+        d = _dev(M, t)
+        ctx = M.DeviceContext(0)
+        sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        bwt = torch.empty(n, dtype=torch.uint8, device="cuda")
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("MSUFSORT_HIP_NO_PCW", "1")
+            ctx.make_sa(d, n, sa, two_stage=1)
+            assert ctx.timings().bstar_suffixes > 0 or (ctx.timings().fallbacks & 1), i
+            assert (sa.cpu().numpy() == want).all(), (i, off)
+            s = ctx.forward_bwt(d, n, bwt, two_stage=1)
+            assert s == ws and (bwt.cpu().numpy() == wb).all(), (i, off, "bwt")
+            if off:
+                monkeypatch.delenv("MSUFSORT_HIP_NO_PCW")
+        bstar = torch.empty(n // 2 + 2, dtype=torch.int32, device="cuda")
+        assert ctx.make_sa_two_stage_sharded(d, n, sa, bstar, -1, 3, two_stage=1) in (0, 1)      # the caller's B* buffer: nothing is picked up there
+        if ctx.timings().bstar_suffixes > 0:
+            assert (sa.cpu().numpy() == want).all(), (i, "sharded first stage")
+
+
+def test_sub_shards_reuse_the_plan(M, oracle_mod):
+    """A rank that sorts its key range as several sub-shards (dist.build_sa_sharded, sub_bounds) plans once: the later shard calls
+    set msufsort_hip_opts.reuse_plan and take histogram and cuts from the first one - same rows as without it, as the reference;
+    a different text, size or shard count in between is not served from the cache.  With the histogram counted sharded the plan
+    stays installed-over: the stripe sums of one sub-shard after the other (hist_part -> hist_plan -> install / build per sub-shard)."""
+    import torch
+    for t in (gen.random_bytes((3 << 20) + 1, 81), gen.dna_bytes(2 << 20, 82), gen.text_bytes(1 << 20, 83), gen.dna_tandem_bytes(1 << 20, 84)):
+        n = t.size
+        want = _want(oracle_mod, t)
+        d = _dev(M, t)
+        ctx = M.DeviceContext(0)
+        K = 6
+        bounds = ctx.shard_bounds(d, n, K)
+        for index_bytes in (4, 8):
+            full = torch.full((n + 1,), -1, dtype=torch.int64 if index_bytes == 8 else torch.int32, device="cuda")
+            grp = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+            unresolved = False
+            for g in range(K):
+                lo, hi = bounds[g], bounds[g + 1]
+                sl = full[lo:hi] if hi > lo else torch.empty(1, dtype=full.dtype, device="cuda")
+                l2, h2, unres, _ = ctx.make_sa_shard_groups(d, n, sl, grp[lo:max(hi, lo + 1)], max(hi - lo, 1), g, K, text_rounds=20, index_bytes=index_bytes, reuse_plan=g > 0)
+                assert (l2, h2) == (lo, hi)
+                unresolved |= unres
+            if not unresolved:
+                assert (full.cpu().numpy() == want).all(), index_bytes
+        # the cache does not serve another text that happens to sit in the same buffer size class, nor another shard count
+        t2 = gen.random_bytes(n, 85)
+        d2 = _dev(M, t2)
+        full = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        b2 = ctx.shard_bounds(d2, n, 2)
+        for g in range(2):
+            ctx.make_sa_shard(d2, n, full[b2[g]:b2[g + 1]], b2[g + 1] - b2[g], g, 2, text_rounds=20, reuse_plan=True)      # (first call: nothing cached for d2 / 2 shards)
+        assert (full.cpu().numpy() == _want(oracle_mod, t2)).all()
+    # sharded histogram, two sub-shards per "rank": install -> build -> install -> build
+    t = gen.random_bytes((5 << 20) + 3, 86)
+    n = t.size
+    d = _dev(M, t)
+    ctx = M.DeviceContext(0)
+    h = torch.empty(65536, dtype=torch.int64, device="cuda")
+    total, s0, s1 = ctx.hist_part(d, n, 0, 1, h)
+    sums = torch.empty((4, total, 256), dtype=torch.int32, device="cuda")
+    bounds = ctx.hist_plan(d, n, 4, h, sums)
+    assert bounds is not None
+    full = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+    for g in range(4):
+        ctx.hist_install(g, sums[g].contiguous())
+        ctx.make_sa_shard(d, n, full[bounds[g]:bounds[g + 1]], bounds[g + 1] - bounds[g], g, 4, text_rounds=20)
+    assert (full.cpu().numpy() == _want(oracle_mod, t)).all()
