@@ -163,6 +163,11 @@ struct msufsort_hip_ctx {
     u32 ind_resident = 0;                         // workgroups of k_ind_fused the device holds at once (occupancy x CUs), asked once
     DevBuf sub_partial, sub_hist, sub_saved;      // deeper histogram of ONE two-byte key (shard boundaries inside heavy keys)
     int64_t sub_key = -1;                         // which key sub_partial describes (-1: none); valid for the current text only
+    // ... and the ones computed before it for the same text (round 6): the plan of a DNA's shards computes the deeper histogram of every
+    // straddled key, and every shard build then asked for its boundary keys again - 32 passes of 8.3 ms over the 8 GiB of BASELINE config 5
+    struct SubParked { int64_t key = -1; DevBuf partial, hist; };
+    std::vector<SubParked> sub_parked;
+    void sub_invalidate() { sub_key = -1; for (auto& e : sub_parked) e.key = -1; }
     DevBuf grp_full, grp_prev, upd, upd_cnt;      // single-process sharded builds: tie-group heads (all rows), their copy at the
                                                   // start of a doubling step, rank updates of one row window
     // Histogram computed sharded (multi-GPU jobs, SURVEY 8(e) "Partitioning"; msufsort_hip_hist_part_dev / _hist_plan_dev /
@@ -304,6 +309,8 @@ struct msufsort_hip_ctx {
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
         grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release(); xh_hist.release(); xh_sums.release(); xh.reset(); plan_cache.reset();
         sub_partial.release(); sub_hist.release(); sub_saved.release(); sub_key = -1;
+        for (auto& e : sub_parked) { e.partial.release(); e.hist.release(); }
+        sub_parked.clear();
         ind_sbits.release(); sel_partial.release(); sel_hist.release(); ind_sstar.release(); ind_spc.release();
         ind_pc.release(); ind_tiles.release(); ind_state.release(); ind_tables.release();
         for (auto& a : active) a.release();
@@ -320,6 +327,7 @@ struct msufsort_hip_ctx {
         for (auto& x : pool_rec) b += x.bytes;
         for (auto& x : pool_hdr) b += x.bytes;
         for (int s = 0; s < 2; ++s) { for (int k = 0; k < 3; ++k) b += lists[s][k].bytes; b += large_round[s].bytes + lvl[s].bytes; }
+        for (auto& e : sub_parked) b += e.partial.bytes;
         b += isa.bytes + grp_full.bytes + grp_prev.bytes + upd.bytes + sub_partial.bytes + hist_partial.bytes + seg_hist.bytes + child_start.bytes + cursor.bytes;
         b += doneB.bytes + doneC.bytes + aux0.bytes + aux1.bytes + aux2.bytes + aux3.bytes + sa_own.bytes + text_own.bytes;
         b += ind_sbits.bytes + sel_partial.bytes + ind_sstar.bytes + ind_spc.bytes + ind_pc.bytes + ind_tiles.bytes + h17_partial.bytes;
@@ -443,7 +451,7 @@ int plan_stripes(msufsort_hip_ctx* c, u64 m, u32* hchunks_out)
     TRY(c->set_attrs());          // (k_hist16 takes 136 KiB of dynamic LDS; shard planning reaches this before any build)
     TRY(c->ensure_fixed(hchunks));
     c->nchunks = nchunks; c->chunk_len = (u32)chunk_len; c->hist_per = per;
-    c->sub_key = -1;
+    c->sub_invalidate();
     *hchunks_out = hchunks;
     return MSUFSORT_HIP_OK;
 }
@@ -469,6 +477,24 @@ int run_subhist(msufsort_hip_ctx* c, const u8* d_text, u64 m, u32 key)
 {
     if (c->sub_key == (int64_t)key) return MSUFSORT_HIP_OK;
     const u32 hchunks = c->nchunks * c->hist_per;
+    {   // park the current key's histogram (a handful of them, at most 3 GiB: a DNA has 16 two-byte keys), take this key's if it is parked
+        const size_t one = (size_t)hchunks * 65536 * 4;
+        if (c->sub_key >= 0 && c->sub_partial.bytes >= one && one <= ((size_t)3 << 30) / 4) {
+            const size_t max_parked = std::min<size_t>(16, ((size_t)3 << 30) / one);
+            msufsort_hip_ctx::SubParked* slot = nullptr;
+            for (auto& e : c->sub_parked) if (e.key < 0) { slot = &e; break; }
+            if (!slot && c->sub_parked.size() < max_parked) { c->sub_parked.emplace_back(); slot = &c->sub_parked.back(); }
+            if (!slot && !c->sub_parked.empty()) slot = &c->sub_parked[(size_t)c->sub_key % c->sub_parked.size()];      // (all taken: one of them goes)
+            if (slot) { std::swap(slot->partial, c->sub_partial); std::swap(slot->hist, c->sub_hist); slot->key = c->sub_key; }
+            c->sub_key = -1;
+        }
+        for (auto& e : c->sub_parked)
+            if (e.key == (int64_t)key && e.partial.bytes >= one) {
+                std::swap(e.partial, c->sub_partial); std::swap(e.hist, c->sub_hist);
+                e.key = -1; c->sub_key = (int64_t)key;
+                return MSUFSORT_HIP_OK;
+            }
+    }
     TRY(c->sub_partial.ensure((size_t)hchunks * 65536 * 4));
     TRY(c->sub_hist.ensure(65536 * 8));
     hipLaunchKernelGGL(k_hist16<1>, dim3(hchunks), dim3(1024), H16_LDS_BYTES, c->stream, d_text, m, c->chunk_len / c->hist_per, hchunks, c->sub_partial.as<u32>(),
@@ -2062,7 +2088,7 @@ int make_sa_shard_impl(msufsort_hip_ctx* c, uint8_t* d_text, int64_t n, typename
         hipLaunchKernelGGL(k_hist_from_u64<W>, dim3(256), dim3(256), 0, c->stream, c->xh_hist.as<u64>(), c->hist.as<typename Wd<W>::hist_t>());
         c->plan_small_alphabet = c->xh.small_alphabet;
         ext_sums = true;
-        c->sub_key = -1;
+        c->sub_invalidate();
         // the plan stays (stage 2): the stripe sums of ANOTHER shard of this text may be installed next (a rank that sorts its key range
         // as several sub-shards, dist.py); any other call drops it
         c->xh.stage = 2; c->xh.shard = -1;

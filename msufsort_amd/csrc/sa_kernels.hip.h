@@ -2530,6 +2530,9 @@ __global__ __launch_bounds__(THREADS, (THREADS == 256 ? 4 : 1)) void k_sort_mid(
 // ------------------------------------------------------------------------------------------------
 #define MIDT_BUN 16          // descriptors per bundle
 #define MIDT_KMAX 8          // segments per tile
+#ifndef MIDT_GATHER_B
+#define MIDT_GATHER_B 8      // key gathers of a lane in flight together
+#endif
 #ifndef MIDT_WAVES
 #define MIDT_WAVES 4         // waves per SIMD the register allocation aims at (128 VGPRs)
 #endif
@@ -2653,7 +2656,7 @@ __global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs,
 #pragma unroll
                     for (int j = 0; j < ITEMS; ++j) ax[j] = (valid[j] && g.pc_out) ? pc_fetch(g.text, (u32)fi[j]) : PC_UNKNOWN;
                 }
-                gather_keys<W, ITEMS, 8>(g, s_code, fi, valid, key);
+                gather_keys<W, ITEMS, MIDT_GATHER_B>(g, s_code, fi, valid, key);
 #pragma unroll
                 for (int j = 0; j < ITEMS; ++j) {
                     idx[j] = valid[j] ? (u32)fi[j] : 0xffffffffu;
