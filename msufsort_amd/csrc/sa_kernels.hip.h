@@ -3408,9 +3408,12 @@ __global__ __launch_bounds__(THREADS) void k_chain_resolve(RecBufs bufs, Desc* _
         if (d.len < 4u || d.len > (u32)(THREADS * ITEMS) || (d.buf & DESC_STALE)) continue;      // (workgroup-uniform)
         if (t == 0) { s_P = 0xffffffffu; s_nf = 0; s_tail = ~0ull; }
         __syncthreads();
+        // (the step is looked for among the first rows: the others are loaded once there is one - most segments of the later doubling
+        // rounds have none, and a class-B segment is up to 18 KB of rows)
         idx_t idx[ITEMS];
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { const u32 p = (u32)j * THREADS + t; idx[j] = p < d.len ? sa_rows[d.sa_off + p] : NONE; }
+        for (int j = 1; j < ITEMS; ++j) idx[j] = NONE;
+        idx[0] = t < d.len ? sa_rows[d.sa_off + t] : NONE;
         const idx_t i00 = sa_rows[d.sa_off];
         if ((u64)i00 >= n) continue;
         const idx_t g0 = isa[i00];                            // the rank every member holds
@@ -3441,6 +3444,8 @@ __global__ __launch_bounds__(THREADS) void k_chain_resolve(RecBufs bufs, Desc* _
         __syncthreads();
         const u32 P = s_P;
         if (P == 0u || P == 0xffffffffu) continue;
+#pragma unroll
+        for (int j = 1; j < ITEMS; ++j) { const u32 p = (u32)j * THREADS + t; idx[j] = p < d.len ? sa_rows[d.sa_off + p] : NONE; }
         // 2. one progression?  every member but one must have its successor i + P in the group
         u32 nf = 0;
         u64 tail = ~0ull;
