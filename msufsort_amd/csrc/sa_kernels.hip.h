@@ -358,13 +358,10 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
         if (t < 8) s_present[t] = 0;
         __syncthreads();
         u64 base = cbeg + (u64)t * 16u;
-        uint4 v = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
-        u32 nx = 0, nx2 = 0;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        u32 nx = 0;
         u32 counted = 0;
-        // TWO loads in flight per lane (round 6): with one, a CU had 20 KiB on the way - at 13 GB/s per CU and ~2 us of loaded HBM latency it
-        // waited for its text (tools/microbench/exp_lds_hist_ceiling.hip: the same adds without the loads run a third faster)
         if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = *reinterpret_cast<const u32*>(text + base + 16); }   // (the text is padded)
-        if (base + 16384u < cend) { v2 = *reinterpret_cast<const uint4*>(text + base + 16384u); nx2 = *reinterpret_cast<const u32*>(text + base + 16384u + 16); }
 #pragma unroll 1
         for (u64 sub = cbeg; sub < cend; sub += H16_SUB) {
 #pragma unroll 1
@@ -374,8 +371,9 @@ __global__ __launch_bounds__(1024) void k_hist16(const u8* __restrict__ text, u6
                 const u32 cn = nx;
                 const u64 cb = base;
                 base += 16384u;
-                v = v2; nx = nx2;
-                if (base + 16384u < cend) { v2 = *reinterpret_cast<const uint4*>(text + base + 16384u); nx2 = *reinterpret_cast<const u32*>(text + base + 16384u + 16); }   // prefetch
+                if (base < cend) { v = *reinterpret_cast<const uint4*>(text + base); nx = *reinterpret_cast<const u32*>(text + base + 16); }   // prefetch
+                // (two loads in flight per lane instead of one: measured in round 6, 0.321 against 0.324 ms per GiB - the LDS atomics, not the
+                // text, are what the kernel waits for: tools/microbench/exp_lds_hist_ceiling.hip)
                 const u32 w[6] = {cv.x, cv.y, cv.z, cv.w, cn, 0u};
                 const u32 lim = cend - cb >= 16 ? 16u : (u32)(cend - cb);
                 u32 pb = 0xffffu;
