@@ -386,7 +386,8 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
     for (int w2 = 0; w2 < 4; ++w2) wcnt[w2][t] = 0;
     if (MODE == 0) goff[t] = (my_code != 255u || tb.nb == 256u) ? tile_hist[(u64)tile * tb.nb + my_code] : 0u;
     __syncthreads();
-    u32 j[IND_ITEMS], bin[IND_ITEMS], npc[IND_ITEMS], posw[IND_ITEMS];
+    u32 j[IND_ITEMS], bin[IND_ITEMS], npc[IND_ITEMS];          // bin[i]: target byte (256: none) in bits 0..8, from the ranking on also the rank inside
+                                                                 // the wave's share of the tile in bits 16.. (one register per source instead of two)
     u32 starmask = 0;
     // (phases, so that all of a thread's loads of one kind are in flight together: rows, then characters)
 #pragma unroll
@@ -437,13 +438,12 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
                 peers &= bit ? bal : ~bal;
             }
         }
-        posw[i] = 0;
         if (on) {
             const int leader = __ffsll((long long)peers) - 1;
             u32 old = 0;
             if ((int)lane == leader) old = atomicAdd(&wcnt[wv][bin[i]], (u32)__popcll(peers));
             old = __shfl(old, leader, 64);
-            posw[i] = old + (u32)__popcll(peers & lt_mask);
+            bin[i] |= (old + (u32)__popcll(peers & lt_mask)) << 16;
         }
     }
     __syncthreads();
@@ -522,9 +522,10 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
     if (FUSED && s_fail) return;
 #pragma unroll
     for (int i = 0; i < IND_ITEMS; ++i)
-        if (bin[i] < 256u) {
-            const u32 k = wcnt[wv][bin[i]] + posw[i];
-            const u32 dst = lv.pass_b ? goff[bin[i]] - k : goff[bin[i]] + k;
+        if ((bin[i] & 0x1ffu) < 256u) {
+            const u32 b = bin[i] & 0x1ffu;
+            const u32 k = wcnt[wv][b] + (bin[i] >> 16);
+            const u32 dst = lv.pass_b ? goff[b] - k : goff[b] + k;
             sa[dst] = j[i] - 1u;
             pc[dst] = npc[i];
         }
@@ -545,7 +546,10 @@ __global__ __launch_bounds__(256) void k_ind_scatter(IndState* st, IndLevel lv, 
 // One level in ONE pass over its rows (instead of k_ind_count + k_ind_scan + k_ind_scatter): tiles are handed out in order by a
 // ticket counter, every tile ranks its sources, publishes its per-byte counts and learns its first target rows from the tiles in
 // front of it (decoupled look-back), then writes.  The rows are read once, the B* rows fetch their characters here.
-__global__ __launch_bounds__(256) void k_ind_fused(IndState* st, IndLevel lv, u32 epoch, u32* sa, u32* pc, const u8* __restrict__ text, IndTables tb,
+#ifndef IND_WAVES
+#define IND_WAVES 1
+#endif
+__global__ __launch_bounds__(256, IND_WAVES) void k_ind_fused(IndState* st, IndLevel lv, u32 epoch, u32* sa, u32* pc, const u8* __restrict__ text, IndTables tb,
                                                    u64* status)
 {
     __shared__ u32 wcnt[4][256];
