@@ -367,7 +367,7 @@ def kernel_table(phases, K, n, workload, ops, ibwt_us):
     mstar = phases[-1].bstar_suffixes
     two_stage = mstar > 0
     ms_ = mstar if two_stage else m          # suffixes the sort phases handle
-    # small alphabets: the key of the first gather round travels with the records through round 0 (DESIGN 1.4a): 4 bytes more per
+    # small alphabets: the key of the first gather round travels with the records through round 0 (DESIGN 1.4): 4 bytes more per
     # suffix written by the scatter, 8 more moved by the partition level
     k1 = 1 if phases[-1].key1_records > 0 else 0
     kern = {
@@ -410,7 +410,7 @@ def traffic_lookup(workload, n, kernel):
     new PMC pass leaves no stale figure in the line (round-3 review)."""
     try:
         pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        e = pt.get("entries", {}).get(workload)
+        e = pt.get("entries", {}).get(f"{workload}@{n}") or pt.get("entries", {}).get(workload)
         if not e or e.get("n") != n or kernel not in e["kernels"]:
             return None, None
         if pt.get("build_id") != build_id():
@@ -594,7 +594,7 @@ def config_lines(M, torch, ctx, dev, steps, no_cpu):
         cfg3["two_stage"] = {"bstar_suffixes": int(mstar), "induced_suffixes": int(n - mstar), "front_ms": round(avg("front_ms"), 3),
                              "induction_ms": round(avg("other_ms"), 3), "level_launches": int(S.phases[-1].induction_launches)}
     cfg3["fallbacks"] = int(sum(p.fallbacks & 1 for p in S.phases))
-    cfg3["key1_records"] = int(S.phases[-1].key1_records)          # suffixes whose first gather round needed no gather (DESIGN 1.4a)
+    cfg3["key1_records"] = int(S.phases[-1].key1_records)          # suffixes whose first gather round needed no gather (DESIGN 1.4)
     cfg3["gathered_records"] = int(sum(p.gathered_records for p in S.phases) / K)
     walk_ms = S.ibwt_us[0] / K / 1e3
     cfg4 = {"workload": f"forward BWT of that text -> inverse BWT, n={n}, output compared with the text on the device", "valid": ok,

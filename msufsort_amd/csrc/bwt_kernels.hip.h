@@ -405,7 +405,7 @@ __device__ __forceinline__ u32 ibwt_start(u32 id, u32 sent, u32 kreg) { return i
 #define IBWT_CW 1024u
 #endif
 #ifndef IBWT_NCH
-#define IBWT_NCH 1                  // chains per lane (2048 lanes per CU walk one chain each: more adds nothing)
+#define IBWT_NCH 1                  // chains per lane (2048 lanes per CU walk one chain each: more adds nothing, see profiles/HISTORY.md, tried and rejected)
 #endif
 #ifndef IBWT_PIECE
 #define IBWT_PIECE 64u              // bytes per scattered store of a chain (a power of two, 16 .. 128): one whole 64-byte sector

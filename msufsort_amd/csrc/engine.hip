@@ -94,7 +94,7 @@ struct Switches {
                                  // histogram first (1, 2: test hooks)
     int sync_debug = 0;          // MSUFSORT_HIP_SYNC_DEBUG
     int key1 = 0;                // MSUFSORT_HIP_KEY1: -1 the first gather round always gathers; 0 small alphabets get its key from k_scatter0 when the caller has
-                                 // seen few byte values; 1 whenever the alphabet turns out small (DESIGN 1.4a)
+                                 // seen few byte values; 1 whenever the alphabet turns out small (DESIGN 1.4)
     bool host_trace = false;     // MSUFSORT_HIP_HOST_TRACE: timeline of the host-pointer entry points on stderr
     int isa_window_kib = 256 << 10;      // MSUFSORT_HIP_ISA_WINDOW_MIB / _KIB (tests): piece of the rank array one pass of its build writes into (0: one pass)
     void load()
@@ -699,7 +699,7 @@ struct Rounds {
     int verbose = 0;
     bool exact_sticky = false, fast_gave_up = false, force_retry = false, no_pack = false;
     bool safe_rank = false, bucket_sort_bits = true;      // (set from c->sw by init())
-    // key of the first gather round from the sequential pass (DESIGN 1.4a): aux_cand = companion buffers are in place and
+    // key of the first gather round from the sequential pass (DESIGN 1.4): aux_cand = companion buffers are in place and
     // k_scatter0 / the level-1 partition were given them; aux_on = the alphabet turned out small (<= 84 codes), the companions
     // exist and round 0's kernels carry them; the records round 0 emits then arrive in round 1 WITH their keys
     bool aux_cand = false, aux_on = false;
@@ -1085,7 +1085,7 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
     Rounds<W> R;
     R.init(c, st, counters);            // (incl. the test hooks: force_retry throws every round's first sort attempt away)
     R.klo = klo; R.khi = khi; R.verbose = verbose;
-    // Key of the first gather round from the sequential pass (DESIGN 1.4a; narrow records): k_scatter0 holds the text of its
+    // Key of the first gather round from the sequential pass (DESIGN 1.4; narrow records): k_scatter0 holds the text of its
     // tile anyway and writes, next to every record, the key the first gather round would fetch with a random text access per
     // suffix.  Worth it where nearly every suffix is still tied after round 0: small alphabets (text, DNA) - whether this is one
     // the caller has seen (byte values of a tail sample, or the host's histogram); the device decides for good (<= 84 codes).

@@ -73,7 +73,7 @@ struct Desc {            // one segment = run of records that are equal on every
 
 // x[] (optional, narrow builds of small alphabets): one 32-bit word per record of p[], same indexing - the key of the FIRST gather
 // round, which k_scatter0 reads off the text tile it holds anyway; it travels with the records through round 0 and the round-0
-// sorts put it into the free upper half of the records they emit, so that round 1 needs no gather (DESIGN.md section 1.4a)
+// sorts put it into the free upper half of the records they emit, so that round 1 needs no gather (DESIGN.md section 1.4)
 struct RecBufs { u64* p[3]; u32* x[3]; };
 
 // counters block (device resident, read back by the host once per phase)
@@ -108,7 +108,7 @@ enum {
 #endif
 #define CLS_A_THREADS 64
 #ifndef CLS_A_ITEMS
-#define CLS_A_ITEMS 8        // <= 512 (12 / 16 measured on text: see DESIGN section 6)
+#define CLS_A_ITEMS 8        // <= 512 (12 / 16 measured on text: see profiles/HISTORY.md, tried and rejected)
 #endif
 #define CLS_B_THREADS 256
 #define CLS_B_ITEMS 18       // <= 4608
@@ -2541,6 +2541,7 @@ __global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs,
 {
     constexpr u32 KL = klow<W>();
     constexpr int ITEMS = 8, CAP = 512, NW = 8;
+    static_assert(CAP_A <= CAP, "a class-A segment must fit one tile");
     __shared__ __attribute__((aligned(16))) u64 ex2[CAP];      // LSD passes: (key, slot) pairs travel as one 8-byte word
     u32* const ex = reinterpret_cast<u32*>(ex2);                 // ... everything else uses the first CAP 32-bit words
     __shared__ u32 wcnt[256];
@@ -2582,6 +2583,7 @@ __global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs,
             while (e < MIDT_BUN) {
                 const u32 l = dtab[e].len;
                 if (l != 0) {
+                    if (K == 0u && l > (u32)CAP) { if (lane == 0) atomicOr(&counters[C_ERR], 0x800u); ++e; break; }      // (not a class-A segment: cannot happen; reported, not looped on)
                     if (K == MIDT_KMAX || T + l > (u32)CAP) break;
                     if (lane == 0) {
                         const Desc d = dtab[e];
@@ -2592,7 +2594,7 @@ __global__ __launch_bounds__(64, MIDT_WAVES) void k_sort_mid_tiles(RecBufs bufs,
                 ++e;
             }
             start = e;
-            if (K == 0) break;
+            if (K == 0) continue;          // (nothing but neutral entries up to `start`: the loop ends when start reaches the bundle's end)
             if (lane <= MIDT_KMAX && lane >= K) st_pre[lane] = lane == K ? T : 0xffffffffu;
             if (lane < 8) misc[lane] = 0;
             __syncthreads();

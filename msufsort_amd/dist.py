@@ -552,9 +552,10 @@ def build_sa_sharded(ctx, d_text, n: int, d_sa_full, rank: int, world: int, dist
     big = 1 << 62
     flag = torch.tensor([depth if unresolved_any else 0, -(depth if unresolved_any else big)], dtype=torch.int64, device=dev)
     if _many(world):
-        # (16 bytes; on the communicator of the small collectives where there is one - behind the sub-slices already posted it would
-        # wait for them; and before the last sub-slice is posted: see the note in DESIGN 3.3)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=hist_group)
+        # (16 bytes, queued before the last sub-slice.  A complete build waits for the slices anyway, so the agreement travels on the same
+        # communicator, in order behind the sub-slices already posted: no second communicator runs beside the exchange.  Only the
+        # pipelined flavour, which returns without waiting, puts it on the small collectives' own communicator)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=hist_group if overlap else None)
         if gather_rows:
             works += post(k - 1)
     dmax, dmin = int(flag[0].item()), -int(flag[1].item())

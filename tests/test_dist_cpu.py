@@ -294,7 +294,7 @@ def test_distributed_doubling_driver_gloo(world, index_bytes, k, tmp_path, oracl
 
 
 def test_sharded_histogram_policy(monkeypatch):
-    """dist.sharded_hist_enabled: on where >= 0.75 GiB of text are counted by the OTHER ranks (measured break-even, DESIGN 3.3b);
+    """dist.sharded_hist_enabled: on where >= 0.75 GiB of text are counted by the OTHER ranks (measured break-even, DESIGN 3.3);
     MSUFSORT_DIST_SHARDED_HIST=1 / 0 force it; one rank only under the always-collective hook."""
     from msufsort_amd import dist as D
     monkeypatch.delenv("MSUFSORT_DIST_SHARDED_HIST", raising=False)

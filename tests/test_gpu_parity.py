@@ -1260,7 +1260,7 @@ def test_trim_releases_the_host_ring(M):
 
 @pytest.mark.parametrize("kind", ["text", "dna", "sigma84", "sigma85", "dna_tandem", "text_tail_zeros"])
 def test_key1_from_the_sequential_pass(M, oracle_mod, monkeypatch, kind):
-    """DESIGN 1.4a: for small alphabets (<= 84 codes) k_scatter0 writes, next to every record, the key the FIRST gather round would
+    """DESIGN 1.4: for small alphabets (<= 84 codes) k_scatter0 writes, next to every record, the key the FIRST gather round would
     fetch (the next cpk symbols as one base-sigma number: 6 for text, 13 for DNA - up to 21 bytes of look-ahead behind the tile);
     it travels with the records through round 0 and round 1 sorts without a single random text access.  Same rows as with the
     lever off (MSUFSORT_HIP_KEY1=-1) and as the reference; the first round's records no longer count as gathered; 85 codes: off.

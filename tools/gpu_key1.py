@@ -1,4 +1,4 @@
-"""A/B of "key of the first gather round from the sequential pass" (DESIGN 1.4a): MSUFSORT_HIP_KEY1=-1 (every gather round gathers,
+"""A/B of "key of the first gather round from the sequential pass" (DESIGN 1.4): MSUFSORT_HIP_KEY1=-1 (every gather round gathers,
 the round-4 behaviour) against the default, on the text / DNA workloads, with the per-round lines of one verbose build each.
 Run on the GPU box: python tools/gpu_key1.py [size]"""
 import os

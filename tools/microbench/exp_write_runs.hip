@@ -1,7 +1,7 @@
 // The write-out of the scatter levels, alone: a workgroup holds a tile of T records sorted by bin, claims a range per (tile, bin)
 // from per-stripe cursors with one atomic each, and writes the tile - consecutive lanes consecutive slots, i.e. runs of T / NB
 // records (on average) that abut at arbitrary 8-byte positions.  What does the store rate depend on: the run length (tile
-// size), the number of bins, alignment?  (Round 4: sizing the lever "longer runs" for k_scatter0 / k_partition)
+// size), the number of bins, alignment?  (Round 4: sizing the lever "longer runs" for k_scatter0 / k_partition, profiles/HISTORY.md.)
 //   hipcc --offload-arch=gfx950 -O3 tools/microbench/exp_write_runs.hip -o tools/microbench/bin/exp_write_runs
 #include <hip/hip_runtime.h>
 #include <cstdio>
