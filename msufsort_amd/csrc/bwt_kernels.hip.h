@@ -50,6 +50,22 @@ __global__ __launch_bounds__(256) void k_bwt_from_pc(const u8* __restrict__ text
     }
 }
 
+// The same for ONE region of rows [lo, hi) that has become final while the build goes on (two-stage build, engine.hip BwtRide).
+// mode 0: the row of suffix 0 lies behind the region, 1: in front of it, 2: inside (k_find_row0 has written it to *sentp).
+__global__ __launch_bounds__(256) void k_find_row0(const u32* __restrict__ sa, u64 lo, u64 hi, unsigned long long* __restrict__ sent)
+{
+    for (u64 r = lo + (u64)blockIdx.x * 256u + threadIdx.x; r < hi; r += (u64)gridDim.x * 256u)
+        if (sa[r] == 0) *sent = r;
+}
+__global__ __launch_bounds__(256) void k_bwt_region(const u8* __restrict__ text, const u32* __restrict__ sa, const u32* __restrict__ pc, u64 lo, u64 hi, u32 mode,
+                                                    const unsigned long long* __restrict__ sentp, u8* __restrict__ out)
+{
+    const u64 sent = mode == 2u ? *sentp : (mode == 1u ? 0ull : ~0ull);
+    for (u64 r = lo + (u64)blockIdx.x * 256u + threadIdx.x; r < hi; r += (u64)gridDim.x * 256u) {
+        const u32 v = sa[r];
+        if (v != 0) out[r - (r > sent)] = r == 0 ? text[v - 1] : (u8)pc[r];
+    }
+}
 
 // demo convention (main.cpp:66-101): out[i] = lcp(SA[i+1], SA[i+2]), i in [0, n-2]; out[n-1] = 0.
 // Direct compare like the demo's match_length, but capped: a pair that is still equal after `cap` bytes raises

@@ -75,6 +75,7 @@ struct DevBuf {
 
 struct HostRing;      // pinned bounce ring for device-to-host copies into pageable memory (host_xfer.inc)
 struct Copier;        // thread that sends finished row ranges to the host while the build goes on (host_xfer.inc)
+struct HostTrace;     // MSUFSORT_HIP_HOST_TRACE timeline (host_xfer.inc)
 
 }  // namespace
 
@@ -96,6 +97,8 @@ struct Switches {
     int key1 = 0;                // MSUFSORT_HIP_KEY1: -1 the first gather round always gathers; 0 small alphabets get its key from k_scatter0 when the caller has
                                  // seen few byte values; 1 whenever the alphabet turns out small
     bool host_trace = false;     // MSUFSORT_HIP_HOST_TRACE: timeline of the host-pointer entry points on stderr
+    bool no_early_b = false;     // MSUFSORT_HIP_NO_EARLY_B: a host-pointer two-stage build sends rows from its last pass only (A / B)
+    bool no_bwt_ride = false;    // MSUFSORT_HIP_NO_BWT_RIDE: the forward transform gathers its bytes after the build (A / B)
     int isa_window_kib = 256 << 10;      // MSUFSORT_HIP_ISA_WINDOW_MIB / _KIB (tests): piece of the rank array one pass of its build writes into (0: one pass)
     void load()
     {
@@ -116,6 +119,8 @@ struct Switches {
         sync_debug = num("MSUFSORT_HIP_SYNC_DEBUG", 0);
         key1 = num("MSUFSORT_HIP_KEY1", 0);
         host_trace = on("MSUFSORT_HIP_HOST_TRACE");
+        no_early_b = on("MSUFSORT_HIP_NO_EARLY_B");
+        no_bwt_ride = on("MSUFSORT_HIP_NO_BWT_RIDE");
         isa_window_kib = std::max(0, on("MSUFSORT_HIP_ISA_WINDOW_KIB") ? num("MSUFSORT_HIP_ISA_WINDOW_KIB", 0) : std::min(1 << 20, num("MSUFSORT_HIP_ISA_WINDOW_MIB", 256)) << 10);
     }
 };
@@ -211,6 +216,17 @@ struct msufsort_hip_ctx {
     Copier* sink = nullptr;
     int32_t* sink_host = nullptr;
     u64 sink_rows = 0;
+    const HostTrace* trace = nullptr;      // the entry point's timeline, for marks from inside the build
+    // Forward transform riding on a two-stage build (msufsort_hip_forward_bwt_dev sets d_out): the byte in front of every row is known
+    // when the row is (pc[]), so every bucket region's bytes are written on gather_stream as soon as the region is final - beside the
+    // remaining induction levels instead of after them - and a host-pointer call (sink) lets them leave at once.
+    struct BwtRide {
+        u8* d_out = nullptr;          // n bytes on the device, final positions (row r -> r - (r > row of suffix 0))
+        int first = -1;               // T[0]: the bucket that holds the row of suffix 0 (-1: ask the device)
+        bool done = false;            // every byte is in d_out, the row of suffix 0 in bwt_sent
+        Copier* sink = nullptr; u8* host_out = nullptr; u64 sent = 0;      // bytes handed to the copier so far
+    } bwt;
+    DevBuf bwt_sent;
     HostRing* ring = nullptr;    // created by the first large device-to-host copy of a host-pointer entry point
     std::mutex ring_mu, ring_use;
 
@@ -307,7 +323,7 @@ struct msufsort_hip_ctx {
         cursor.release(); cursor0.release(); tile_start.release(); trivial.release(); seg_hist.release(); counters.release();
         h17_partial.release(); h17_fb.release(); h17.release(); child_start17.release(); child_cnt17.release(); cursor17.release();
         isa.release(); doneB.release(); doneC.release(); text_own.release(); sa_own.release(); aux0.release(); aux1.release(); aux2.release(); aux3.release();
-        grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release(); xh_hist.release(); xh_sums.release(); xh.reset(); plan_cache.reset();
+        grp_full.release(); grp_prev.release(); upd.release(); upd_cnt.release(); bwt_sent.release(); xh_hist.release(); xh_sums.release(); xh.reset(); plan_cache.reset();
         sub_partial.release(); sub_hist.release(); sub_saved.release(); sub_key = -1;
         for (auto& e : sub_parked) { e.partial.release(); e.hist.release(); }
         sub_parked.clear();
@@ -2239,11 +2255,13 @@ int msufsort_hip_make_sa_i32_ctx(msufsort_hip_ctx* c, const uint8_t* text, int64
     Copier copier;
     if (stream_rows) {
         if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        copier.tr = &tr;
         copier.start(c->device, c->copy_stream, c);
         c->sink = &copier; c->sink_host = sa_out; c->sink_rows = 0;
     }
+    c->trace = &tr;
     int r = msufsort_hip_make_sa_i32_dev(c, c->text_own.as<u8>(), n, c->sa_own.as<int32_t>(), opts);
-    c->sink = nullptr;
+    c->sink = nullptr; c->trace = nullptr;
     tr.mark("built");
     if (stream_rows) {
         if (r == MSUFSORT_HIP_OK) {

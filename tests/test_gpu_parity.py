@@ -1031,6 +1031,39 @@ def test_host_entry_points_fresh_result(M, oracle_mod):
     assert (M.reverse_burrows_wheeler_transform(b, s) == t2).all()
 
 
+@pytest.mark.parametrize("kind,n,two_stage", [("text", (84 << 20) + 3, 0), ("dna", (66 << 20) + 1, 1)])
+def test_host_two_stage_results_leave_while_the_build_goes_on(M, oracle_mod, monkeypatch, kind, n, two_stage):
+    """Host-pointer calls on inputs that take the two-stage build: the rows (suffix array) and the bytes (forward transform) of a bucket
+    region leave as soon as the region is final - B regions from the right-to-left pass already, the bytes written on a second
+    stream from the rows' preceding characters, the bucket of T[0] closing the hole of the sentinel row by itself.  Checked against
+    a device-resident sort-all build and the transform gathered from ITS rows; the switches give the same results."""
+    import torch
+    t = gen.GENERATORS[kind](n, 41)
+    ctx = M.DeviceContext(0)
+    d = _dev(M, t)
+    ref = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, n, ref, two_stage=-1)
+    assert ctx.validate_sa(d, n, ref) == 0
+    bref = torch.empty(n, dtype=torch.uint8, device="cuda")
+    sref = ctx.bwt_from_sa(d, n, ref, bref)
+    want, bwant = ref.cpu().numpy(), bref.cpu().numpy()
+    b1 = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert ctx.forward_bwt(d, n, b1, two_stage=two_stage) == sref and torch.equal(b1, bref)      # device-resident: the bytes ride on the build
+    assert ctx.timings().bstar_suffixes > 0
+    del ctx, d, ref, bref, b1
+    torch.cuda.empty_cache()
+    for env in ({}, {"MSUFSORT_HIP_NO_EARLY_B": "1"}, {"MSUFSORT_HIP_NO_BWT_RIDE": "1"}):
+        for k in ("MSUFSORT_HIP_NO_EARLY_B", "MSUFSORT_HIP_NO_BWT_RIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if "MSUFSORT_HIP_NO_BWT_RIDE" not in env:
+            assert (M.make_suffix_array(t, two_stage=two_stage) == want).all()
+        if "MSUFSORT_HIP_NO_EARLY_B" not in env or kind == "text":
+            b, s = M.forward_burrows_wheeler_transform(t, two_stage=two_stage)
+            assert s == sref and (b == bwant).all()
+
+
 @pytest.mark.parametrize("kind,n,shards", [("text", (2 << 20) + 77, 2), ("text", (2 << 20) + 77, 8), ("dna", 1 << 20, 3), ("text_copy", 1 << 19, 4)])
 def test_two_stage_sharded_first_stage(M, oracle_mod, kind, n, shards):
     """msufsort_hip_make_sa_two_stage_sharded_dev with all shards on this GPU (shard = -1, no exchange): the B* suffixes sorted shard
