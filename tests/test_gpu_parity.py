@@ -1052,8 +1052,12 @@ def test_host_two_stage_results_leave_while_the_build_goes_on(M, oracle_mod, mon
     assert ctx.timings().bstar_suffixes > 0
     del ctx, d, ref, bref, b1
     torch.cuda.empty_cache()
-    for env in ({}, {"MSUFSORT_HIP_NO_EARLY_B": "1"}, {"MSUFSORT_HIP_NO_BWT_RIDE": "1"}):
-        for k in ("MSUFSORT_HIP_NO_EARLY_B", "MSUFSORT_HIP_NO_BWT_RIDE"):
+    # (IND_SPIN = 1: a look-back of the induction times out AFTER rows / bytes of some regions have left - the attempt is abandoned, all
+    # suffixes are sorted, and what left early is sent again behind the stale copies)
+    for env in ({}, {"MSUFSORT_HIP_NO_EARLY_B": "1"}, {"MSUFSORT_HIP_NO_BWT_RIDE": "1"}, {"MSUFSORT_HIP_IND_SPIN": "1"}):
+        if "MSUFSORT_HIP_IND_SPIN" in env and kind != "text":
+            continue
+        for k in ("MSUFSORT_HIP_NO_EARLY_B", "MSUFSORT_HIP_NO_BWT_RIDE", "MSUFSORT_HIP_IND_SPIN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
