@@ -99,6 +99,7 @@ struct Switches {
     bool host_trace = false;     // MSUFSORT_HIP_HOST_TRACE: timeline of the host-pointer entry points on stderr
     bool no_early_b = false;     // MSUFSORT_HIP_NO_EARLY_B: a host-pointer two-stage build sends rows from its last pass only (A / B)
     bool no_bwt_ride = false;    // MSUFSORT_HIP_NO_BWT_RIDE: the forward transform gathers its bytes after the build (A / B)
+    bool no_tiny2 = false;       // MSUFSORT_HIP_NO_TINY2: k_sort_tiny ranks by one key per gather (A / B)
     int isa_window_kib = 256 << 10;      // MSUFSORT_HIP_ISA_WINDOW_MIB / _KIB (tests): piece of the rank array one pass of its build writes into (0: one pass)
     void load()
     {
@@ -121,6 +122,7 @@ struct Switches {
         host_trace = on("MSUFSORT_HIP_HOST_TRACE");
         no_early_b = on("MSUFSORT_HIP_NO_EARLY_B");
         no_bwt_ride = on("MSUFSORT_HIP_NO_BWT_RIDE");
+        no_tiny2 = on("MSUFSORT_HIP_NO_TINY2");
         isa_window_kib = std::max(0, on("MSUFSORT_HIP_ISA_WINDOW_KIB") ? num("MSUFSORT_HIP_ISA_WINDOW_KIB", 0) : std::min(1 << 20, num("MSUFSORT_HIP_ISA_WINDOW_MIB", 256)) << 10);
     }
 };
@@ -1365,7 +1367,9 @@ int build_sa(msufsort_hip_ctx* c, u8* d_text, u64 n, typename Wd<W>::sa_t* d_sa_
             pc_out = c->sel_pc + (1 + rank0 - slice_row_lo);
             if (!c->sel_pc_used) { HIP_TRY(hipMemsetAsync(pc_out, 0xff, (size_t)ms * 4, st)); c->sel_pc_used = true; }
         }
-        R.gather = GatherSpec{fuse ? d_text : nullptr, n, ks, pc_out};
+        // narrow text rounds with keys of up to 8 symbols: k_sort_tiny ranks by this round's key and the next one's (GS_TINY2)
+        const u32 gflags = (!W && fuse && ks.cpk <= 8u && !c->sw.no_tiny2) ? GS_TINY2 : 0u;
+        R.gather = GatherSpec{fuse ? d_text : nullptr, n, ks, pc_out, gflags};
         // tandem repeats: tie groups that are one arithmetic progression of positions are finished at once (k_chain_resolve)
         if constexpr (!W) {
             if (R.mode == MODE_ISA && depth <= 4096) {

@@ -991,7 +991,10 @@ struct GatherSpec {
                           // does not fetch them with a random text access per B* suffix (reference: the entries of the multi-threaded
                           // induction cache their preceding symbol, msufsort.cpp:674-790).  Written at most once per row, together with
                           // the row's final write; rows finalised by a kernel that gathered nothing keep PC_UNKNOWN.
+    u32 flags;            // GS_TINY2: k_sort_tiny reads TWO keys' worth of symbols per gather and ranks by both (narrow text rounds whose
+                          // two windows fit one 16-byte load): a run that the next round would have split is split now
 };
+#define GS_TINY2 1u
 #define PC_UNKNOWN 0xffffffffu
 
 // the (up to) three characters in front of suffix j and how many there are: T[j-1] | T[j-2] << 8 | T[j-3] << 16 | count << 24
@@ -1041,6 +1044,37 @@ __device__ __forceinline__ void gather_keys(const GatherSpec& g, const u8* code,
         }
 #pragma unroll
         for (int k = 0; k < B; ++k) if (b0 + k < N) key[b0 + k] = valid[b0 + k] ? window_key<W>(w[k], g.ks, code) : 0xffffffffu;
+    }
+}
+
+// k_sort_tiny with GS_TINY2 (narrow): this round's key AND the next round's from one 16-byte window (8 bytes for plain 4-byte windows).
+// A tie run costs a random 64-byte sector per record and round whatever is read from it; the second key comes from the same sector
+// in seven cases of eight.  Zero padding behind the text makes the second key what the next round would have gathered.
+template <int N>
+__device__ __forceinline__ void gather_keys2(const GatherSpec& g, const u8* code, const u32 (&idx)[N], const bool (&valid)[N], u32 (&key)[N], u32 (&key2)[N])
+{
+    const bool plain = g.ks.cpk == 4u;                          // (kernel-uniform; packed keys: 5 .. 8 symbols, GS_TINY2 is not set beyond)
+    u32 w[N][4];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0;
+        if (valid[k]) {
+            const u64 pos = (u64)idx[k] + g.ks.depth;
+            if (pos < g.n) {                                    // (the text is padded with >= 64 zero bytes)
+                if (plain) __builtin_memcpy(w[k], g.text + pos, 8);
+                else __builtin_memcpy(w[k], g.text + pos, 16);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (!valid[k]) { key[k] = 0xffffffffu; key2[k] = 0xffffffffu; continue; }
+        key[k] = window_key<false>(w[k], g.ks, code);
+        const u64 lo = (u64)w[k][0] | ((u64)w[k][1] << 32), hi = (u64)w[k][2] | ((u64)w[k][3] << 32);
+        const u32 sh = 8u * g.ks.cpk;                           // 32 .. 64
+        const u64 s2 = sh >= 64u ? hi : ((lo >> sh) | (hi << (64u - sh)));
+        const u32 w2[4] = {(u32)s2, (u32)(s2 >> 32), 0u, 0u};
+        key2[k] = window_key<false>(w2, g.ks, code);
     }
 }
 
@@ -2986,8 +3020,9 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
     __shared__ u8 s_code[256];
     if (g.text) s_code[threadIdx.x] = code[threadIdx.x];
     constexpr int WIN = 256, HALO = TINY_MAX, TOT = WIN + HALO;
-    __shared__ u32 lkey[TOT], lrun[TOT];
+    __shared__ u32 lkey[TOT], lrun[TOT], lkey2[TOT];
     __shared__ u32 s_total, s_base, s_cb, s_ce, s_fb, s_fe;      // window total / base; chunk [cb, ce); pending fill [fb, fe)
+    const bool dbl = !W && !deep && g.text != nullptr && (g.flags & GS_TINY2) != 0u;      // two keys per gather (kernel-uniform)
     const u32 count = counters[cnt_idx];
     const u32 t = threadIdx.x;
     const u32 rank0 = counters[C_RANK0];
@@ -3016,7 +3051,15 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
             if constexpr (!W) {      // two-stage builds: the characters in front of the suffix, for the records that come out final (GatherSpec::pc_out)
                 if (g.pc_out) { ax[0] = valid[0] ? pc_fetch(g.text, (u32)fi[0]) : PC_UNKNOWN; ax[1] = valid[1] ? pc_fetch(g.text, (u32)fi[1]) : PC_UNKNOWN; }
             }
-            gather_keys<W, 2, 2>(g, s_code, fi, valid, key);
+            if constexpr (!W) {
+                if (dbl) {
+                    u32 key2[2];
+                    const u32 fi32[2] = {(u32)fi[0], (u32)fi[1]};
+                    gather_keys2<2>(g, s_code, fi32, valid, key, key2);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) if (have[k]) lkey2[t + k * WIN] = key2[k];
+                } else gather_keys<W, 2, 2>(g, s_code, fi, valid, key);
+            } else gather_keys<W, 2, 2>(g, s_code, fi, valid, key);
 #pragma unroll
             for (int k = 0; k < 2; ++k) if (have[k]) lkey[t + k * WIN] = key[k] >> KL;
         }
@@ -3040,6 +3083,23 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const u64* __restrict__ pool_
                         continue;
                     }
                     bool found = false;
+                    if (dbl) {                                   // ranked by (key, next key)
+                        const u32 my2 = lkey2[e];
+                        for (u32 q0 = 0; q0 < len; q0 += 4) {
+                            u32 kq[4], kr[4];
+#pragma unroll
+                            for (u32 i = 0; i < 4; ++i) { const u32 a = ls + (q0 + i < len ? q0 + i : len - 1u); kq[i] = lkey[a]; kr[i] = lkey2[a]; }
+#pragma unroll
+                            for (u32 i = 0; i < 4; ++i) {
+                                const u32 q = q0 + i;
+                                if (q < len) {
+                                    const bool same = kq[i] == my && kr[i] == my2;
+                                    n_lt[k] += (kq[i] < my) | ((kq[i] == my) & (kr[i] < my2));
+                                    if (same) { if (!found) { found = true; lead[k] = ls + q; } n_eq[k]++; n_eqb[k] += q < off; }
+                                }
+                            }
+                        }
+                    } else
                     for (u32 q0 = 0; q0 < len; q0 += 4) {       // four LDS reads in flight (the last ones clamped to the run)
                         u32 kq[4];
 #pragma unroll
