@@ -100,6 +100,8 @@ struct Switches {
     bool no_early_b = false;     // MSUFSORT_HIP_NO_EARLY_B: a host-pointer two-stage build sends rows from its last pass only (A / B)
     bool no_bwt_ride = false;    // MSUFSORT_HIP_NO_BWT_RIDE: the forward transform gathers its bytes after the build (A / B)
     bool no_tiny2 = false;       // MSUFSORT_HIP_NO_TINY2: k_sort_tiny ranks by one key per gather (A / B)
+    bool ind_pc_raw = false;     // MSUFSORT_HIP_IND_PC_RAW: the induction's rows carry three plain bytes whatever the alphabet (A / B)
+    bool ind_pc_bits5 = false;   // MSUFSORT_HIP_IND_PC_BITS=5: ... 5-bit dense numbers for 17 .. 32 byte values (tests; measured slower)
     int isa_window_kib = 256 << 10;      // MSUFSORT_HIP_ISA_WINDOW_MIB / _KIB (tests): piece of the rank array one pass of its build writes into (0: one pass)
     void load()
     {
@@ -123,6 +125,8 @@ struct Switches {
         no_early_b = on("MSUFSORT_HIP_NO_EARLY_B");
         no_bwt_ride = on("MSUFSORT_HIP_NO_BWT_RIDE");
         no_tiny2 = on("MSUFSORT_HIP_NO_TINY2");
+        ind_pc_raw = on("MSUFSORT_HIP_IND_PC_RAW");
+        ind_pc_bits5 = num("MSUFSORT_HIP_IND_PC_BITS", 0) == 5;
         isa_window_kib = std::max(0, on("MSUFSORT_HIP_ISA_WINDOW_KIB") ? num("MSUFSORT_HIP_ISA_WINDOW_KIB", 0) : std::min(1 << 20, num("MSUFSORT_HIP_ISA_WINDOW_MIB", 256)) << 10);
     }
 };

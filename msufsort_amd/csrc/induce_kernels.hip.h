@@ -15,9 +15,13 @@
 //   pass A, c0 = 0 .. 255: the rows of bucket c0, read left to right, put every A-type predecessor at the left end of the A
 //       area of bucket T[j-1] >= c0: levels over the A area (what lands in A(c0) itself feeds the next level), then the B area.
 //
-// Every row carries up to three characters in front of its suffix (pc[row] = T[j-1] | T[j-2] << 8 | T[j-3] << 16 | count << 24,
-// j = SA[row]), so a source costs no text access to find its target, and the row it induces inherits the remaining
-// characters: text is read (one unaligned 4-byte load) only for B* rows and for every third row of an induction chain.
+// Every row carries characters in front of its suffix (pc[row] = T[j-1] | older << 8 | count << 24, j = SA[row]), so a source costs
+// no text access to find its target, and the row it induces inherits the remaining characters.  `older` (16 bits): T[j-2], T[j-3] as
+// they are - or, for alphabets of up to 16 byte values (IndTables::pc_bits < 8, round 6), the DENSE NUMBERS of T[j-2] .. T[j-1-K],
+// K = 16 / pc_bits: 4 older characters for 16 values, 8 for a DNA.  The text is read (one unaligned load) only for B* rows the
+// first stage left without characters and for every (K + 1)-th row of an induction chain - every third row with plain bytes, every
+// ninth for a DNA (a fetch is a random 64-byte sector: 17 - 22 ps each at the rate the levels sustain,
+// profiles/r06_induction_lookback_window_and_fetch_slope.txt).
 // Random text accesses of the whole second stage: about 1.3 per B* suffix, each a 128-byte line of HBM traffic (against a line
 // per tied suffix and key round in the sort-all path).
 #pragma once
@@ -173,6 +177,7 @@ struct IndTables {
     const u8* sym;          // [nb] the byte value of every dense number
     u32 nb;                 // dense numbers, rounded up to a multiple of 8: per-tile counts are kept as [tile][nb]
     u32 nsym;               // byte values in use
+    u32 pc_bits;            // bits per older character in pc[] (2 .. 5: dense numbers, 5 by switch only; 8: plain bytes)
 };
 
 #define IND_MAX_LEVELS 32768u
@@ -207,12 +212,46 @@ __global__ __launch_bounds__(256) void k_place_bstar(const u32* __restrict__ sst
 {
     const u32 key = keys[blockIdx.x];
     const u32 cnt = tb.sub_bs[key], src = tb.bs_off[key], dst = tb.sub_start[key];
-    for (u32 i = blockIdx.y * 256u + threadIdx.x; i < cnt; i += gridDim.y * 256u) { sa[dst + i] = sstar[src + i]; pc[dst + i] = spc ? spc[src + i] : PC_UNKNOWN; }
+    const u32 bits = tb.pc_bits;
+    for (u32 i = blockIdx.y * 256u + threadIdx.x; i < cnt; i += gridDim.y * 256u) {
+        sa[dst + i] = sstar[src + i];
+        u32 v = spc ? spc[src + i] : PC_UNKNOWN;
+        if (v != PC_UNKNOWN && bits != 8u) {         // the sorts leave plain bytes (pc_fetch): the older ones become dense numbers
+            const u32 n_ch = v >> 24;
+            u32 older = 0;
+            if (n_ch >= 2u) older |= (u32)tb.code[(v >> 8) & 255u];
+            if (n_ch >= 3u) older |= (u32)tb.code[(v >> 16) & 255u] << bits;
+            v = (v & 255u) | (older << 8) | (n_ch << 24);
+        }
+        pc[dst + i] = v;
+    }
 }
 
 // the (up to) three characters in front of suffix j and how many there are: pc_fetch (sa_kernels.hip.h; the sorts of the first stage
 // read them next to the keys they gather)
 __device__ __forceinline__ u32 ind_fetch(const u8* __restrict__ text, u32 j) { return pc_fetch(text, j); }
+// ... only T[j-1]: valid whatever the format of the older characters (count 1: the row it induces fetches its own)
+__device__ __forceinline__ u32 ind_fetch1(const u8* __restrict__ text, u32 j) { return j ? ((u32)text[j - 1u] | (1u << 24)) : 0u; }
+// ... in the format of the level: T[j-1], then up to K = 16 / bits older characters as dense numbers (codes: byte -> number, LDS)
+__device__ __forceinline__ u32 ind_fetch_p(const u8* __restrict__ text, u32 j, u32 bits, const u8* codes)
+{
+    if (bits == 8u) return pc_fetch(text, j);
+    const u32 K = 16u / bits;
+    if (j < 12u) {                                   // (the first bytes of the text: no 12-byte window in front)
+        if (j == 0u) return 0u;
+        const u32 cnt = j < K + 1u ? j : K + 1u;
+        u32 older = 0;
+        for (u32 k = 1; k < cnt; ++k) older |= (u32)codes[text[j - 1u - k]] << (bits * (k - 1u));
+        return (u32)text[j - 1u] | (older << 8) | (cnt << 24);
+    }
+    u32 w[3];
+    __builtin_memcpy(w, text + j - 12u, 12);         // byte 11 = T[j-1], byte 11 - k = T[j-1-k]
+    u32 older = 0;
+#pragma unroll
+    for (int k = 1; k <= 8; ++k)
+        if ((u32)k <= K) older |= (u32)codes[(w[(11 - k) >> 2] >> (8 * ((11 - k) & 3))) & 255u] << (bits * (u32)(k - 1));
+    return (w[2] >> 24) | (older << 8) | ((K + 1u) << 24);
+}
 
 #define IND_ITEMS 16
 #define IND_TILE (256u * IND_ITEMS)      // sources per tile: 256 threads x 16, wave-major rows of 64
@@ -236,7 +275,7 @@ __global__ __launch_bounds__(256) void k_ind_setup(IndState* __restrict__ st, In
     } else {
         u32 v = tb.bkt[t];
         const u32 last = text[n - 1];
-        if (t == last) { sa[v] = n - 1; pc[v] = ind_fetch(text, n - 1); ++v; }
+        if (t == last) { sa[v] = n - 1; pc[v] = ind_fetch1(text, n - 1); ++v; }
         st->cur[t] = v;
         if (t == 0) sa[0] = n;
     }
@@ -299,7 +338,7 @@ __global__ __launch_bounds__(256) void k_ind_count(const IndState* __restrict__ 
             if (row[i] != 0xffffffffu) { pcv[i] = pc[row[i]]; star[i] = star[i] && pcv[i] == PC_UNKNOWN; }
 #pragma unroll
         for (int i = 0; i < IND_ITEMS; ++i)
-            if (row[i] != 0xffffffffu && star[i]) pcv[i] = ind_fetch(text, j[i]);
+            if (row[i] != 0xffffffffu && star[i]) pcv[i] = ind_fetch1(text, j[i]);      // (diagnostic path: one character, any format)
 #pragma unroll
         for (int i = 0; i < IND_ITEMS; ++i) {
             const bool in = row[i] != 0xffffffffu;
@@ -379,9 +418,12 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     __shared__ u32 s_fail;
     __shared__ u8 s_codes[256];            // dense number of every byte value (255: not in use; all 256 in use: the identity)
+    __shared__ u8 s_syms[256];             // ... and back
+    const u32 pbits = tb.pc_bits;          // (workgroup-uniform)
     __syncthreads();
     if (t == 0) s_fail = 0u;
     s_codes[t] = (u8)my_code;
+    s_syms[t] = t < tb.nb ? tb.sym[t] : (u8)0;
 #pragma unroll
     for (int w2 = 0; w2 < 4; ++w2) wcnt[w2][t] = 0;
     if (MODE == 0) goff[t] = (my_code != 255u || tb.nb == 256u) ? tile_hist[(u64)tile * tb.nb + my_code] : 0u;
@@ -407,7 +449,7 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
 #pragma unroll
         for (int i = 0; i < IND_ITEMS; ++i) {
             const u32 q = tile * IND_TILE + wv * (IND_ITEMS * 64u) + i * 64u + lane;
-            if (q < cnt && npc[i] == PC_UNKNOWN) { starmask |= 1u << i; npc[i] = ind_fetch(text, j[i]); }
+            if (q < cnt && npc[i] == PC_UNKNOWN) { starmask |= 1u << i; npc[i] = ind_fetch_p(text, j[i], pbits, s_codes); }
         }
     }
 #pragma unroll
@@ -417,12 +459,15 @@ __device__ __forceinline__ void ind_tile(IndState* st, const IndLevel& lv, const
             const u32 w = npc[i];
             if ((starmask >> i) & 1u) pc[hi - 1u - q] = w;
             bin[i] = ind_bin(lv, j[i], w);
-            npc[i] = ((w >> 8) & 0xffffu) | (((w >> 24) - 1u) << 24);          // the new row inherits my other characters
+            // the new row inherits my other characters: the next one as a byte again, the rest move down
+            const u32 older = (w >> 8) & 0xffffu;
+            if (pbits == 8u) npc[i] = older | (((w >> 24) - 1u) << 24);
+            else npc[i] = (u32)s_syms[older & ((1u << pbits) - 1u)] | ((older >> pbits) << 8) | (((w >> 24) - 1u) << 24);
         }
     }
 #pragma unroll
     for (int i = 0; i < IND_ITEMS; ++i)
-        if (bin[i] < 256u && (npc[i] >> 24) == 0u) npc[i] = ind_fetch(text, j[i] - 1u);                // ... or fetches its own
+        if (bin[i] < 256u && (npc[i] >> 24) == 0u) npc[i] = ind_fetch_p(text, j[i] - 1u, pbits, s_codes);                // ... or fetches its own
     const u32 nbits = tb.nsym > 1u ? 32u - (u32)__builtin_clz(tb.nsym - 1u) : 1u;     // bits of a dense byte number: 5 for a text, 3 for DNA
 #pragma unroll
     for (int i = 0; i < IND_ITEMS; ++i) {

@@ -786,6 +786,39 @@ def test_two_stage_generators(M, oracle_mod, kind, n, seed):
     _two_stage(M, oracle_mod, gen.GENERATORS[kind](n, seed), taken=kind != "dna_tandem")
 
 
+@pytest.mark.parametrize("sigma", [2, 3, 4, 7, 8, 13, 16, 17, 29, 32])
+def test_two_stage_rows_carry_dense_numbers(M, oracle_mod, monkeypatch, sigma):
+    """The induction's rows carry the characters in front of their suffixes as dense numbers of 2 / 3 / 4 bits for alphabets of up to
+    4 / 8 / 16 byte values (5 bits up to 32 by switch), plain bytes beyond: every width, the switch to plain bytes, runs of one byte,
+    suffixes near the start of the text (no 12-byte window in front) - rows and transformed bytes against the sort-all build."""
+    import torch
+    rng = np.random.default_rng(1000 + sigma)
+    syms = np.sort(rng.choice(np.arange(1, 256), size=sigma, replace=False)).astype(np.uint8)
+    n = 700001
+    body = syms[(rng.integers(0, sigma, size=n) * rng.integers(0, 2, size=n)) % sigma]      # skewed: half the positions are the first symbol
+    body[1000:1400] = syms[-1]                                                                # a run
+    body[:3] = syms[[0, sigma - 1, 0]]
+    t = np.ascontiguousarray(body)
+    ctx = M.DeviceContext(0)
+    d = _dev(M, t)
+    ref = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ctx.make_sa(d, n, ref, two_stage=-1)
+    assert ctx.validate_sa(d, n, ref) == 0
+    bref = torch.empty(n, dtype=torch.uint8, device="cuda")
+    sref = ctx.bwt_from_sa(d, n, ref, bref)
+    for env in ({}, {"MSUFSORT_HIP_IND_PC_RAW": "1"}, {"MSUFSORT_HIP_IND_PC_BITS": "5"}):
+        for k in ("MSUFSORT_HIP_IND_PC_RAW", "MSUFSORT_HIP_IND_PC_BITS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        ctx.make_sa(d, n, sa, two_stage=1)
+        assert ctx.timings().bstar_suffixes > 0
+        assert torch.equal(sa, ref)
+        b = torch.empty(n, dtype=torch.uint8, device="cuda")
+        assert ctx.forward_bwt(d, n, b, two_stage=1) == sref and torch.equal(b, bref)
+
+
 def test_two_stage_edges(M, oracle_mod):
     rng = np.random.default_rng(3)
     body = gen.text_bytes(200000, 11)
