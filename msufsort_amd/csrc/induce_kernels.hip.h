@@ -39,14 +39,23 @@
 // ---- suffix types: bitmap of the B* positions ----
 // diag[c] += B positions whose next byte is the same byte c.  (With different bytes the pair decides the type: the 16-bit
 // histogram of all suffixes already is the histogram of the B suffixes above the diagonal, and zero below it.)
+// Since round 6 also what k_maxrun counted in a pass of its own: the longest run of every byte value (2 or more; = the number of levels
+// an induction pass needs inside that byte's bucket) and runs[c][k] = runs of byte c that are k + 2 long (k = 7: nine or more), the
+// bounds for the sizes of the deeper levels.  A run belongs to the thread that holds its FIRST byte; the type bits F already say
+// where neighbouring bytes differ.
 __global__ __launch_bounds__(TY_THREADS) void k_types(const u8* __restrict__ text, u64 n, u32* __restrict__ bs_bits,
-                                                      u32* __restrict__ flags, u32* __restrict__ diag /* 256, zeroed */)
+                                                      u32* __restrict__ flags, u32* __restrict__ diag /* 256, zeroed */,
+                                                      u32* __restrict__ maxrun /* 256, zeroed */, u32* __restrict__ runs /* 256 x 8, zeroed */)
 {
     __shared__ u32 s_has[TY_THREADS / 64], s_first[TY_THREADS / 64];
     __shared__ u32 s_carry;
     __shared__ u32 s_diag[256];
+    __shared__ u32 s_max[256];
+    __shared__ u32 s_runs[256 * 8];
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     s_diag[t] = 0;
+    s_max[t] = 0;
+    for (u32 i = t; i < 2048u; i += TY_THREADS) s_runs[i] = 0;
     // (a workgroup takes many tiles and adds its diagonal counts to the global ones once: every such add is an atomic on one
     // of a few dozen addresses, which the memory system serves one after the other)
     const u64 ntiles = (n + TY_TILE - 1) / TY_TILE;
@@ -112,57 +121,54 @@ __global__ __launch_bounds__(TY_THREADS) void k_types(const u8* __restrict__ tex
     }
     const u32 nxt = (tb >> 1) | (carry << 31);
     bs_bits[base >> 5] = tb & ~nxt;
+    // byte i of my 32 (i varies per lane: the word is picked with selects, indexing w[] with it would put the array into scratch)
+    auto byte_at = [&](u32 i) {
+        const u32 q = i >> 2;
+        const u32 lo4 = q & 2u ? (q & 1u ? w[3] : w[2]) : (q & 1u ? w[1] : w[0]), hi4 = q & 2u ? (q & 1u ? w[7] : w[6]) : (q & 1u ? w[5] : w[4]);
+        return ((q & 4u ? hi4 : lo4) >> (8u * (i & 3u))) & 255u;
+    };
     const u32 eq = tb & ~F;                           // B positions inside a run of equal bytes
-    if (__ballot(eq != 0)) {                          // (static indexing: a loop over the set bits would put w[] into scratch)
+    if (__ballot(eq != 0)) {                          // (static indexing; a loop over the runs of set bits with byte_at: DNA 1.07 -> 1.17 ms per GiB)
 #pragma unroll
         for (int i = 0; i < 32; ++i)
             if ((eq >> i) & 1u) atomicAdd(&s_diag[(w[i >> 2] >> (8 * (i & 3))) & 255u], 1u);
     }
+    // runs of two or more equal bytes that START in my 32 positions: R bit i = byte i equals byte i + 1 (both inside the text)
+    {
+        const u32 R = ~F;
+        u32 before = (u32)__shfl_up((int)(w[7] >> 24), 1, 64);               // the byte in front of my first one
+        if (lane == 0) before = base != 0 && base < n ? text[base - 1] : 0x100u;
+        const u32 cont0 = before == (w[0] & 255u) ? 1u : 0u;
+        u32 S2 = R & ~((R << 1) | cont0);
+        {
+            while (S2) {                             // (a text: 0.6 starts per thread)
+                    const u32 i = (u32)__ffs((int)S2) - 1u;
+                    S2 &= S2 - 1u;
+                    const u32 ch = byte_at(i);
+                    const u32 rest = ~(R >> i);
+                    const u32 ones = rest ? (u32)__ffs((int)rest) - 1u : 32u;      // equal neighbours from i on, inside my word
+                    u32 len = ones + 1u;
+                    if ((u32)i + ones == 32u) {      // the run reaches my last byte and the first one behind it: how far does it go?
+                        bool open = true;
+#pragma unroll
+                        for (int k = 1; k < 4; ++k)
+                            if (open) { if (base + 32u + (u32)k < n && ((w[8] >> (8 * k)) & 255u) == ch) ++len; else open = false; }
+                        if (open) {
+                            u64 p = base + 36u;
+                            while (p < n && text[p] == ch && len < IND_MAXRUN_CAP) { ++p; ++len; }
+                        }
+                    }
+                    if (len >= IND_MAXRUN_CAP) atomicOr(flags, IND_FLAG_LONGRUN);
+                    if (len > s_max[ch]) atomicMax(&s_max[ch], len);
+                    atomicAdd(&s_runs[ch * 8u + (len > 9u ? 9u : len) - 2u], 1u);
+                }
+        }
+    }
     }
     __syncthreads();
     if (s_diag[t]) atomicAdd(&diag[t], s_diag[t]);
-}
-
-// longest run of every byte value (number of levels an induction pass needs inside that byte's bucket)
-// runs[c][k]: number of runs of byte c that are k + 2 long (k = 7: nine or more) - bounds for the sizes of the deeper levels
-__global__ __launch_bounds__(256) void k_maxrun(const u8* __restrict__ text, u64 n, u32* __restrict__ maxrun /* 256, zeroed */, u32* __restrict__ flags,
-                                                u32* __restrict__ runs /* 256 x 8, zeroed */)
-{
-    __shared__ u32 s_max[256];
-    __shared__ u32 s_runs[256 * 8];
-    const u32 t = threadIdx.x;
-    s_max[t] = 0;
-    for (u32 i = t; i < 2048u; i += 256u) s_runs[i] = 0;
-    __syncthreads();
-    for (u64 base = ((u64)blockIdx.x * 256u + t) * 16u; base < n; base += (u64)gridDim.x * 256u * 16u) {
-        const uint4 v = *reinterpret_cast<const uint4*>(text + base);
-        const u32 w[4] = {v.x, v.y, v.z, v.w};
-        u32 prev = base ? text[base - 1] : 0x100u;
-        u32 run_c = 0x100u, run_len = 0;             // run that STARTS inside my 16 bytes and is still open
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const u32 ch = (w[i >> 2] >> (8 * (i & 3))) & 255u;
-            const bool in = base + i < n;
-            if (in && ch != prev) {
-                if (run_c < 256u) {
-                    if (run_len > s_max[run_c]) atomicMax(&s_max[run_c], run_len);
-                    if (run_len >= 2u) atomicAdd(&s_runs[run_c * 8u + (run_len > 9u ? 9u : run_len) - 2u], 1u);
-                }
-                run_c = ch; run_len = 1;
-            } else if (in && run_c < 256u) ++run_len;
-            if (in) prev = ch;
-        }
-        if (run_c < 256u) {                          // my last run may continue behind my bytes
-            u64 p = base + 16;
-            while (p < n && text[p] == run_c && run_len < IND_MAXRUN_CAP) { ++p; ++run_len; }
-            if (run_len >= IND_MAXRUN_CAP) atomicOr(flags, IND_FLAG_LONGRUN);
-            if (run_len > s_max[run_c]) atomicMax(&s_max[run_c], run_len);
-            if (run_len >= 2u) atomicAdd(&s_runs[run_c * 8u + (run_len > 9u ? 9u : run_len) - 2u], 1u);
-        }
-    }
-    __syncthreads();
     if (s_max[t]) atomicMax(&maxrun[t], s_max[t]);
-    for (u32 i = t; i < 2048u; i += 256u) if (s_runs[i]) atomicAdd(&runs[i], s_runs[i]);
+    for (u32 i = t; i < 2048u; i += TY_THREADS) if (s_runs[i]) atomicAdd(&runs[i], s_runs[i]);
 }
 
 // ---- tables of the row layout (made on the host from the three histograms) ----
@@ -668,7 +674,7 @@ __global__ __launch_bounds__(256, IND_WAVES) void k_ind_fused(IndState* st, IndL
     }
 }
 
-// Levels that are known to be short (at most one tile, from the run-length counts of k_maxrun): ONE workgroup takes all the
+// Levels that are known to be short (at most one tile, from the run-length counts of k_types): ONE workgroup takes all the
 // remaining levels of a bucket, one after the other - most levels of a text are a handful of rows, and a level of three
 // launches costs more than it computes.
 __global__ __launch_bounds__(256) void k_ind_small(IndState* st, IndLevel lv, u32 nlevels, u32* sa, u32* pc, const u8* __restrict__ text, IndTables tb)
