@@ -277,6 +277,9 @@ int msufsort_hip_plan_cuts(const uint64_t* bstart, int64_t n, int64_t z, int32_t
  *      (n > 2^31 - 2, or opts->force_wide: through the wide engine and int64 rows) */
 int msufsort_hip_forward_bwt(uint8_t* inout, int64_t n, int64_t* sentinel_row,
                              const msufsort_hip_opts* opts);
+/* d_bwt_out must not overlap d_text (BAD_ARG): the bytes are written while the text is still being read - after a two-stage build
+ * (text-like inputs) region by region beside the remaining induction levels, on the context's second stream; the call returns when
+ * both streams have finished. */
 int msufsort_hip_forward_bwt_dev(msufsort_hip_ctx* ctx, uint8_t* d_text, int64_t n,
                                  uint8_t* d_bwt_out /* n */, int64_t* sentinel_row,
                                  const msufsort_hip_opts* opts);

@@ -894,6 +894,9 @@ def test_two_stage_forward_bwt(M, oracle_mod):
         back = torch.empty(n, dtype=torch.uint8, device="cuda")
         ctx.inverse_bwt(b1, n, s1, back)
         assert torch.equal(back, d[:n])
+        with pytest.raises(Exception):                       # in place on the device: refused (the bytes are written while the text is read)
+            ctx.forward_bwt(d, n, d[8:], two_stage=1)
+        assert torch.equal(back, d[:n])
 
 
 def test_two_stage_fuzz(M, oracle_mod):

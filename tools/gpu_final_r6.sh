@@ -45,7 +45,7 @@ timeout 600 bash tools/gpu_sq_cmd.sh $O/pmc_sq_random.txt python3 $R/bench.py --
 MSUFSORT_HIP_LIB=$R/msufsort_amd/lib/libmsufsort_hip_prof_mid.so timeout 300 python tools/gpu_one.py text 1073741823 0 1 2>&1 | grep "mid prof" > $O/mid_prof_text.txt
 MSUFSORT_HIP_MID_SINGLE=1 MSUFSORT_HIP_LIB=$R/msufsort_amd/lib/libmsufsort_hip_prof_mid.so timeout 300 python tools/gpu_one.py text 1073741823 0 1 2>&1 | grep "mid prof" > $O/mid_prof_text_single.txt
 # A/B of the round's levers on this build
-for e in A=1 MSUFSORT_HIP_MID_SINGLE=1 MSUFSORT_HIP_NO_PCW=1; do for w in "text 1073741823" "dna 1073741823" "dna_tandem 268435456"; do set -- $w
+for e in A=1 MSUFSORT_HIP_MID_SINGLE=1 MSUFSORT_HIP_NO_PCW=1 MSUFSORT_HIP_NO_TINY2=1 MSUFSORT_HIP_IND_PC_RAW=1; do for w in "text 1073741823" "dna 1073741823" "dna_tandem 268435456"; do set -- $w
   echo "== $e $1" >> $O/levers_ab.txt; env $e timeout 300 python tools/gpu_one.py $1 $2 0 3 2>&1 | grep -E "build [12]|errors" >> $O/levers_ab.txt; done; done
 paste - - - - < $O/levers_ab.txt | cut -c1-120
 MSUFSORT_TEST_VERBOSE=1 timeout 300 python - > $O/text_rounds.txt 2>&1 <<'PY'
@@ -60,6 +60,11 @@ ctx = M.DeviceContext(0); sa = torch.empty(n + 1, dtype=torch.int32, device="cud
 ctx.make_sa(d, n, sa); ctx.make_sa(d, n, sa, verbose=1)
 tm = ctx.timings(); print("total", tm.total_ms, "induction", tm.other_ms, "front", tm.front_ms)
 PY
+# host-pointer calls on the 1 GiB text: the library's own timeline (results leave region by region), then the same calls with the round's host-side levers off
+MSUFSORT_HIP_HOST_TRACE=1 timeout 600 python tools/gpu_host_text.py text 1073741823 2 sa,fbwt 2>&1 | grep -v -E "slice copy|amdgpu.ids" > $O/host_trace_text.txt
+MSUFSORT_HIP_NO_EARLY_B=1 MSUFSORT_HIP_NO_BWT_RIDE=1 MSUFSORT_HIP_RING_PART=64 timeout 600 python tools/gpu_host_text.py text 1073741823 2 sa,fbwt 2>&1 | grep -v -E "host trace|amdgpu.ids" > $O/host_text_levers_off.txt
+grep -E "rep [12]" $O/host_trace_text.txt $O/host_text_levers_off.txt | cut -c1-160
+for e in A=1 MSUFSORT_HIP_NO_BWT_RIDE=1; do echo "== $e" >> $O/fbwt_dev_ab.txt; for w in text dna; do env $e timeout 300 python tools/gpu_fbwt_dev.py $w 1073741823 4 2>&1 | grep forward_bwt_dev >> $O/fbwt_dev_ab.txt; done; done; cat $O/fbwt_dev_ab.txt
 ./tools/microbench/bin/exp_lds_hist_ceiling > $O/microbench_lds_hist_ceiling.txt 2>&1; cat $O/microbench_lds_hist_ceiling.txt
 # small multi-rank lines (gloo, all ranks on the one GPU): plumbing, NOT performance figures
 export MSUFSORT_BENCH_BACKEND=gloo MSUFSORT_BENCH_ONE_DEVICE=1
