@@ -546,8 +546,9 @@ def config5_line(M, torch, ctx, dev, no_cpu):
     # index); a doubling step reads row + group head (12), gathers the rank of suffix + h (8) and writes row + head (12) per row it scans
     m = int(tm.m)
     dbl_rows = int(tm.doubling_records)
-    kern = {"k_hist16": (tm.hist16_ms, n),
-            f"k_scatter0 (x{G} shards)": (tm.scatter0_ms, G * n + 8 * m),
+    # (the plan - the 16-bit histogram of the text and the deeper histograms of its heavy two-byte keys, ~0.13 s - runs once per build in
+    # front of the shards and has no phase timer of its own: it is inside sa_ms / sa_device_ms, not in this table)
+    kern = {f"k_scatter0 (x{G} shards)": (tm.scatter0_ms, G * n + 8 * m),
             "k_partition(level 1)": (tm.scatter1_ms, 16 * m),
             "round-0 LDS sorts (k_sort_mid/k_sort_tiny)": (tm.bucket_sort_ms, 16 * m),
             "key rounds (k_refill + k_partition levels + LDS sorts)": (tm.refine_ms, 24 * int(tm.gathered_records)),
