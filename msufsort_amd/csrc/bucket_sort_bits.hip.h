@@ -89,6 +89,13 @@ __global__ __launch_bounds__(THREADS, 1024 / THREADS) void k_sort_bits(RecBufs b
         }
     }
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform, in a scalar register
+    // The words start out zero and every segment leaves them zero again: they are cleared while its rows go out (they are dead from
+    // the end of phase D on), under the barrier that closes the segment - not in a phase and behind a barrier of their own at the
+    // start of the next one (round 6: 1,900 of a segment's 25,700 clocks, profiles/r06_bits_prof.txt)
+#define BITS_CLEAR() do { uint4* z_ = reinterpret_cast<uint4*>(bw); const uint4 z4_ = {0u, 0u, 0u, 0u}; \
+        _Pragma("unroll") for (u32 i_ = 0; i_ < 4; ++i_) z_[i_ * THREADS + threadIdx.x] = z4_; if (threadIdx.x == 0) z_[NW / 4] = z4_; } while (0)
+    BITS_CLEAR();
+    __syncthreads();
 #ifdef BITS_PROF
     __shared__ unsigned long long prof_acc[16];
     unsigned long long prof_last = clock64();
@@ -123,13 +130,10 @@ __global__ __launch_bounds__(THREADS, 1024 / THREADS) void k_sort_bits(RecBufs b
         bool ok = kbits <= 30u && len != 0 && len <= (u32)LEN_MAX;       // (key_out must fit 32 bits: (2^GB + 16) << (kbits - GB))
         u32 res_t = 0, res_s = 0;
 
-        if (ok) {                                                // ---- clear the words
+        if (ok) {
+            // (the flags: nobody reads them between the barrier that closed the previous segment and barrier (2); the first writer
+            // is the scan's last thread, behind (3))
             if (t < 16) misc[t] = 0;
-            uint4* z = reinterpret_cast<uint4*>(bw);
-            const uint4 z4 = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (u32 i = 0; i < 4; ++i) z[i * THREADS + t] = z4;
-            if (t == 0) z[NW / 4] = z4;
             // the lanes of the segment's last, partly filled row that lie outside it get the key of the spare word: from
             // here on no phase needs a bounds test
             if (len & 127u) {
@@ -140,8 +144,8 @@ __global__ __launch_bounds__(THREADS, 1024 / THREADS) void k_sort_bits(RecBufs b
                         if (BITS_P(2 * q + 1) >= len) key[2 * q + 1] = key_out;
                     }
             }
-            __syncthreads();                                                        // (1)
         }
+        const bool touched = ok;                                 // phase A runs: the words need clearing afterwards
         BPROF(0);
         BITS_LOAD(0, LB);
         const u32 shw = sh + 2u;                                 // byte offset of a key's word: (key >> shw) & ~3
@@ -326,6 +330,7 @@ __global__ __launch_bounds__(THREADS, 1024 / THREADS) void k_sort_bits(RecBufs b
         }
         BPROF(7);
         BITS_LOAD(4 * LB, NL);
+        if (touched) BITS_CLEAR();                               // (block-uniform; nothing reads the words any more)
         if (ok) {                                                // ---- rows out
             const u32 nt = misc[4];
             if (t == 0 && nt != 0) {
@@ -389,4 +394,5 @@ __global__ __launch_bounds__(THREADS, 1024 / THREADS) void k_sort_bits(RecBufs b
 #undef BITS_SRC
 #undef BITS_LOAD
 #undef BITS_WORD
+#undef BITS_CLEAR
 }
