@@ -56,7 +56,7 @@ typedef struct msufsort_hip_opts {
     int32_t force_wide;        /* int64 entry points: use the wide (40-bit index) engine also below 2^31 - 1 bytes (parity tests) */
     int32_t two_stage;         /* msufsort_hip_make_sa_i32_dev (and what is built on it: forward BWT, host-pointer entry points):
                                   0 = sort only the B* suffixes and induce the others (the reference's two stages, cpp:1496-1555 +
-                                  cpp:646-1057) when the input looks like text or DNA (4..128 byte values in use; at least 80 MiB,
+                                  cpp:646-1057) when the input looks like text or DNA (4..128 byte values in use; at least 136 MiB,
                                   320 MiB below 16 values; no very long runs of one byte), 1 = whenever possible, -1 = never; inputs that do not suit (or
                                   whose B* suffixes tie too deep) are sorted completely, as before */
     int32_t reuse_plan;        /* msufsort_hip_make_sa_shard*_dev: 1 = this call builds ANOTHER shard of the text the previous shard call on this

@@ -1067,7 +1067,7 @@ def test_host_entry_points_fresh_result(M, oracle_mod):
     assert (M.reverse_burrows_wheeler_transform(b, s) == t2).all()
 
 
-@pytest.mark.parametrize("kind,n,two_stage", [("text", (84 << 20) + 3, 0), ("dna", (66 << 20) + 1, 1)])
+@pytest.mark.parametrize("kind,n,two_stage", [("text", (84 << 20) + 3, 1), ("dna", (66 << 20) + 1, 1)])
 def test_host_two_stage_results_leave_while_the_build_goes_on(M, oracle_mod, monkeypatch, kind, n, two_stage):
     """Host-pointer calls on inputs that take the two-stage build: the rows (suffix array) and the bytes (forward transform) of a bucket
     region leave as soon as the region is final - B regions from the right-to-left pass already, the bytes written on a second
