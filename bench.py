@@ -378,7 +378,9 @@ def kernel_table(phases, K, n, workload, ops, ibwt_us):
     }
     if two_stage:
         rows_read = phases[-1].b_suffixes + n        # pass B reads the B rows, pass A every row
-        fetches = mstar + (n - mstar) / 3            # one 4-byte text fetch per B* suffix and per third induced suffix
+        # one text fetch per B* suffix and per induced suffix that has used its characters up: the rows carry three plain bytes, or - for
+        # alphabets of up to 16 byte values (a DNA) - up to nine characters as dense numbers: every third / ninth row of a chain
+        fetches = mstar + (n - mstar) / (9 if workload.startswith("dna") else 3)
         if os.environ.get("MSUFSORT_HIP_IND_CLASSIC"):
             # three kernels per level: rows read twice (count + scatter: 4 B index + 4 B characters each time)
             kern["induction (k_ind_count + k_ind_scan + k_ind_scatter)"] = (avg("other_ms"), int(16 * rows_read + 8 * (n - mstar) + 4 * fetches))
