@@ -70,6 +70,14 @@ if txt:
     out["entries"]["text"] = {"n": n, "source": "profiles/r06_pmc_traffic_text_sa.txt", "kernels": ent,
                               "raw_fetch_plus_write": {"induction (k_ind_fused + k_ind_small)": int(total(txt, "k_ind_fused", "k_ind_small") - total(txt, "k_ind_fused", "k_ind_small", field="fetch_raw")),
                                                        "key rounds (k_refill + k_partition levels + LDS sorts)": int(total(txt, *key_p) - total(txt, *key_p, field="fetch_raw"))}}
+dna = passes("pmc_traffic_dna.txt")
+if dna:
+    key_p = ("k_sort_mid", "k_sort_tiny", "k_count", "k_refill", "k_carry_copy", "k_sort_fast2")
+    out["entries"]["dna"] = {"n": n, "source": "profiles/r06_pmc_traffic_dna.txt",
+                             "kernels": {"k_hist16": int(total(dna, "k_hist16<0>")), "k_scatter0": int(total(dna, "k_scatter0<false>")),
+                                         "induction (k_ind_fused + k_ind_small)": int(total(dna, "k_ind_fused", "k_ind_small")),
+                                         "key rounds (k_refill + k_partition levels + LDS sorts)": int(total(dna, *key_p))},
+                             "raw_fetch_plus_write": {"induction (k_ind_fused + k_ind_small)": int(total(dna, "k_ind_fused", "k_ind_small") - total(dna, "k_ind_fused", "k_ind_small", field="fetch_raw"))}}
 if wlk and "text" in out["entries"]:
     out["entries"]["text"]["kernels"]["k_ibwt_walk"] = int(total(wlk, "k_ibwt_walk"))
     out["entries"]["text"]["kernels"]["k_lcp"] = int(total(wlk, "k_lcp"))

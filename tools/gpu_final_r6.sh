@@ -34,6 +34,7 @@ head -12 $O/kernel_stats_random.txt | cut -c1-150
 timeout 600 bash tools/gpu_pmc_cmd.sh $O/pmc_traffic_random.txt python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-configs --no-host > /dev/null 2>&1; head -5 $O/pmc_traffic_random.txt
 timeout 600 bash tools/gpu_pmc_cmd.sh $O/pmc_traffic_random_256MiB.txt python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-configs --no-host --size 268435456 > /dev/null 2>&1
 timeout 600 bash tools/gpu_pmc_cmd.sh $O/pmc_traffic_text_sa.txt python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --workload text --op sa --no-configs --no-host > /dev/null 2>&1
+timeout 600 bash tools/gpu_pmc_cmd.sh $O/pmc_traffic_dna.txt python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --workload dna --op sa --no-configs --no-host > /dev/null 2>&1
 timeout 600 bash tools/gpu_pmc_cmd.sh $O/pmc_traffic_text_ibwt_lcp.txt python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --workload text --op sa,bwt,ibwt,lcp --no-configs --no-host > /dev/null 2>&1
 timeout 600 bash tools/gpu_pmc_cmd.sh $O/pmc_traffic_dna_tandem_256MiB.txt python3 $R/tools/gpu_one.py dna_tandem 268435456 0 1 > /dev/null 2>&1
 CFG5_CHECK=0 PHASE_SPLIT="k_isa_from_slice<true>" timeout 1500 bash tools/gpu_pmc_cmd.sh $O/pmc_traffic_cfg5.txt python3 $R/tools/gpu_cfg5.py 33 1 32 > /dev/null 2>&1; grep PHASE $O/pmc_traffic_cfg5.txt
